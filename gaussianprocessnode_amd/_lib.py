@@ -1,0 +1,122 @@
+"""ctypes binding of the C ABI declared in include/sgp_hip.h.
+
+The product path has no CPU fallback: if the library is missing or no gfx950 device is visible the
+calls raise.  (`oracle/` is test infrastructure and is never imported from this package.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+SGP_FLAG_NO_GRAPH = 1
+SGP_FLAG_KEEP_KUF = 2
+SGP_S_YY, SGP_S_W, SGP_S_N, SGP_S_COUNT = 0, 1, 2, 8
+(SGP_R_SUM_I1, SGP_R_SUM_I2, SGP_R_ENERGY, SGP_R_INFO_KUU, SGP_R_INFO_LAMBDA, SGP_R_INFO_PRIOR,
+ SGP_R_LOGDET_KUU, SGP_R_LOGDET_LAMBDA, SGP_R_COUNT) = range(9)
+SGP_T_COUNT = 8
+
+EXPORTS = [
+    "sgp_abi_version", "sgp_create", "sgp_destroy", "sgp_last_error", "sgp_set_inducing", "sgp_set_data",
+    "sgp_set_kernel", "sgp_set_prior", "sgp_set_noise", "sgp_sweep_local", "sgp_sweep_finish", "sgp_sweep",
+    "sgp_stats_layout", "sgp_bind_stats", "sgp_get_posterior", "sgp_get_scalars", "sgp_get_stats",
+    "sgp_get_kuu_chol", "sgp_get_wishart_invscale", "sgp_w_stats", "sgp_predict", "sgp_theta_objective",
+    "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps",
+]
+
+
+class SGPError(RuntimeError):
+    """Negative status from the C ABI (bad argument, HIP error, no device)."""
+
+
+class PosDefException(ArithmeticError):
+    """Positive status k: leading minor k is not positive definite (Julia's PosDefException(k))."""
+
+    def __init__(self, k, msg=""):
+        super().__init__(f"matrix is not positive definite; Cholesky failed at minor {k}. {msg}")
+        self.info = k
+
+
+class Config(C.Structure):
+    _fields_ = [("n_max", C.c_int64), ("m", C.c_int32), ("d", C.c_int32), ("d_out", C.c_int32),
+                ("device", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """Load csrc/libsgp_hip.so (building it first if hipcc is available).  Raises if it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise SGPError(f"{path} is missing: build it with `python -m gaussianprocessnode_amd._build`")
+        _build.build()
+    lib = C.CDLL(path)
+    dp = C.POINTER(C.c_double)
+    vp = C.c_void_p
+    lib.sgp_abi_version.restype = C.c_int
+    lib.sgp_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.sgp_destroy.argtypes = [vp]
+    lib.sgp_last_error.argtypes = [vp]
+    lib.sgp_last_error.restype = C.c_char_p
+    lib.sgp_set_inducing.argtypes = [vp, dp]
+    lib.sgp_set_data.argtypes = [vp, dp, dp, dp, dp, C.c_int64, C.c_double]
+    lib.sgp_set_kernel.argtypes = [vp, C.c_double, dp, C.c_int32, C.c_double]
+    lib.sgp_set_prior.argtypes = [vp, dp, dp, C.c_int32]
+    lib.sgp_set_noise.argtypes = [vp, dp, C.c_double]
+    for name in ("sgp_sweep_local", "sgp_sweep_finish", "sgp_sweep"):
+        getattr(lib, name).argtypes = [vp, vp]
+    lib.sgp_stats_layout.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    lib.sgp_bind_stats.argtypes = [vp, vp]
+    lib.sgp_get_posterior.argtypes = [vp, dp, dp, dp]
+    lib.sgp_get_scalars.argtypes = [vp, dp]
+    lib.sgp_get_stats.argtypes = [vp, dp, dp, dp]
+    lib.sgp_get_kuu_chol.argtypes = [vp, dp]
+    lib.sgp_get_wishart_invscale.argtypes = [vp, dp]
+    lib.sgp_w_stats.argtypes = [vp, dp, dp, vp]
+    lib.sgp_predict.argtypes = [vp, dp, C.c_int64, dp, dp]
+    lib.sgp_theta_objective.argtypes = [vp, dp, dp]
+    lib.sgp_kernelmatrix.argtypes = [C.c_int32, dp, C.c_int64, dp, C.c_int64, C.c_int32, C.c_double, dp, C.c_int32, dp]
+    lib.sgp_potrf.argtypes = [C.c_int32, dp, C.c_int32, dp]
+    lib.sgp_potri.argtypes = [C.c_int32, dp, C.c_int32, dp]
+    lib.sgp_get_timestamps.argtypes = [vp, C.POINTER(C.c_int64)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name != "sgp_last_error":
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def as_f64(a, shape=None):
+    """C-contiguous float64 view/copy (the memory layout the ABI expects: points along axis 0)."""
+    arr = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and arr.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {arr.shape}")
+    return arr
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def check(rc: int, handle=None, what: str = ""):
+    if rc == 0:
+        return
+    lib = load()
+    msg = lib.sgp_last_error(handle)
+    msg = msg.decode() if msg else ""
+    if rc > 0:
+        raise PosDefException(rc, f"{what} {msg}")
+    raise SGPError(f"{what} failed with status {rc}: {msg}")

@@ -1,0 +1,768 @@
+// sgp_api.hip -- C ABI (include/sgp_hip.h) over the gfx950 kernels of sgp_kernels.hip.h.
+//
+// The handle owns every device buffer of one rank's shard; a sweep is two launch sequences
+// (sgp_sweep_local, sgp_sweep_finish) with the packed statistics buffer as the only hand-off, so that a
+// multi-GPU caller can sum-all-reduce that buffer in between (RCCL through torch.distributed).  Each
+// sequence is captured once into a hipGraph and replayed (the tail is a chain of ~70 small dependent
+// kernels: eager launches would be host-bound); per-sweep scalars travel through a pinned Params block
+// that the graph's first node copies to the device.
+#include "../../include/sgp_hip.h"
+#include "sgp_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+using namespace sgp;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int64_t key_n = -1;
+    int key_prior = -1;
+    void* key_stats = nullptr;
+    bool valid = false;
+    void reset() {
+        if (exec) hipGraphExecDestroy(exec);
+        if (graph) hipGraphDestroy(graph);
+        exec = nullptr; graph = nullptr; valid = false;
+    }
+};
+
+}  // namespace
+
+struct sgp_handle {
+    sgp_config cfg{};
+    int M = 0, Mp = 0, D = 0, dout = 1, Q = 0, Qp = 0, T = 0, TQ = 0;
+    int64_t n = 0, n_max = 0;
+    double n_nodes = 0;
+    bool has_omega = false, has_yv = false, have_data = false, have_kernel = false, have_inducing = false;
+    int prior_form = 2;            // 1 dense precision, 2 isotropic
+    bool swept_local = false, swept = false;
+    int n_ell = 1;
+    // device buffers
+    double *dXu = nullptr, *dXus = nullptr, *dX = nullptr, *dYw = nullptr, *dY = nullptr, *dYv = nullptr, *dOmega = nullptr;
+    double *dKuf = nullptr, *dBpart = nullptr, *dSlabs = nullptr, *dStatsOwn = nullptr, *dStats = nullptr, *dDataScal = nullptr;
+    double *dKuu = nullptr, *dWk = nullptr, *dKinv = nullptr;
+    double *dLam = nullptr, *dWl = nullptr, *dSigma = nullptr, *dR = nullptr, *dXi = nullptr, *dMu = nullptr;
+    double *dLambda0 = nullptr, *dXi0 = nullptr, *dOut = nullptr, *dWishart = nullptr, *dTrace = nullptr, *dTmp = nullptr;
+    double *dPa = nullptr, *dPb = nullptr;
+    int* dInfo = nullptr;
+    int64_t* dStamps = nullptr;
+    Params* hParams = nullptr;     // pinned
+    Params* dParams = nullptr;
+    hipStream_t own = nullptr, side = nullptr;
+    hipEvent_t evFork = nullptr, evSide = nullptr;
+    int nchunks = 1, chunk = 0, nblk = 0, ntiles = 0;
+    int64_t stats_count = 0;
+    size_t slab_capacity = 0;
+    Graph gLocal, gFinish;
+    std::string err;
+};
+
+#define HIPCHK(h, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            char buf_[512];                                                                               \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            if (h) (h)->err = buf_; else g_create_error = buf_;                                           \
+            return SGP_ERR_HIP;                                                                           \
+        }                                                                                                 \
+    } while (0)
+
+static int fail(sgp_handle* h, int code, const char* msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------
+// dense building blocks (launch sequences)
+// ------------------------------------------------------------------------------------------------
+static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, hipStream_t s) {
+    for (int j = 0; j < Tn; ++j) {
+        hipLaunchKernelGGL(k_potrf_panel, dim3(Tn - j), dim3(256), 0, s, A, ld, j, info, n_valid);
+        int nt = Tn - 1 - j;
+        if (nt > 0) hipLaunchKernelGGL(k_potrf_trail, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, A, ld, j);
+    }
+}
+static void launch_trtri(const double* L, double* W, int ld, int Tn, hipStream_t s) {
+    hipLaunchKernelGGL(k_trtri_diag, dim3(Tn), dim3(256), 0, s, L, W, ld);
+    if (Tn > 1) hipLaunchKernelGGL(k_trtri_col, dim3(Tn - 1, 4), dim3(256), 0, s, L, W, ld, Tn);
+}
+static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s) {
+    hipLaunchKernelGGL(k_ata_lower, dim3(Tn * (Tn + 1) / 2), dim3(256), 0, s, W, C, ld, Tn);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int sgp_abi_version(void) { return SGP_ABI_VERSION; }
+
+extern "C" const char* sgp_last_error(const sgp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+template <typename T>
+static hipError_t dalloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+}
+
+extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
+    if (!cfg || !out) return fail(nullptr, SGP_ERR_ARG, "sgp_create: null argument");
+    *out = nullptr;
+    if (cfg->m < 1 || cfg->d < 1 || cfg->d > MAXD || cfg->d_out < 1 || cfg->d_out > MAXO || cfg->n_max < 1)
+        return fail(nullptr, SGP_ERR_ARG, "sgp_create: need m >= 1, 1 <= d <= 32, 1 <= d_out <= 4, n_max >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, SGP_ERR_NODEVICE, "sgp_create: no HIP device visible (the HIP path has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, SGP_ERR_ARG, "sgp_create: bad device ordinal");
+    HIPCHK((sgp_handle*)nullptr, hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIPCHK((sgp_handle*)nullptr, hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, SGP_ERR_NODEVICE, "sgp_create: device is not gfx950 (MI355X); this library is built for gfx950 only");
+
+    sgp_handle* h = new sgp_handle();
+    h->cfg = *cfg;
+    h->M = cfg->m; h->D = cfg->d; h->dout = cfg->d_out; h->n_max = cfg->n_max;
+    h->Mp = round_up(h->M, TB);
+    h->Q = h->dout * h->M;
+    h->Qp = round_up(h->Q, TB);
+    h->T = h->Mp / TB;
+    h->TQ = h->Qp / TB;
+    h->ntiles = h->T * (h->T + 1) / 2;
+    const size_t Mp = h->Mp, Qp = h->Qp, nmax = (size_t)h->n_max;
+    h->stats_count = (int64_t)(Mp * Mp + Mp * h->dout + SGP_S_COUNT + (size_t)h->dout * h->dout);
+    // worst-case slab count: enough chunks to put ~2 blocks on each of the 256 CUs
+    int max_chunks = std::max(1, (2 * 256 + h->ntiles - 1) / h->ntiles);
+    h->slab_capacity = (size_t)max_chunks * h->ntiles * TB * TB;
+    const size_t nblk_max = (nmax + TB - 1) / TB;
+
+#define ALLOC(ptr, count)                                            \
+    do {                                                             \
+        hipError_t e_ = dalloc(&(ptr), (count));                     \
+        if (e_ != hipSuccess) {                                      \
+            g_create_error = std::string("hipMalloc failed for " #ptr ": ") + hipGetErrorString(e_); \
+            sgp_destroy(h);                                          \
+            return SGP_ERR_NOMEM;                                    \
+        }                                                            \
+    } while (0)
+    ALLOC(h->dXu, (size_t)h->M * h->D);
+    ALLOC(h->dXus, Mp * h->D);
+    ALLOC(h->dX, nmax * h->D);
+    ALLOC(h->dYw, nmax * h->dout);
+    ALLOC(h->dY, nmax * h->dout);
+    ALLOC(h->dYv, nmax);
+    ALLOC(h->dOmega, nmax);
+    ALLOC(h->dKuf, Mp * nmax);
+    ALLOC(h->dBpart, nblk_max * h->dout * Mp);
+    ALLOC(h->dSlabs, h->slab_capacity);
+    ALLOC(h->dStatsOwn, (size_t)h->stats_count);
+    ALLOC(h->dDataScal, SGP_S_COUNT + (size_t)h->dout * h->dout);
+    ALLOC(h->dKuu, Mp * Mp);
+    ALLOC(h->dWk, Mp * Mp);
+    ALLOC(h->dKinv, Mp * Mp);
+    ALLOC(h->dLam, Qp * Qp);
+    ALLOC(h->dWl, Qp * Qp);
+    ALLOC(h->dSigma, Qp * Qp);
+    ALLOC(h->dR, Qp * Qp);
+    ALLOC(h->dTmp, Qp * Qp);
+    ALLOC(h->dLambda0, Qp * Qp);
+    ALLOC(h->dXi, Qp);
+    ALLOC(h->dMu, Qp);
+    ALLOC(h->dXi0, Qp);
+    ALLOC(h->dOut, SGP_R_COUNT);
+    ALLOC(h->dWishart, MAXO * MAXO);
+    ALLOC(h->dTrace, (size_t)TRACE_BLOCKS * TRACE_SLOTS);
+    ALLOC(h->dInfo, 4);
+    ALLOC(h->dStamps, 2 * SGP_T_COUNT);
+    ALLOC(h->dParams, 1);
+    if (cfg->flags & SGP_FLAG_KEEP_KUF) {
+        ALLOC(h->dPa, (size_t)h->T * nmax);
+        ALLOC(h->dPb, (size_t)h->T * nmax);
+    }
+#undef ALLOC
+    h->dStats = h->dStatsOwn;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->hParams), sizeof(Params), hipHostMallocDefault) != hipSuccess) {
+        g_create_error = "hipHostMalloc failed for the parameter block";
+        sgp_destroy(h);
+        return SGP_ERR_NOMEM;
+    }
+    memset(h->hParams, 0, sizeof(Params));
+    h->hParams->sigma2 = 1.0;
+    for (int d = 0; d < MAXD; ++d) h->hParams->inv_ell[d] = 1.0;
+    h->hParams->W[0] = 1.0;
+    h->hParams->prior_iso = 1.0;
+    if (hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evSide, hipEventDisableTiming) != hipSuccess) {
+        g_create_error = "stream/event creation failed";
+        sgp_destroy(h);
+        return SGP_ERR_HIP;
+    }
+    hipMemset(h->dInfo, 0, 4 * sizeof(int));
+    hipMemset(h->dOut, 0, SGP_R_COUNT * sizeof(double));
+    hipMemset(h->dStamps, 0, 2 * SGP_T_COUNT * sizeof(int64_t));
+    hipMemset(h->dMu, 0, Qp * sizeof(double));
+    hipMemset(h->dXi0, 0, Qp * sizeof(double));
+    *out = h;
+    return 0;
+}
+
+extern "C" int sgp_destroy(sgp_handle* h) {
+    if (!h) return 0;
+    hipSetDevice(h->cfg.device);
+    hipDeviceSynchronize();
+    h->gLocal.reset();
+    h->gFinish.reset();
+    void* bufs[] = {h->dXu, h->dXus, h->dX, h->dYw, h->dY, h->dYv, h->dOmega, h->dKuf, h->dBpart, h->dSlabs, h->dStatsOwn,
+                    h->dDataScal, h->dKuu, h->dWk, h->dKinv, h->dLam, h->dWl, h->dSigma, h->dR, h->dTmp, h->dLambda0,
+                    h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (h->hParams) hipHostFree(h->hParams);
+    if (h->evFork) hipEventDestroy(h->evFork);
+    if (h->evSide) hipEventDestroy(h->evSide);
+    if (h->own) hipStreamDestroy(h->own);
+    if (h->side) hipStreamDestroy(h->side);
+    delete h;
+    return 0;
+}
+
+extern "C" int sgp_set_inducing(sgp_handle* h, const double* Xu) {
+    if (!h || !Xu) return fail(h, SGP_ERR_ARG, "sgp_set_inducing: null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpy(h->dXu, Xu, sizeof(double) * h->M * h->D, hipMemcpyHostToDevice));
+    h->have_inducing = true;
+    h->swept = h->swept_local = false;
+    return 0;
+}
+
+extern "C" int sgp_set_data(sgp_handle* h, const double* X, const double* y_mean, const double* y_var,
+                            const double* pt_weight, int64_t n, double n_nodes) {
+    if (!h || !X || !y_mean) return fail(h, SGP_ERR_ARG, "sgp_set_data: null argument");
+    if (n < 0 || n > h->n_max) return fail(h, SGP_ERR_ARG, "sgp_set_data: n outside [0, n_max]");
+    if (y_var && h->dout != 1) return fail(h, SGP_ERR_ARG, "sgp_set_data: y_var is only defined for d_out = 1");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int dout = h->dout;
+    std::vector<double> yw((size_t)std::max<int64_t>(n, 1) * dout);
+    std::vector<double> scal(SGP_S_COUNT + (size_t)dout * dout, 0.0);
+    double s_w = 0.0;
+    for (int64_t i = 0; i < n; ++i) s_w += pt_weight ? pt_weight[i] : 1.0;
+    for (int o = 0; o < dout; ++o)
+        for (int64_t i = 0; i < n; ++i) yw[(size_t)o * n + i] = y_mean[(size_t)o * n + i] * (pt_weight ? pt_weight[i] : 1.0);
+    // Ryy[a][b] = sum_n omega y_a y_b (+ sum omega v for the scalar case)
+    for (int a = 0; a < dout; ++a)
+        for (int b = 0; b < dout; ++b) {
+            double s = 0.0;
+            for (int64_t i = 0; i < n; ++i) s += yw[(size_t)a * n + i] * y_mean[(size_t)b * n + i];
+            scal[SGP_S_COUNT + a + (size_t)b * dout] = s;
+        }
+    double s_yy = scal[SGP_S_COUNT];
+    if (y_var)
+        for (int64_t i = 0; i < n; ++i) s_yy += (pt_weight ? pt_weight[i] : 1.0) * y_var[i];
+    scal[SGP_S_YY] = s_yy;
+    if (dout == 1) scal[SGP_S_COUNT] = s_yy;
+    scal[SGP_S_W] = s_w;
+    scal[SGP_S_N] = (n_nodes > 0) ? n_nodes : (double)n;
+    if (n > 0) {
+        HIPCHK(h, hipMemcpy(h->dX, X, sizeof(double) * n * h->D, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->dYw, yw.data(), sizeof(double) * n * dout, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->dY, y_mean, sizeof(double) * n * dout, hipMemcpyHostToDevice));
+        if (y_var) HIPCHK(h, hipMemcpy(h->dYv, y_var, sizeof(double) * n, hipMemcpyHostToDevice));
+        if (pt_weight) HIPCHK(h, hipMemcpy(h->dOmega, pt_weight, sizeof(double) * n, hipMemcpyHostToDevice));
+    }
+    HIPCHK(h, hipMemcpy(h->dDataScal, scal.data(), sizeof(double) * scal.size(), hipMemcpyHostToDevice));
+    h->n = n;
+    h->n_nodes = scal[SGP_S_N];
+    h->has_omega = pt_weight != nullptr;
+    h->has_yv = y_var != nullptr;
+    h->have_data = true;
+    h->nblk = (int)((n + TB - 1) / TB);
+    // split the point axis so that tiles x chunks ~ 2 blocks per CU, chunk a multiple of the stage size
+    int want = std::max(1, (2 * 256 + h->ntiles - 1) / h->ntiles);
+    int64_t per = (n + want - 1) / want;
+    per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);
+    h->chunk = (int)per;
+    h->nchunks = (int)std::max<int64_t>(1, (n + per - 1) / per);
+    if ((size_t)h->nchunks * h->ntiles * TB * TB > h->slab_capacity)
+        return fail(h, SGP_ERR_ARG, "sgp_set_data: internal slab capacity exceeded");
+    h->swept = h->swept_local = false;
+    return 0;
+}
+
+extern "C" int sgp_set_kernel(sgp_handle* h, double sigma2, const double* ell, int32_t n_ell, double jitter) {
+    if (!h || !ell) return fail(h, SGP_ERR_ARG, "sgp_set_kernel: null argument");
+    if (n_ell != 1 && n_ell != h->D) return fail(h, SGP_ERR_ARG, "sgp_set_kernel: n_ell must be 1 or D");
+    if (!(sigma2 > 0.0) || !(jitter >= 0.0)) return fail(h, SGP_ERR_ARG, "sgp_set_kernel: sigma2 must be > 0, jitter >= 0");
+    for (int d = 0; d < h->D; ++d) {
+        double l = ell[n_ell == 1 ? 0 : d];
+        if (!(l > 0.0)) return fail(h, SGP_ERR_ARG, "sgp_set_kernel: lengthscales must be > 0");
+        h->hParams->inv_ell[d] = 1.0 / l;
+    }
+    h->hParams->sigma2 = sigma2;
+    h->hParams->jitter = jitter;
+    h->n_ell = n_ell;
+    h->have_kernel = true;
+    return 0;
+}
+
+extern "C" int sgp_set_noise(sgp_handle* h, const double* W, double E_log_w) {
+    if (!h || !W) return fail(h, SGP_ERR_ARG, "sgp_set_noise: null argument");
+    for (int i = 0; i < h->dout * h->dout; ++i) h->hParams->W[i] = W[i];
+    h->hParams->E_logw = E_log_w;
+    return 0;
+}
+
+// upload a Q x Q host matrix into a padded Qp x Qp device buffer (pad = identity)
+static int upload_padded(sgp_handle* h, const double* src, double* dst) {
+    const size_t Q = h->Q, Qp = h->Qp;
+    std::vector<double> tmp(Qp * Qp, 0.0);
+    for (size_t j = 0; j < Qp; ++j) {
+        if (j < Q) memcpy(&tmp[j * Qp], &src[j * Q], Q * sizeof(double));
+        else tmp[j * Qp + j] = 1.0;
+    }
+    HIPCHK(h, hipMemcpy(dst, tmp.data(), Qp * Qp * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int sgp_set_prior(sgp_handle* h, const double* vec, const double* mat, int32_t form) {
+    if (!h || !mat) return fail(h, SGP_ERR_ARG, "sgp_set_prior: null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t Q = h->Q, Qp = h->Qp;
+    if (form == 2) {
+        if (!(mat[0] > 0.0)) return fail(h, SGP_ERR_ARG, "sgp_set_prior: isotropic variance must be > 0");
+        h->hParams->prior_iso = 1.0 / mat[0];
+        h->prior_form = 2;
+        return 0;
+    }
+    if (!vec) return fail(h, SGP_ERR_ARG, "sgp_set_prior: null mean");
+    std::vector<double> v(Qp, 0.0);
+    memcpy(v.data(), vec, Q * sizeof(double));
+    if (form == 1) {
+        int rc = upload_padded(h, mat, h->dLambda0);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpy(h->dXi0, v.data(), Qp * sizeof(double), hipMemcpyHostToDevice));
+        h->prior_form = 1;
+        return 0;
+    }
+    if (form != 0) return fail(h, SGP_ERR_ARG, "sgp_set_prior: form must be 0, 1 or 2");
+    // mean + covariance: Lambda0 = Sigma0^-1 by Cholesky, xi0 = Lambda0 mu0 (ReactiveMP converts the
+    // MvNormalMeanCovariance prior before the first product, GPnode/UniSGPnode.jl:62-63)
+    int rc = upload_padded(h, mat, h->dTmp);
+    if (rc) return rc;
+    hipStream_t s = h->own;
+    HIPCHK(h, hipMemsetAsync(h->dInfo + 2, 0, sizeof(int), s));
+    launch_potrf(h->dTmp, h->Qp, h->TQ, h->dInfo + 2, h->Q, s);
+    launch_trtri(h->dTmp, h->dWl, h->Qp, h->TQ, s);
+    launch_ata(h->dWl, h->dLambda0, h->Qp, h->TQ, s);
+    HIPCHK(h, hipMemcpyAsync(h->dMu, v.data(), Qp * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_symv, dim3((h->Qp + 3) / 4), dim3(256), 0, s, h->dLambda0, h->dMu, h->dXi0, h->Qp, h->Qp);
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    int info = 0;
+    HIPCHK(h, hipMemcpy(&info, h->dInfo + 2, sizeof(int), hipMemcpyDeviceToHost));
+    h->prior_form = 1;
+    if (info > 0) { h->err = "sgp_set_prior: prior covariance is not positive definite"; return info; }
+    return 0;
+}
+
+extern "C" int sgp_stats_layout(const sgp_handle* h, void** stats_dev, int64_t* count, int32_t* mp) {
+    if (!h) return SGP_ERR_ARG;
+    if (stats_dev) *stats_dev = h->dStats;
+    if (count) *count = h->stats_count;
+    if (mp) *mp = h->Mp;
+    return 0;
+}
+
+extern "C" int sgp_bind_stats(sgp_handle* h, void* stats_dev) {
+    if (!h) return SGP_ERR_ARG;
+    h->dStats = stats_dev ? static_cast<double*>(stats_dev) : h->dStatsOwn;
+    h->gLocal.valid = false;
+    h->gFinish.valid = false;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch sequences
+// ------------------------------------------------------------------------------------------------
+static void enqueue_local(sgp_handle* h, hipStream_t s) {
+    const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
+    hipMemcpyAsync(h->dParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice, s);
+    hipMemsetAsync(h->dInfo, 0, 2 * sizeof(int), s);
+    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->dParams, M, Mp, D);
+    // fork: the K_uu chain depends on theta and Xu only and runs beside the data-sized work
+    hipEventRecord(h->evFork, s);
+    hipStreamWaitEvent(h->side, h->evFork, 0);
+    hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, h->side, h->dXus, h->dKuu, h->dParams, M, Mp, D);
+    launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->side);
+    launch_trtri(h->dKuu, h->dWk, Mp, T, h->side);
+    launch_ata(h->dWk, h->dKinv, Mp, T, h->side);
+    hipEventRecord(h->evSide, h->side);
+    // data-sized work
+    if (h->n > 0) {
+        hipLaunchKernelGGL(k_gram_uf, dim3(T, h->nblk), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
+                           h->dParams, M, Mp, D, h->n, h->dout);
+        hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles, h->nchunks), dim3(256), 0, s, h->dKuf,
+                           h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk);
+    }
+    hipLaunchKernelGGL(k_assemble, dim3(T, T), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
+                       h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
+                       SGP_S_COUNT + h->dout * h->dout);
+    hipStreamWaitEvent(s, h->evSide, 0);     // join (also keeps the side chain inside a captured graph)
+}
+
+static void enqueue_finish(sgp_handle* h, hipStream_t s) {
+    const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp, TQ = h->TQ;
+    hipMemsetAsync(h->dInfo + 1, 0, sizeof(int), s);
+    hipMemsetAsync(h->dInfo + 3, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_form_lambda, dim3(TQ, TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dLam, h->dXi,
+                       h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form);
+    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Q, s);
+    launch_trtri(h->dLam, h->dWl, Qp, TQ, s);
+    launch_ata(h->dWl, h->dSigma, Qp, TQ, s);
+    hipLaunchKernelGGL(k_symv, dim3((Qp + 3) / 4), dim3(256), 0, s, h->dSigma, h->dXi, h->dMu, Qp, Qp);
+    hipLaunchKernelGGL(k_form_R, dim3(TQ, TQ), dim3(256), 0, s, h->dSigma, h->dMu, h->dR, Q, Qp);
+    hipLaunchKernelGGL(k_trace_partial, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dR, h->dTrace, M, Mp,
+                       h->dout, Qp);
+    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, h->dTrace, h->dMu, h->dKuu, h->dLam, h->dInfo,
+                       h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS);
+    // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69): factor R in place (lower), transposed on read-out
+    launch_potrf(h->dR, Qp, TQ, h->dInfo + 3, Q, s);
+}
+
+typedef void (*enqueue_fn)(sgp_handle*, hipStream_t);
+
+static int run_sequence(sgp_handle* h, Graph& g, enqueue_fn fn, hipStream_t s) {
+    if (h->cfg.flags & SGP_FLAG_NO_GRAPH) {
+        fn(h, s);
+        HIPCHK(h, hipGetLastError());
+        return 0;
+    }
+    if (!g.valid || g.key_n != h->n || g.key_prior != h->prior_form || g.key_stats != (void*)h->dStats) {
+        g.reset();
+        // capture on the library's own stream (the caller's stream may be the legacy default stream)
+        HIPCHK(h, hipStreamBeginCapture(h->own, hipStreamCaptureModeThreadLocal));
+        fn(h, h->own);
+        hipError_t e = hipStreamEndCapture(h->own, &g.graph);
+        if (e != hipSuccess) { h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return SGP_ERR_HIP; }
+        HIPCHK(h, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        g.key_n = h->n; g.key_prior = h->prior_form; g.key_stats = h->dStats; g.valid = true;
+    }
+    HIPCHK(h, hipGraphLaunch(g.exec, s));
+    return 0;
+}
+
+static int check_ready(sgp_handle* h) {
+    if (!h) return SGP_ERR_ARG;
+    if (!h->have_inducing || !h->have_data || !h->have_kernel)
+        return fail(h, SGP_ERR_ARG, "sweep: set_inducing, set_data and set_kernel must be called first");
+    return 0;
+}
+
+extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
+    rc = run_sequence(h, h->gLocal, enqueue_local, s);
+    if (rc) return rc;
+    h->swept_local = true;
+    return 0;
+}
+
+extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
+    if (!h) return SGP_ERR_ARG;
+    if (!h->swept_local) return fail(h, SGP_ERR_ARG, "sgp_sweep_finish: call sgp_sweep_local first");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
+    int rc = run_sequence(h, h->gFinish, enqueue_finish, s);
+    if (rc) return rc;
+    h->swept = true;
+    return 0;
+}
+
+extern "C" int sgp_sweep(sgp_handle* h, void* stream) {
+    int rc = sgp_sweep_local(h, stream);
+    if (rc) return rc;
+    return sgp_sweep_finish(h, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// results
+// ------------------------------------------------------------------------------------------------
+static int sync_all(sgp_handle* h) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    return 0;
+}
+
+static int download_square(sgp_handle* h, const double* dsrc, int ld, int n, double* dst) {
+    HIPCHK(h, hipMemcpy2D(dst, sizeof(double) * n, dsrc, sizeof(double) * ld, sizeof(double) * n, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int sgp_get_scalars(sgp_handle* h, double* out) {
+    if (!h || !out) return fail(h, SGP_ERR_ARG, "sgp_get_scalars: null argument");
+    if (!h->swept) return fail(h, SGP_ERR_ARG, "sgp_get_scalars: no finished sweep");
+    int rc = sync_all(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(out, h->dOut, SGP_R_COUNT * sizeof(double), hipMemcpyDeviceToHost));
+    if (out[SGP_R_INFO_KUU] > 0) { h->err = "K_uu is not positive definite"; return (int)out[SGP_R_INFO_KUU]; }
+    if (out[SGP_R_INFO_LAMBDA] > 0) { h->err = "Lambda is not positive definite"; return (int)out[SGP_R_INFO_LAMBDA]; }
+    return 0;
+}
+
+extern "C" int sgp_get_posterior(sgp_handle* h, double* mu_v, double* Sigma_v, double* Uv) {
+    if (!h) return SGP_ERR_ARG;
+    if (!h->swept) return fail(h, SGP_ERR_ARG, "sgp_get_posterior: no finished sweep");
+    int rc = sync_all(h);
+    if (rc) return rc;
+    int info[4];
+    HIPCHK(h, hipMemcpy(info, h->dInfo, sizeof info, hipMemcpyDeviceToHost));
+    if (info[0] > 0) { h->err = "K_uu is not positive definite"; return info[0]; }
+    if (info[1] > 0) { h->err = "Lambda is not positive definite"; return info[1]; }
+    const int Q = h->Q, Qp = h->Qp;
+    if (mu_v) HIPCHK(h, hipMemcpy(mu_v, h->dMu, sizeof(double) * Q, hipMemcpyDeviceToHost));
+    if (Sigma_v) { rc = download_square(h, h->dSigma, Qp, Q, Sigma_v); if (rc) return rc; }
+    if (Uv) {
+        hipLaunchKernelGGL(k_transpose, dim3(h->TQ, h->TQ), dim3(256), 0, h->own, h->dR, h->dTmp, Qp);
+        HIPCHK(h, hipStreamSynchronize(h->own));
+        rc = download_square(h, h->dTmp, Qp, Q, Uv);
+        if (rc) return rc;
+        for (int j = 0; j < Q; ++j)
+            for (int i = j + 1; i < Q; ++i) Uv[(size_t)j * Q + i] = 0.0;
+    }
+    return 0;
+}
+
+extern "C" int sgp_get_stats(sgp_handle* h, double* Psi2, double* B, double* scalars) {
+    if (!h) return SGP_ERR_ARG;
+    if (!h->swept_local) return fail(h, SGP_ERR_ARG, "sgp_get_stats: no sweep yet");
+    int rc = sync_all(h);
+    if (rc) return rc;
+    const int M = h->M, Mp = h->Mp;
+    if (Psi2) { rc = download_square(h, h->dStats, Mp, M, Psi2); if (rc) return rc; }
+    if (B)
+        HIPCHK(h, hipMemcpy2D(B, sizeof(double) * M, h->dStats + (size_t)Mp * Mp, sizeof(double) * Mp, sizeof(double) * M,
+                              h->dout, hipMemcpyDeviceToHost));
+    if (scalars)
+        HIPCHK(h, hipMemcpy(scalars, h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, SGP_S_COUNT * sizeof(double),
+                            hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int sgp_get_kuu_chol(sgp_handle* h, double* KuuL) {
+    if (!h || !KuuL) return fail(h, SGP_ERR_ARG, "sgp_get_kuu_chol: null argument");
+    if (!h->swept_local) return fail(h, SGP_ERR_ARG, "sgp_get_kuu_chol: no sweep yet");
+    int rc = sync_all(h);
+    if (rc) return rc;
+    rc = download_square(h, h->dKuu, h->Mp, h->M, KuuL);
+    if (rc) return rc;
+    for (int j = 0; j < h->M; ++j)
+        for (int i = 0; i < j; ++i) KuuL[(size_t)j * h->M + i] = 0.0;
+    return 0;
+}
+
+extern "C" int sgp_get_wishart_invscale(sgp_handle* h, double* S) {
+    if (!h || !S) return fail(h, SGP_ERR_ARG, "sgp_get_wishart_invscale: null argument");
+    if (!h->swept) return fail(h, SGP_ERR_ARG, "sgp_get_wishart_invscale: no finished sweep");
+    if (h->dout == 1) return fail(h, SGP_ERR_ARG, "sgp_get_wishart_invscale: d_out = 1 (use sgp_get_scalars)");
+    int rc = sync_all(h);
+    if (rc) return rc;
+    std::vector<double> tmp(MAXO * MAXO);
+    HIPCHK(h, hipMemcpy(tmp.data(), h->dWishart, sizeof(double) * MAXO * MAXO, hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->dout * h->dout; ++i) S[i] = tmp[i];
+    return 0;
+}
+
+extern "C" int sgp_get_timestamps(sgp_handle* h, int64_t* out) {
+    if (!h || !out) return SGP_ERR_ARG;
+    int rc = sync_all(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(out, h->dStamps, 2 * SGP_T_COUNT * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-point :w quantities
+// ------------------------------------------------------------------------------------------------
+extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) {
+    if (!h) return SGP_ERR_ARG;
+    if (!(h->cfg.flags & SGP_FLAG_KEEP_KUF)) return fail(h, SGP_ERR_ARG, "sgp_w_stats: create the handle with SGP_FLAG_KEEP_KUF");
+    if (!h->swept) return fail(h, SGP_ERR_ARG, "sgp_w_stats: no finished sweep");
+    if (h->dout != 1) return fail(h, SGP_ERR_ARG, "sgp_w_stats: d_out must be 1");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
+    const int64_t n = h->n;
+    if (n == 0) return 0;
+    double *dI1 = nullptr, *dI2 = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dI1), sizeof(double) * n));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dI2), sizeof(double) * n));
+    HIPCHK(h, hipDeviceSynchronize());
+    // |L^-1 k_n|^2 with the explicit inverse factor W_k, |Uv k_n|^2 = |L_R^T k_n|^2
+    hipLaunchKernelGGL(k_quadform_cols, dim3(h->T, h->nblk), dim3(256), 0, s, h->dWk, h->dKuf, h->dPa, h->Mp, h->T, n, 0);
+    hipLaunchKernelGGL(k_quadform_cols, dim3(h->T, h->nblk), dim3(256), 0, s, h->dR, h->dKuf, h->dPb, h->Mp, h->T, n, 1);
+    hipLaunchKernelGGL(k_w_point_finish, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, h->dPa, h->dPb, h->dKuf, h->dMu,
+                       h->dY, h->has_yv ? h->dYv : nullptr, dI1, dI2, h->dParams, h->M, h->Mp, h->T, n);
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    if (I1) HIPCHK(h, hipMemcpy(I1, dI1, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (I2) HIPCHK(h, hipMemcpy(I2, dI2, sizeof(double) * n, hipMemcpyDeviceToHost));
+    hipFree(dI1);
+    hipFree(dI2);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prediction
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+static void launch_predict(sgp_handle* h, const double* dXs, const double* dMu, double* dMean, int64_t ns, hipStream_t s) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_predict<DT>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, h->dXus, dXs, dMu,
+                       dMean, h->dParams, h->M, h->Mp, h->D, ns, h->dout);
+}
+
+extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const double* mu_v, double* mean) {
+    if (!h || !Xstar || !mean || ns < 0) return fail(h, SGP_ERR_ARG, "sgp_predict: bad argument");
+    if (!h->have_inducing || !h->have_kernel) return fail(h, SGP_ERR_ARG, "sgp_predict: set_inducing and set_kernel first");
+    if (!mu_v && !h->swept) return fail(h, SGP_ERR_ARG, "sgp_predict: no posterior in the handle and mu_v is NULL");
+    if (ns == 0) return 0;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    hipStream_t s = h->own;
+    double *dXs = nullptr, *dMean = nullptr, *dMuTmp = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dXs), sizeof(double) * ns * h->D));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dMean), sizeof(double) * ns * h->dout));
+    HIPCHK(h, hipMemcpy(dXs, Xstar, sizeof(double) * ns * h->D, hipMemcpyHostToDevice));
+    const double* dMu = h->dMu;
+    if (mu_v) {
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dMuTmp), sizeof(double) * h->Q));
+        HIPCHK(h, hipMemcpy(dMuTmp, mu_v, sizeof(double) * h->Q, hipMemcpyHostToDevice));
+        dMu = dMuTmp;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->dParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->dParams, h->M, h->Mp, h->D);
+    switch (h->D) {
+        case 1: launch_predict<1>(h, dXs, dMu, dMean, ns, s); break;
+        case 2: launch_predict<2>(h, dXs, dMu, dMean, ns, s); break;
+        case 3: launch_predict<3>(h, dXs, dMu, dMean, ns, s); break;
+        case 4: launch_predict<4>(h, dXs, dMu, dMean, ns, s); break;
+        case 8: launch_predict<8>(h, dXs, dMu, dMean, ns, s); break;
+        default: launch_predict<0>(h, dXs, dMu, dMean, ns, s); break;
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpy(mean, dMean, sizeof(double) * ns * h->dout, hipMemcpyDeviceToHost));
+    hipFree(dXs);
+    hipFree(dMean);
+    if (dMuTmp) hipFree(dMuTmp);
+    return 0;
+}
+
+extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
+    if (!h || !value) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: null argument");
+    if (grad) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: gradient not implemented in this round");
+    if (!h->swept || h->dout != 1) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: needs a finished UniSGP sweep");
+    double out[SGP_R_COUNT], sc[SGP_S_COUNT];
+    int rc = sgp_get_scalars(h, out);
+    if (rc) return rc;
+    rc = sgp_get_stats(h, nullptr, nullptr, sc);
+    if (rc) return rc;
+    // -sum_n [ -w/2 k_nn + w/2 |alpha_n|^2 - w/2 |beta_n|^2 + w y_n k_n.mu ] = w/2 (sum I1 + sum I2 - s_yy)
+    *value = 0.5 * h->hParams->W[0] * (out[SGP_R_SUM_I1] + out[SGP_R_SUM_I2] - sc[SGP_S_YY]);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone building blocks (host in / host out, blocking)
+// ------------------------------------------------------------------------------------------------
+static int set_device_checked(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, SGP_ERR_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(nullptr, SGP_ERR_ARG, "bad device ordinal");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, SGP_ERR_HIP, "hipSetDevice failed");
+    return 0;
+}
+
+extern "C" int sgp_kernelmatrix(int32_t device, const double* A, int64_t na, const double* B, int64_t nb, int32_t d,
+                                double sigma2, const double* ell, int32_t n_ell, double* K) {
+    if (!A || !B || !K || !ell || d < 1 || d > MAXD || (n_ell != 1 && n_ell != d) || na < 0 || nb < 0)
+        return fail(nullptr, SGP_ERR_ARG, "sgp_kernelmatrix: bad argument");
+    int rc = set_device_checked(device);
+    if (rc) return rc;
+    if (na == 0 || nb == 0) return 0;
+    sgp_handle* h = nullptr;
+    Params P;
+    memset(&P, 0, sizeof P);
+    P.sigma2 = sigma2;
+    for (int i = 0; i < d; ++i) P.inv_ell[i] = 1.0 / ell[n_ell == 1 ? 0 : i];
+    double *dA = nullptr, *dB = nullptr, *dK = nullptr;
+    Params* dP = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dA), sizeof(double) * na * d));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dB), sizeof(double) * nb * d));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dK), sizeof(double) * na * nb));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dP), sizeof(Params)));
+    HIPCHK(h, hipMemcpy(dA, A, sizeof(double) * na * d, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(dB, B, sizeof(double) * nb * d, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(dP, &P, sizeof(Params), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kernelmatrix, dim3((unsigned)((na * nb + 255) / 256)), dim3(256), 0, 0, dA, dB, dK, dP, na, nb, d);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpy(K, dK, sizeof(double) * na * nb, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dB); hipFree(dK); hipFree(dP);
+    return 0;
+}
+
+static int dense_common(int32_t device, const double* A, int32_t n, double* out, bool inverse) {
+    if (!A || !out || n < 1) return fail(nullptr, SGP_ERR_ARG, "sgp_potrf/potri: bad argument");
+    int rc = set_device_checked(device);
+    if (rc) return rc;
+    sgp_handle* h = nullptr;
+    const int np = round_up(n, TB), Tn = np / TB;
+    std::vector<double> tmp((size_t)np * np, 0.0);
+    for (int j = 0; j < np; ++j) {
+        if (j < n) memcpy(&tmp[(size_t)j * np], &A[(size_t)j * n], sizeof(double) * n);
+        else tmp[(size_t)j * np + j] = 1.0;
+    }
+    double *dA = nullptr, *dW = nullptr, *dC = nullptr;
+    int* dInfo = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dA), sizeof(double) * np * np));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dInfo), sizeof(int)));
+    HIPCHK(h, hipMemset(dInfo, 0, sizeof(int)));
+    HIPCHK(h, hipMemcpy(dA, tmp.data(), sizeof(double) * np * np, hipMemcpyHostToDevice));
+    launch_potrf(dA, np, Tn, dInfo, n, 0);
+    const double* result = dA;
+    if (inverse) {
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dW), sizeof(double) * np * np));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dC), sizeof(double) * np * np));
+        launch_trtri(dA, dW, np, Tn, 0);
+        launch_ata(dW, dC, np, Tn, 0);
+        result = dC;
+    }
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipGetLastError());
+    int info = 0;
+    HIPCHK(h, hipMemcpy(&info, dInfo, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy2D(out, sizeof(double) * n, result, sizeof(double) * np, sizeof(double) * n, n, hipMemcpyDeviceToHost));
+    if (!inverse)
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < j; ++i) out[(size_t)j * n + i] = 0.0;
+    hipFree(dA); hipFree(dInfo);
+    if (dW) hipFree(dW);
+    if (dC) hipFree(dC);
+    if (info > 0) { g_create_error = "matrix is not positive definite"; return info; }
+    return 0;
+}
+
+extern "C" int sgp_potrf(int32_t device, const double* A, int32_t n, double* L) { return dense_common(device, A, n, L, false); }
+extern "C" int sgp_potri(int32_t device, const double* A, int32_t n, double* Ainv) { return dense_common(device, A, n, Ainv, true); }

@@ -1,0 +1,958 @@
+// sgp_kernels.hip.h -- hand-written gfx950 (CDNA4, wave64) kernels of the sparse-GP VMP sweep.
+//
+// Everything is FP64 (cond(Lambda) ~ 7e8 at the kin40k operating point).
+// Dense contractions run on v_mfma_f64_16x16x4_f64 through one LDS-panel tile routine
+// (tile_mma_64x64); the lane maps below were verified on hardware with tools/mfma_f64_probe.hip:
+//     A operand: lane l holds A[i = l & 15][k = l >> 4]        (16 x 4)
+//     B operand: lane l holds B[k = l >> 4][j = l & 15]        (4 x 16)
+//     C/D      : lane l, reg r holds D[row = (l >> 4) + 4 r][col = l & 15]
+//
+// Storage conventions (device):
+//     * square matrices: column-major, leading dimension = padded size (multiple of TB = 64);
+//       the pad block of an SPD matrix is the identity, of a statistics matrix zero.
+//     * K_uf: column-major Mp x N (column n = K(Xu, x_n), the reference's Psi1_trans of point n).
+//     * LDS operand panels: P[k][i] with row stride PS = 80 doubles, so that the two k-rows read by
+//       one 32-lane group of ds_read_b64 fall on opposite halves of the 64 banks (conflict-free).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sgp {
+
+constexpr int TB = 64;          // tile edge of every blocked algorithm
+constexpr int PS = 80;          // LDS panel row stride (doubles): 2*PS*2 dwords = 32 (mod 64)
+constexpr int KB = 16;          // points (k extent) per LDS stage of the streaming SYRK
+constexpr int MAXD = 32;        // max input dimension
+constexpr int MAXO = 4;         // max outputs of a MultiSGP node
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Parameters that change from sweep to sweep (theta, w): kept in device memory so that a captured
+// hipGraph replays with fresh values (the graph's first node copies them from pinned host memory).
+struct Params {
+    double sigma2;
+    double jitter;
+    double E_logw;
+    double n_override;          // unused (<0)
+    double inv_ell[MAXD];
+    double W[MAXO * MAXO];      // mean(q_w): scalar w_bar in W[0] for UniSGP, d_out x d_out for MultiSGP
+    double prior_iso;           // prior precision on the diagonal when prior form = isotropic
+    double pad[7];
+};
+
+__device__ __forceinline__ int64_t realtime_ticks() { return (int64_t)__builtin_amdgcn_s_memrealtime(); }
+
+// ------------------------------------------------------------------------------------------------
+// timestamp marker: one thread writes the 100 MHz constant clock (bench.py's per-phase durations)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_stamp(int64_t* slot) {
+    if (threadIdx.x == 0) *slot = realtime_ticks();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Xu (D x M, AoS) -> Xus (SoA, scaled by 1/ell, padded to Mp with zeros)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_prep_xu(const double* __restrict__ Xu, double* __restrict__ Xus, const Params* __restrict__ P,
+                          int M, int Mp, int D) {
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= Mp) return;
+    for (int d = 0; d < D; ++d) Xus[(size_t)d * Mp + m] = (m < M) ? Xu[(size_t)m * D + d] * P->inv_ell[d] : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_uu (+ jitter I), padded with the identity.  One 64 x 64 tile per block, 16 entries per thread.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gram_uu(const double* __restrict__ Xus, double* __restrict__ Kuu,
+                                                 const Params* __restrict__ P, int M, int Mp, int D) {
+    __shared__ double ui[MAXD * TB];
+    __shared__ double uj[MAXD * TB];
+    const int I = blockIdx.x * TB, J = blockIdx.y * TB;
+    for (int t = threadIdx.x; t < D * TB; t += 256) {
+        int d = t / TB, r = t % TB;
+        ui[t] = Xus[(size_t)d * Mp + I + r];
+        uj[t] = Xus[(size_t)d * Mp + J + r];
+    }
+    __syncthreads();
+    const int i = threadIdx.x & 63;
+    const int jg = threadIdx.x >> 6;
+    const double s2 = P->sigma2, jit = P->jitter;
+    for (int jj = 0; jj < 16; ++jj) {
+        int j = jg * 16 + jj;
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) { double t = ui[d * TB + i] - uj[d * TB + j]; d2 = fma(t, t, d2); }
+        int gi = I + i, gj = J + j;
+        double v;
+        if (gi < M && gj < M) v = s2 * exp(-0.5 * d2) + (gi == gj ? jit : 0.0);
+        else v = (gi == gj) ? 1.0 : 0.0;
+        Kuu[(size_t)gj * Mp + gi] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_uf tile 64 (m) x 64 (n) per block; each thread a 4 x 4 micro-tile.  Also the per-block partial of
+// B = K_uf * Yw  (Yw = omega .* y, n x d_out), reduced deterministically later by k_assemble.
+//   X   : D x N AoS (one point per column), unscaled;  Yw : N x d_out column-major
+//   Kuf : Mp x N column-major;  bpart : [nblk][d_out][Mp]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gram_uf(const double* __restrict__ Xus, const double* __restrict__ X,
+                                                 const double* __restrict__ Yw, double* __restrict__ Kuf,
+                                                 double* __restrict__ bpart, const Params* __restrict__ P,
+                                                 int M, int Mp, int D, int64_t N, int d_out) {
+    __shared__ double us[MAXD * TB];
+    __shared__ double xs[MAXD * TB];
+    __shared__ double ys[MAXO * TB];
+    __shared__ double red[16 * TB];
+    const int I = blockIdx.x * TB;
+    const int64_t n0 = (int64_t)blockIdx.y * TB;
+    for (int t = threadIdx.x; t < D * TB; t += 256) {
+        int d = t / TB, r = t % TB;
+        us[t] = Xus[(size_t)d * Mp + I + r];
+    }
+    for (int t = threadIdx.x; t < D * TB; t += 256) {       // coalesced AoS read, transposed into SoA
+        int p = t / D, d = t % D;
+        int64_t n = n0 + p;
+        xs[d * TB + p] = (n < N) ? X[(size_t)n * D + d] * P->inv_ell[d] : 0.0;
+    }
+    for (int t = threadIdx.x; t < d_out * TB; t += 256) {
+        int o = t / TB, p = t % TB;
+        int64_t n = n0 + p;
+        ys[t] = (n < N) ? Yw[(size_t)o * N + n] : 0.0;
+    }
+    __syncthreads();
+    const int tm = threadIdx.x & 15, tn = threadIdx.x >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int d = 0; d < D; ++d) {
+        double u[4], x[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { u[a] = us[d * TB + tm * 4 + a]; x[a] = xs[d * TB + tn * 4 + a]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { double t = u[a] - x[b]; acc[a][b] = fma(t, t, acc[a][b]); }
+    }
+    const double s2 = P->sigma2;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        int64_t n = n0 + tn * 4 + b;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int m = I + tm * 4 + a;
+            double v = (m < M && n < N) ? s2 * exp(-0.5 * acc[a][b]) : 0.0;
+            acc[a][b] = v;
+        }
+        if (n < N) {
+            double* dst = Kuf + (size_t)n * Mp + I + tm * 4;
+            *reinterpret_cast<double2*>(dst) = make_double2(acc[0][b], acc[1][b]);
+            *reinterpret_cast<double2*>(dst + 2) = make_double2(acc[2][b], acc[3][b]);
+        }
+    }
+    // partial B for this block's 64 points: reduce the 16 n-groups through LDS in a fixed order
+    for (int o = 0; o < d_out; ++o) {
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            double s = 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s = fma(acc[a][b], ys[o * TB + tn * 4 + b], s);
+            red[tn * TB + tm * 4 + a] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < TB) {
+            double s = 0.0;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += red[g * TB + threadIdx.x];
+            bpart[((size_t)blockIdx.y * d_out + o) * Mp + I + threadIdx.x] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA tile routine: acc(64 x 64, 4 waves x (2 x 2) tiles of 16 x 16) += sum_k As[k][i] * Bs[k][j]
+// ------------------------------------------------------------------------------------------------
+struct Acc4 { d4 t[2][2]; };
+
+__device__ __forceinline__ void acc_zero(Acc4& a) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a.t[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+}
+
+// kcount must be a multiple of 4.  As/Bs point at LDS panels with row stride PS.
+__device__ __forceinline__ void tile_mma(Acc4& acc, const double* As, const double* Bs, int kcount, int lane, int wr, int wc) {
+    const int li = lane & 15, lk = lane >> 4;
+    const double* ap = As + lk * PS + wr * 32 + li;
+    const double* bp = Bs + lk * PS + wc * 32 + li;
+#pragma unroll 4
+    for (int k = 0; k < kcount; k += 4) {
+        double a0 = ap[0], a1 = ap[16];
+        double b0 = bp[0], b1 = bp[16];
+        acc.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.t[0][0], 0, 0, 0);
+        acc.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.t[0][1], 0, 0, 0);
+        acc.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.t[1][0], 0, 0, 0);
+        acc.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.t[1][1], 0, 0, 0);
+        ap += 4 * PS;
+        bp += 4 * PS;
+    }
+}
+
+// element (i, j) of the 64 x 64 tile owned by (lane, wave, ti, tj, r)
+__device__ __forceinline__ int acc_row(int lane, int wr, int ti, int r) { return wr * 32 + ti * 16 + (lane >> 4) + 4 * r; }
+__device__ __forceinline__ int acc_col(int lane, int wc, int tj) { return wc * 32 + tj * 16 + (lane & 15); }
+
+// panel[k][i] = G[(row0 + i) + (col0 + k) * ld]  for i < 64, k < kcount   (contiguous along i in memory)
+__device__ __forceinline__ void load_panel_n(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0,
+                                             int kcount, int tid) {
+    for (int t = tid; t < kcount * 16; t += 256) {
+        int k = t >> 4, rq = t & 15;
+        const double* src = G + (size_t)(col0 + k) * ld + row0 + rq * 4;
+        double2 v0 = *reinterpret_cast<const double2*>(src);
+        double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+        double* dst = panel + k * PS + rq * 4;
+        dst[0] = v0.x; dst[1] = v0.y; dst[2] = v1.x; dst[3] = v1.y;
+    }
+}
+// panel[k][i] = G[(row0 + k) + (col0 + i) * ld]  (contiguous along k in memory: transposing load)
+__device__ __forceinline__ void load_panel_t(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0,
+                                             int kcount, int tid) {
+    const int kq = kcount >> 2;                 // groups of 4 consecutive k
+    for (int t = tid; t < kq * 64; t += 256) {
+        int g = t % kq, i = t / kq;
+        const double* src = G + (size_t)(col0 + i) * ld + row0 + g * 4;
+        double2 v0 = *reinterpret_cast<const double2*>(src);
+        double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+        panel[(g * 4 + 0) * PS + i] = v0.x;
+        panel[(g * 4 + 1) * PS + i] = v0.y;
+        panel[(g * 4 + 2) * PS + i] = v1.x;
+        panel[(g * 4 + 3) * PS + i] = v1.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming SYRK over the points: slab[c][t] (64 x 64, stored [i][j] row-major) =
+//     sum_{n in chunk c} K[I+i, n] * omega_n * K[J+j, n]      for the lower tile t = (I, J), I >= J.
+// Split over the point axis so that >= 1 block per CU exists even for M = 512 (36 tiles);
+// partial slabs are summed in a fixed order by k_assemble (bitwise reproducible, no atomics).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_from_index(int t, int& I, int& J) {
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    I = i;
+    J = t - i * (i + 1) / 2;
+}
+
+__global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
+                                                     double* __restrict__ slabs, int Mp, int64_t N, int chunk) {
+    __shared__ double lds[2 * 2 * KB * PS];           // [buf][panel A|B][KB][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    int I, J;
+    tile_from_index(blockIdx.x, I, J);
+    const bool diag = (I == J);
+    const int64_t nbeg = (int64_t)blockIdx.y * chunk;
+    int64_t nend = nbeg + chunk;
+    if (nend > N) nend = N;
+    const int stages = (int)((nend - nbeg + KB - 1) / KB);
+    // staging map: thread -> (point p = tid >> 4, row quad rq = tid & 15): 32 B of one K_uf column
+    const int p = tid >> 4, rq = tid & 15;
+    Acc4 acc;
+    acc_zero(acc);
+    double ra[4], rb[4];
+    auto gload = [&](int s) {
+        int64_t n = nbeg + (int64_t)s * KB + p;
+        if (n < nend) {
+            const double* src = Kuf + (size_t)n * Mp + I * TB + rq * 4;
+            double2 v0 = *reinterpret_cast<const double2*>(src);
+            double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+            ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
+            double w = omega ? omega[n] : 1.0;
+            if (!diag) {
+                const double* sb = Kuf + (size_t)n * Mp + J * TB + rq * 4;
+                double2 u0 = *reinterpret_cast<const double2*>(sb);
+                double2 u1 = *reinterpret_cast<const double2*>(sb + 2);
+                rb[0] = u0.x * w; rb[1] = u0.y * w; rb[2] = u1.x * w; rb[3] = u1.y * w;
+            } else {
+                rb[0] = ra[0] * w; rb[1] = ra[1] * w; rb[2] = ra[2] * w; rb[3] = ra[3] * w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ra[q] = 0.0; rb[q] = 0.0; }
+        }
+    };
+    auto lstore = [&](int buf) {
+        double* A = lds + buf * (2 * KB * PS) + p * PS + rq * 4;
+        double* B = A + KB * PS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { A[q] = ra[q]; B[q] = rb[q]; }
+    };
+    if (stages > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < stages) gload(s + 1);
+        const double* A = lds + buf * (2 * KB * PS);
+        tile_mma(acc, A, A + KB * PS, KB, lane, wr, wc);
+        if (s + 1 < stages) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    double* out = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (TB * TB);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj)] = acc.t[ti][tj][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sum the SYRK slabs and the B partials into the packed statistics buffer (the all-reduce payload):
+//   stats = [Psi2 (Mp x Mp, full symmetric) | B (Mp x d_out) | scalars]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ slabs, const double* __restrict__ bpart,
+                                                  const double* __restrict__ data_scalars, double* __restrict__ stats,
+                                                  int Mp, int ntiles, int nchunks, int nblk, int d_out, int nscal) {
+    __shared__ double tile[TB * (TB + 1)];
+    const int I = blockIdx.x, J = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (I >= J) {
+        const int t = I * (I + 1) / 2 + J;
+        for (int e = tid; e < TB * TB; e += 256) {      // e = i * 64 + j (slab order, coalesced)
+            double s = 0.0;
+            for (int c = 0; c < nchunks; ++c) s += slabs[((size_t)c * ntiles + t) * (TB * TB) + e];
+            tile[(e >> 6) * (TB + 1) + (e & 63)] = s;   // tile[i][j]
+        }
+        __syncthreads();
+        for (int e = tid; e < TB * TB; e += 256) {
+            int j = e >> 6, i = e & 63;                 // coalesced along i
+            stats[(size_t)(J * TB + j) * Mp + I * TB + i] = tile[i * (TB + 1) + j];
+            if (I != J) stats[(size_t)(I * TB + i) * Mp + J * TB + j] = tile[i * (TB + 1) + j];
+        }
+    }
+    if (I == 0 && J == 0) {
+        double* B = stats + (size_t)Mp * Mp;
+        for (int e = tid; e < Mp * d_out; e += 256) {
+            int o = e / Mp, m = e % Mp;
+            double s = 0.0;
+            for (int b = 0; b < nblk; ++b) s += bpart[((size_t)b * d_out + o) * Mp + m];
+            B[e] = s;
+        }
+        for (int e = tid; e < nscal; e += 256) B[(size_t)Mp * d_out + e] = data_scalars[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lambda = Lambda0 + W (x) Psi2 ,  xi = xi0 + vec(B W)   (GPnode/UniSGPnode.jl:62-63 summed over the
+// N messages of :144-173; MultiSGP: GPnode/MultiSGPnode.jl:306-307).  Q = d_out * M, padded to Qp with I.
+// prior_form: 1 = dense precision Lambda0 (Qp x Qp) + xi0, 2 = isotropic precision P->prior_iso, xi0 = 0.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_form_lambda(const double* __restrict__ stats, const double* __restrict__ Lambda0,
+                                                     const double* __restrict__ xi0, double* __restrict__ Lam,
+                                                     double* __restrict__ xi, const Params* __restrict__ P,
+                                                     int M, int Mp, int d_out, int Q, int Qp, int prior_form) {
+    const int gi = blockIdx.x * TB + (threadIdx.x & 63);
+    const int jg = threadIdx.x >> 6;
+    const double* Psi2 = stats;
+    const double* B = stats + (size_t)Mp * Mp;
+    for (int jj = 0; jj < 16; ++jj) {
+        int gj = blockIdx.y * TB + jg * 16 + jj;
+        double v;
+        if (gi < Q && gj < Q) {
+            int a = gi / M, i = gi % M, b = gj / M, j = gj % M;
+            double prior = (prior_form == 1) ? Lambda0[(size_t)gj * Qp + gi] : (gi == gj ? P->prior_iso : 0.0);
+            v = prior + P->W[a + b * d_out] * Psi2[(size_t)j * Mp + i];
+        } else v = (gi == gj) ? 1.0 : 0.0;
+        Lam[(size_t)gj * Qp + gi] = v;
+    }
+    if (blockIdx.y == 0 && threadIdx.x < TB) {
+        double v = 0.0;
+        if (gi < Q) {
+            int a = gi / M, i = gi % M;
+            v = (prior_form == 1) ? xi0[gi] : 0.0;
+            for (int e = 0; e < d_out; ++e) v = fma(B[(size_t)e * Mp + i], P->W[e + a * d_out], v);
+        }
+        xi[gi] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Blocked right-looking Cholesky (lower), tile 64.
+//   k_potrf_panel(j): block b of the grid owns row-block i = j + b of block column j.  Every block factors
+//   the 64 x 64 diagonal tile itself in LDS (redundant compute instead of an inter-block hand-off), block 0
+//   writes L_jj, blocks b >= 1 solve X L_jj^T = A_ij for their tile.
+//   k_potrf_trail(j): A_ik -= L_ij L_kj^T for j < k <= i on the matrix cores.
+// Thread layout of the panel kernel: 4 adjacent lanes (q = tid & 3) share one row r = tid >> 2; lane q keeps
+// the row's entries k = q (mod 4) in registers, so a row never needs another row's registers; the factor's
+// rows are exchanged through LDS.  `info` receives (global column + 1) of the first non-positive pivot.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double quad_sum(double v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+
+// Factor the lower triangle held in S (64 x 64, row stride TB+1, S[r][c]) in place:
+// on exit S[r][c] (c <= r) holds the UNNORMALISED column sums s_rc and rinv[c] = 1/sqrt(s_cc);
+// L[r][c] = s_rc * rinv[c].
+__device__ __forceinline__ void potf2_lds(double* S, double* rinv, int* info, int col_base, int n_valid) {
+    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
+    double Ls[16];                               // s_rk / s_kk for k = 4 i + q
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Ls[i] = 0.0;
+#pragma unroll
+    for (int c = 0; c < TB; ++c) {
+        double part = 0.0;
+#pragma unroll
+        for (int i = 0; i < (c + 3) / 4; ++i) {
+            int k = 4 * i + q;
+            double sck = (k < c) ? S[c * (TB + 1) + k] : 0.0;
+            part = fma(Ls[i], sck, part);
+        }
+        double sum = quad_sum(part);
+        double s_rc = S[r * (TB + 1) + c] - sum;
+        if (r >= c && q == 0) S[r * (TB + 1) + c] = s_rc;
+        __syncthreads();
+        double scc = S[c * (TB + 1) + c];
+        if (!(scc > 0.0)) {
+            if (tid == 0 && col_base + c < n_valid) atomicCAS(info, 0, col_base + c + 1);
+            scc = 1.0;
+        }
+        double ri = 1.0 / sqrt(scc);
+        if (tid == 0) rinv[c] = ri;
+        if ((c & 3) == q) Ls[c >> 2] = (r >= c) ? s_rc * ri * ri : 0.0;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_potrf_panel(double* __restrict__ A, int ld, int j, int* __restrict__ info, int n_valid) {
+    __shared__ double S[TB * (TB + 1)];
+    __shared__ double X[TB * (TB + 1)];
+    __shared__ double rinv[TB];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int j0 = j * TB;
+    for (int e = tid; e < TB * TB; e += 256) {           // coalesced along rows of the column-major tile
+        int c = e >> 6, r = e & 63;
+        S[r * (TB + 1) + c] = A[(size_t)(j0 + c) * ld + j0 + r];
+    }
+    if (b > 0) {
+        const int i0 = (j + b) * TB;
+        for (int e = tid; e < TB * TB; e += 256) {
+            int c = e >> 6, r = e & 63;
+            X[r * (TB + 1) + c] = A[(size_t)(j0 + c) * ld + i0 + r];
+        }
+    }
+    __syncthreads();
+    potf2_lds(S, rinv, info, j0, n_valid);
+    if (b == 0) {
+        for (int e = tid; e < TB * TB; e += 256) {
+            int c = e >> 6, r = e & 63;
+            A[(size_t)(j0 + c) * ld + j0 + r] = (r >= c) ? S[r * (TB + 1) + c] * rinv[c] : 0.0;
+        }
+        return;
+    }
+    // X_rc = (A_rc - sum_{k<c} X_rk L_ck) / L_cc,  L_ck = s_ck rinv_k,  L_cc = 1 / rinv_c
+    const int r = tid >> 2, q = tid & 3;
+    double Xs[16];                                      // X_rk * rinv_k for k = 4 i + q
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Xs[i] = 0.0;
+#pragma unroll
+    for (int c = 0; c < TB; ++c) {
+        double part = 0.0;
+#pragma unroll
+        for (int i = 0; i < (c + 3) / 4; ++i) {
+            int k = 4 * i + q;
+            double sck = (k < c) ? S[c * (TB + 1) + k] : 0.0;
+            part = fma(Xs[i], sck, part);
+        }
+        double sum = quad_sum(part);
+        double ri = rinv[c];
+        double x = (X[r * (TB + 1) + c] - sum) * ri;
+        if (q == 0) X[r * (TB + 1) + c] = x;
+        if ((c & 3) == q) Xs[c >> 2] = x * ri;
+    }
+    __syncthreads();
+    const int i0 = (j + b) * TB;
+    for (int e = tid; e < TB * TB; e += 256) {
+        int c = e >> 6, rr = e & 63;
+        A[(size_t)(j0 + c) * ld + i0 + rr] = X[rr * (TB + 1) + c];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_potrf_trail(double* __restrict__ A, int ld, int j) {
+    __shared__ double lds[2 * TB * PS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    int a, b;
+    tile_from_index(blockIdx.x, a, b);                   // a >= b, offsets within the trailing matrix
+    const int i0 = (j + 1 + a) * TB, k0 = (j + 1 + b) * TB, j0 = j * TB;
+    double* As = lds;
+    double* Bs = lds + TB * PS;
+    load_panel_n(As, A, ld, i0, j0, TB, tid);
+    if (a != b) load_panel_n(Bs, A, ld, k0, j0, TB, tid);
+    __syncthreads();
+    Acc4 acc;
+    acc_zero(acc);
+    tile_mma(acc, As, (a != b) ? Bs : As, TB, lane, wr, wc);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = acc_row(lane, wr, ti, r), col = acc_col(lane, wc, tj);
+                if (a != b || row >= col) {
+                    size_t idx = (size_t)(k0 + col) * ld + i0 + row;
+                    A[idx] -= acc.t[ti][tj][r];
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triangular inverse W = L^-1 (lower).
+//   k_trtri_diag: one block per diagonal tile, rows independent (4 lanes per row as above):
+//       W_rc = (delta_rc - sum_{c<k<=r} W_rk L_kc) / L_cc   for c = r .. 0
+//   k_trtri_col: block (c, s) owns the 16-column strip s of block column c and walks down the rows:
+//       W_ic = - W_ii * sum_{c<=k<i} L_ik W_kc          (two MFMA products per block row)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_trtri_diag(const double* __restrict__ L, double* __restrict__ W, int ld) {
+    __shared__ double S[TB * (TB + 1)];                 // S[k][c] = L_kc
+    __shared__ double Xo[TB * (TB + 1)];
+    const int tid = threadIdx.x, j0 = blockIdx.x * TB;
+    for (int e = tid; e < TB * TB; e += 256) {
+        int c = e >> 6, r = e & 63;
+        S[r * (TB + 1) + c] = L[(size_t)(j0 + c) * ld + j0 + r];
+    }
+    __syncthreads();
+    const int r = tid >> 2, q = tid & 3;
+    double Wr[16];                                      // W_rk for k = 4 i + q
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Wr[i] = 0.0;
+#pragma unroll
+    for (int c = TB - 1; c >= 0; --c) {
+        double part = 0.0;
+#pragma unroll
+        for (int i = c / 4; i < 16; ++i) {
+            int k = 4 * i + q;
+            double lkc = (k > c) ? S[k * (TB + 1) + c] : 0.0;
+            part = fma(Wr[i], lkc, part);               // Wr[i] is zero for k > r
+        }
+        double sum = quad_sum(part);
+        double w = (c <= r) ? (((c == r) ? 1.0 : 0.0) - sum) / S[c * (TB + 1) + c] : 0.0;
+        if (q == 0) Xo[r * (TB + 1) + c] = w;
+        if ((c & 3) == q) Wr[c >> 2] = w;
+    }
+    __syncthreads();
+    for (int e = tid; e < TB * TB; e += 256) {
+        int c = e >> 6, rr = e & 63;
+        W[(size_t)(j0 + c) * ld + j0 + rr] = Xo[rr * (TB + 1) + c];
+    }
+}
+
+// One wave computes a 16 x 16 output tile over K = 64: rows wave*16.., operands in LDS panels.
+__device__ __forceinline__ d4 strip_mma(d4 acc, const double* As, const double* Bs, int lane, int wave) {
+    const int li = lane & 15, lk = lane >> 4;
+    const double* ap = As + lk * PS + wave * 16 + li;
+    const double* bp = Bs + lk * PS + li;
+#pragma unroll 4
+    for (int k = 0; k < TB; k += 4) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], bp[0], acc, 0, 0, 0);
+        ap += 4 * PS;
+        bp += 4 * PS;
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) k_trtri_col(const double* __restrict__ L, double* __restrict__ W, int ld, int T) {
+    __shared__ double As[TB * PS];
+    __shared__ double Bs[TB * PS];                       // only 16 columns used: Bs[k][0..15]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int c0 = c * TB + s * 16;                      // first global column of the strip
+    for (int i = c + 1; i < T; ++i) {
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int k = c; k < i; ++k) {
+            __syncthreads();
+            // As[kk][r] = L[(i*64 + r), (k*64 + kk)] ; Bs[kk][cc] = W[(k*64 + kk), c0 + cc]
+            load_panel_n(As, L, ld, i * TB, k * TB, TB, tid);
+            for (int t = tid; t < TB * 16; t += 256) {
+                int cc = t >> 6, kk = t & 63;
+                Bs[kk * PS + cc] = W[(size_t)(c0 + cc) * ld + k * TB + kk];
+            }
+            __syncthreads();
+            acc = strip_mma(acc, As, Bs, lane, wave);
+        }
+        __syncthreads();
+        // second product: W_ic = - W_ii * Acc ; As[kk][r] = W_ii[r][kk] (column-major tile -> panel_n), Bs = Acc
+        load_panel_n(As, W, ld, i * TB, i * TB, TB, tid);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Bs[(wave * 16 + (lane >> 4) + 4 * r) * PS + (lane & 15)] = acc[r];
+        __syncthreads();
+        d4 out = strip_mma((d4){0.0, 0.0, 0.0, 0.0}, As, Bs, lane, wave);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = i * TB + wave * 16 + (lane >> 4) + 4 * r;
+            W[(size_t)(c0 + (lane & 15)) * ld + row] = -out[r];
+        }
+        __threadfence_block();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C = W^T W for lower-triangular W (inverse from the Cholesky factor: Sigma = L^-T L^-1), full symmetric out.
+// Tile (I, J), I >= J: sum over block rows k = I .. T-1.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ata_lower(const double* __restrict__ W, double* __restrict__ C, int ld, int T) {
+    __shared__ double lds[2 * TB * PS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    int I, J;
+    tile_from_index(blockIdx.x, I, J);
+    double* As = lds;
+    double* Bs = lds + TB * PS;
+    Acc4 acc;
+    acc_zero(acc);
+    for (int k = I; k < T; ++k) {
+        __syncthreads();
+        load_panel_t(As, W, ld, k * TB, I * TB, TB, tid);          // As[kk][i] = W[k*64 + kk, I*64 + i]
+        if (I != J) load_panel_t(Bs, W, ld, k * TB, J * TB, TB, tid);
+        __syncthreads();
+        tile_mma(acc, As, (I != J) ? Bs : As, TB, lane, wr, wc);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = I * TB + acc_row(lane, wr, ti, r), col = J * TB + acc_col(lane, wc, tj);
+                double v = acc.t[ti][tj][r];
+                C[(size_t)col * ld + row] = v;
+                if (I != J) C[(size_t)row * ld + col] = v;
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mu = Sigma xi (one wave per row, Sigma symmetric so a row is read as a contiguous column)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_symv(const double* __restrict__ S, const double* __restrict__ x,
+                                              double* __restrict__ y, int n, int ld) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) s = fma(S[(size_t)row * ld + j], x[j], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[row] = s;
+}
+
+// R = Sigma + mu mu^T on the first q entries, identity pad kept
+__global__ void __launch_bounds__(256) k_form_R(const double* __restrict__ Sigma, const double* __restrict__ mu,
+                                                double* __restrict__ R, int Q, int Qp) {
+    const int gi = blockIdx.x * TB + (threadIdx.x & 63);
+    const int jg = threadIdx.x >> 6;
+    for (int jj = 0; jj < 16; ++jj) {
+        int gj = blockIdx.y * TB + jg * 16 + jj;
+        double v = Sigma[(size_t)gj * Qp + gi];
+        if (gi < Q && gj < Q) v = fma(mu[gi], mu[gj], v);
+        R[(size_t)gj * Qp + gi] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scalars of the sweep.  Two passes, fixed summation order (bitwise reproducible):
+//   k_trace_partial: block g sums its columns of   slot 0: Kinv o Psi2  (tr(Kuu^-1 Psi2): sum I1 = s_kk - t1)
+//                                                  slot 1 + a + b d_out: Rblk[a][b] o Psi2   (tr(R Psi2) / Psi4)
+//   k_scalars: UniSGP  sum I2 = s_yy - 2 b^T mu + t2 ;  energy = 0.5 [ w (sum I1 + sum I2) - n E_logw + n log 2 pi ]
+//                      (GPnode/UniSGPnode.jl:196-238, 337-359, 411-436 summed over the nodes)
+//              MultiSGP inverse scale S = I1 + Ryy - EY - EY^T + Psi4 (GPnode/MultiSGPnode.jl:391-404),
+//                      energy = 0.5 [ tr(W S) - n E_logdetW + n d_out log 2 pi ]   (GPnode/MultiSGPnode.jl:544-632)
+// ------------------------------------------------------------------------------------------------
+constexpr int TRACE_BLOCKS = 128;
+constexpr int TRACE_SLOTS = 1 + MAXO * MAXO;
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+
+__global__ void __launch_bounds__(256) k_trace_partial(const double* __restrict__ stats, const double* __restrict__ Kinv,
+                                                       const double* __restrict__ R, double* __restrict__ partial,
+                                                       int M, int Mp, int d_out, int Qp) {
+    __shared__ double red[4];
+    const double* Psi2 = stats;
+    const int tid = threadIdx.x;
+    double t1 = 0.0;
+    for (int j = blockIdx.x; j < M; j += gridDim.x)
+        for (int i = tid; i < M; i += 256) t1 = fma(Kinv[(size_t)j * Mp + i], Psi2[(size_t)j * Mp + i], t1);
+    t1 = block_sum(t1, red);
+    if (tid == 0) partial[blockIdx.x * TRACE_SLOTS] = t1;
+    for (int a = 0; a < d_out; ++a)
+        for (int b = 0; b < d_out; ++b) {
+            double t2 = 0.0;
+            for (int j = blockIdx.x; j < M; j += gridDim.x)
+                for (int i = tid; i < M; i += 256)
+                    t2 = fma(R[(size_t)(b * M + j) * Qp + a * M + i], Psi2[(size_t)j * Mp + i], t2);
+            t2 = block_sum(t2, red);
+            if (tid == 0) partial[blockIdx.x * TRACE_SLOTS + 1 + a + b * d_out] = t2;
+        }
+}
+
+__global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stats, const double* __restrict__ partial,
+                                                 const double* __restrict__ mu, const double* __restrict__ Lkuu,
+                                                 const double* __restrict__ Llam, const int* __restrict__ info,
+                                                 const Params* __restrict__ P, double* __restrict__ out,
+                                                 double* __restrict__ wishart, int M, int Mp, int d_out, int Q, int Qp,
+                                                 int nblocks) {
+    __shared__ double red[4];
+    __shared__ double tr[TRACE_SLOTS];
+    const double* B = stats + (size_t)Mp * Mp;
+    const double* sc = B + (size_t)Mp * d_out;
+    const int tid = threadIdx.x;
+    if (tid < 1 + d_out * d_out) {
+        double s = 0.0;
+        for (int g = 0; g < nblocks; ++g) s += partial[g * TRACE_SLOTS + tid];
+        tr[tid] = s;
+    }
+    __syncthreads();
+    const double s_kk = P->sigma2 * sc[1];
+    const double n = sc[2];
+    const double sum_I1 = s_kk - tr[0];
+    double ld_k = 0.0, ld_l = 0.0;
+    for (int e = tid; e < M; e += 256) ld_k += log(Lkuu[(size_t)e * Mp + e]);
+    for (int e = tid; e < Q; e += 256) ld_l += log(Llam[(size_t)e * Qp + e]);
+    ld_k = 2.0 * block_sum(ld_k, red);
+    ld_l = 2.0 * block_sum(ld_l, red);
+    const double LOG2PI = 1.8378770664093454835606594728112;
+    if (d_out == 1) {
+        double bmu = 0.0;
+        for (int e = tid; e < M; e += 256) bmu = fma(B[e], mu[e], bmu);
+        bmu = block_sum(bmu, red);
+        if (tid == 0) {
+            const double sum_I2 = sc[0] - 2.0 * bmu + tr[1];
+            const double w = P->W[0];
+            out[0] = sum_I1;
+            out[1] = sum_I2;
+            out[2] = 0.5 * (w * (sum_I1 + sum_I2) - n * P->E_logw + n * LOG2PI);
+        }
+    } else {
+        const double* Ryy = sc + 8;
+        double tr_WS = 0.0;
+        for (int a = 0; a < d_out; ++a)
+            for (int b = 0; b < d_out; ++b) {
+                double ey_ab = 0.0, ey_ba = 0.0;             // EY[a][b] = mu^(b) . B[:, a]
+                for (int e = tid; e < M; e += 256) {
+                    ey_ab = fma(mu[b * M + e], B[(size_t)a * Mp + e], ey_ab);
+                    ey_ba = fma(mu[a * M + e], B[(size_t)b * Mp + e], ey_ba);
+                }
+                ey_ab = block_sum(ey_ab, red);
+                ey_ba = block_sum(ey_ba, red);
+                double Sab = (a == b ? sum_I1 : 0.0) + Ryy[a + b * d_out] - ey_ab - ey_ba + tr[1 + a + b * d_out];
+                if (tid == 0) wishart[a + b * d_out] = Sab;
+                tr_WS += P->W[b + a * d_out] * Sab;
+            }
+        if (tid == 0) {
+            out[0] = sum_I1;
+            out[1] = 0.0;
+            out[2] = 0.5 * (tr_WS - n * P->E_logw + n * d_out * LOG2PI);
+        }
+    }
+    if (tid == 0) {
+        out[3] = (double)info[0];
+        out[4] = (double)info[1];
+        out[5] = (double)info[2];
+        out[6] = ld_k;
+        out[7] = ld_l;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prediction: mean[s, o] = sum_m K(x*_s, u_m) mu[o*M + m]   (GPnode/UniSGPnode.jl:96-104 batched).
+// One thread per test point, Xus tile and mu staged in LDS.
+// ------------------------------------------------------------------------------------------------
+template <int DT>   // DT > 0: input dimension known at compile time (x stays in registers); DT = 0: runtime D <= MAXD
+__global__ void __launch_bounds__(256) k_predict(const double* __restrict__ Xus, const double* __restrict__ Xs,
+                                                 const double* __restrict__ mu, double* __restrict__ mean,
+                                                 const Params* __restrict__ P, int M, int Mp, int Drt, int64_t NS, int d_out) {
+    __shared__ double us[MAXD * TB];
+    __shared__ double ms[MAXO * TB];
+    constexpr int DA = DT > 0 ? DT : MAXD;
+    const int D = DT > 0 ? DT : Drt;
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double x[DA];
+#pragma unroll
+    for (int d = 0; d < DA; ++d) x[d] = (s < NS && d < D) ? Xs[(size_t)s * D + d] * P->inv_ell[d] : 0.0;
+    double acc[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) acc[o] = 0.0;
+    for (int m0 = 0; m0 < M; m0 += TB) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < D * TB; t += 256) us[t] = Xus[(size_t)(t / TB) * Mp + m0 + (t % TB)];
+        for (int t = threadIdx.x; t < d_out * TB; t += 256) {
+            int o = t / TB, m = m0 + (t % TB);
+            ms[t] = (m < M) ? mu[o * M + m] : 0.0;
+        }
+        __syncthreads();
+        const int mcount = (M - m0 < TB) ? (M - m0) : TB;
+        for (int m = 0; m < mcount; ++m) {
+            double d2 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DA; ++d)
+                if (d < D) { double t = x[d] - us[d * TB + m]; d2 = fma(t, t, d2); }
+            double k = exp(-0.5 * d2);
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o)
+                if (o < d_out) acc[o] = fma(k, ms[o * TB + m], acc[o]);
+        }
+    }
+    if (s < NS)
+        for (int o = 0; o < d_out; ++o) mean[(size_t)o * NS + s] = P->sigma2 * acc[o];
+}
+
+// generic K(A, B): na x nb column-major
+__global__ void __launch_bounds__(256) k_kernelmatrix(const double* __restrict__ A, const double* __restrict__ B,
+                                                      double* __restrict__ K, const Params* __restrict__ P,
+                                                      int64_t na, int64_t nb, int D) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= na * nb) return;
+    const int64_t i = e % na, j = e / na;
+    double d2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+        double t = (A[(size_t)i * D + d] - B[(size_t)j * D + d]) * P->inv_ell[d];
+        d2 = fma(t, t, d2);
+    }
+    K[e] = P->sigma2 * exp(-0.5 * d2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-point :w quantities (GPnode/UniSGPnode.jl:196-238) from the resident K_uf:
+//   out[n] = sum_m (F K_uf)[m, n]^2  with F lower-triangular (F = L^-1 -> |alpha_n|^2) or, with F = L_R^T
+//   replaced by its transpose product, |Uv k_n|^2 = k_n^T R k_n = |L_R^T k_n|^2.
+// Tile: 64 rows of F K x 64 points per block, K loop over block columns of F; squared column sums are
+// reduced over the row-blocks by atomics-free two-pass (partial[rowblk][n]).
+//   mode 0: F used as stored (lower, rows i, sum over k <= i);  mode 1: F^T (upper), sum over k >= i.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_quadform_cols(const double* __restrict__ F, const double* __restrict__ Kuf,
+                                                       double* __restrict__ partial, int ld, int T, int64_t N, int mode) {
+    __shared__ double lds[2 * TB * PS];
+    __shared__ double colsum[4][TB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int I = blockIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.y * TB;
+    double* As = lds;
+    double* Bs = lds + TB * PS;
+    Acc4 acc;
+    acc_zero(acc);
+    const int kbeg = (mode == 0) ? 0 : I, kend = (mode == 0) ? I + 1 : T;
+    for (int k = kbeg; k < kend; ++k) {
+        __syncthreads();
+        if (mode == 0) {
+            // As[kk][i] = F[(I*64 + i), (k*64 + kk)]
+            load_panel_n(As, F, ld, I * TB, k * TB, TB, tid);
+        } else {
+            // As[kk][i] = F^T[(I*64+i), (k*64+kk)] = F[(k*64+kk), (I*64+i)]
+            load_panel_t(As, F, ld, k * TB, I * TB, TB, tid);
+        }
+        // Bs[kk][j] = Kuf[(k*64 + kk), n0 + j]
+        for (int t = tid; t < TB * 16; t += 256) {
+            int j = t >> 4, g = t & 15;
+            int64_t n = n0 + j;
+            double v[4] = {0.0, 0.0, 0.0, 0.0};
+            if (n < N) {
+                const double* src = Kuf + (size_t)n * ld + k * TB + g * 4;
+                double2 v0 = *reinterpret_cast<const double2*>(src);
+                double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+                v[0] = v0.x; v[1] = v0.y; v[2] = v1.x; v[3] = v1.y;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Bs[(g * 4 + q) * PS + j] = v[q];
+        }
+        __syncthreads();
+        if (mode == 0 && k == I) {
+            // diagonal tile of a lower-triangular F: zero the strict upper part of the panel
+            for (int t = tid; t < TB * TB; t += 256) {
+                int kk = t >> 6, i = t & 63;
+                if (kk > i) As[kk * PS + i] = 0.0;
+            }
+            __syncthreads();
+        } else if (mode == 1 && k == I) {
+            for (int t = tid; t < TB * TB; t += 256) {
+                int kk = t >> 6, i = t & 63;
+                if (kk < i) As[kk * PS + i] = 0.0;
+            }
+            __syncthreads();
+        }
+        tile_mma(acc, As, Bs, TB, lane, wr, wc);
+    }
+    // column sums of squares over this block's 64 rows
+    double cs[2] = {0.0, 0.0};
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[tj] = fma(acc.t[ti][tj][r], acc.t[ti][tj][r], cs[tj]);
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        cs[tj] += __shfl_xor(cs[tj], 16);
+        cs[tj] += __shfl_xor(cs[tj], 32);
+    }
+    __syncthreads();
+    if (lane < 16) {
+        colsum[wave][(wc * 32) + lane] = cs[0];           // waves (wr,wc): rows wr*32.., cols wc*32..
+        colsum[wave][(wc * 32) + 16 + lane] = cs[1];
+    }
+    __syncthreads();
+    if (tid < TB) {
+        int wcol = tid >> 5;                               // which wc owns this column
+        double s = colsum[0 * 2 + wcol][tid] + colsum[1 * 2 + wcol][tid];
+        int64_t n = n0 + tid;
+        if (n < N) partial[(size_t)I * N + n] = s;
+    }
+}
+
+// I1_n = sigma2 - sum_I pa[I][n] ;  I2_n = y^2 + v - 2 y (k_n . mu) + sum_I pb[I][n]
+__global__ void __launch_bounds__(256) k_w_point_finish(const double* __restrict__ pa, const double* __restrict__ pb,
+                                                        const double* __restrict__ Kuf, const double* __restrict__ mu,
+                                                        const double* __restrict__ y, const double* __restrict__ yv,
+                                                        double* __restrict__ I1, double* __restrict__ I2,
+                                                        const Params* __restrict__ P, int M, int Mp, int T, int64_t N) {
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    double kmu = 0.0;
+    for (int m = lane; m < M; m += 64) kmu = fma(Kuf[(size_t)n * Mp + m], mu[m], kmu);
+    for (int o = 32; o > 0; o >>= 1) kmu += __shfl_xor(kmu, o);
+    if (lane == 0) {
+        double a = 0.0, b = 0.0;
+        for (int I = 0; I < T; ++I) { a += pa[(size_t)I * N + n]; b += pb[(size_t)I * N + n]; }
+        double yy = y[n], v = yv ? yv[n] : 0.0;
+        if (I1) I1[n] = P->sigma2 - a;
+        if (I2) I2[n] = yy * yy + v - 2.0 * yy * kmu + b;
+    }
+}
+
+// transpose-copy of a square column-major matrix (Uv = L_R^T on the way out)
+__global__ void __launch_bounds__(256) k_transpose(const double* __restrict__ A, double* __restrict__ At, int ld) {
+    __shared__ double tile[TB * (TB + 1)];
+    const int I = blockIdx.x * TB, J = blockIdx.y * TB;
+    for (int e = threadIdx.x; e < TB * TB; e += 256) {
+        int c = e >> 6, r = e & 63;
+        tile[r * (TB + 1) + c] = A[(size_t)(J + c) * ld + I + r];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < TB * TB; e += 256) {
+        int c = e >> 6, r = e & 63;
+        At[(size_t)(I + c) * ld + J + r] = tile[c * (TB + 1) + r];
+    }
+}
+
+}  // namespace sgp

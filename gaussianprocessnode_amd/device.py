@@ -1,0 +1,208 @@
+"""`SGPDevice`: one rank's resident sparse-GP state on one MI355X, a thin object over the C ABI.
+
+Array conventions follow the reference's Julia memory layout through NumPy C-order:
+points `X` are (N, D) (= column-major D x N), `Xu` is (M, D), symmetric matrices are (M, M).
+Nothing here computes on the CPU: every method is a call into csrc/libsgp_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_f64, check, ptr
+
+
+@dataclass
+class SweepScalars:
+    sum_I1: float
+    sum_I2: float
+    energy: float
+    info_kuu: int
+    info_lambda: int
+    logdet_kuu: float
+    logdet_lambda: float
+
+
+class SGPDevice:
+    """Owns the device buffers for (n_max points, M inducing points, D dims, d_out outputs)."""
+
+    def __init__(self, n_max: int, m: int, d: int, d_out: int = 1, device: int = 0, use_graph: bool = True,
+                 keep_kuf: bool = False):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        flags = (0 if use_graph else _lib.SGP_FLAG_NO_GRAPH) | (_lib.SGP_FLAG_KEEP_KUF if keep_kuf else 0)
+        cfg = _lib.Config(n_max=int(n_max), m=int(m), d=int(d), d_out=int(d_out), device=int(device), flags=flags)
+        check(self._lib.sgp_create(C.byref(cfg), C.byref(self._h)), None, "sgp_create")
+        self.n_max, self.M, self.D, self.d_out, self.device = int(n_max), int(m), int(d), int(d_out), int(device)
+        self.Q = self.M * self.d_out
+        self.n = 0
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.sgp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- inputs
+    def set_inducing(self, Xu):
+        Xu = as_f64(np.reshape(Xu, (self.M, self.D)))
+        check(self._lib.sgp_set_inducing(self._h, ptr(Xu)), self._h, "sgp_set_inducing")
+
+    def set_data(self, X, y_mean, y_var=None, weights=None, n_nodes: Optional[float] = None):
+        X = as_f64(np.reshape(X, (-1, self.D)))
+        n = X.shape[0]
+        # y: (n,) or (n, d_out) -> column-major n x d_out == C-order (d_out, n)
+        y = np.asarray(y_mean, dtype=np.float64).reshape(n, self.d_out)
+        y_cm = as_f64(y.T)
+        yv = None if y_var is None else as_f64(np.reshape(y_var, (n,)))
+        w = None if weights is None else as_f64(np.reshape(weights, (n,)))
+        check(self._lib.sgp_set_data(self._h, ptr(X), ptr(y_cm), ptr(yv), ptr(w), n,
+                                     float(-1.0 if n_nodes is None else n_nodes)), self._h, "sgp_set_data")
+        self.n = n
+
+    def set_kernel(self, sigma2: float, ell, jitter: float = 0.0):
+        ell = as_f64(np.atleast_1d(ell))
+        check(self._lib.sgp_set_kernel(self._h, float(sigma2), ptr(ell), int(ell.size), float(jitter)), self._h,
+              "sgp_set_kernel")
+
+    def set_prior_meancov(self, mu0, Sigma0):
+        mu0 = as_f64(np.reshape(mu0, (self.Q,)))
+        S0 = as_f64(np.reshape(Sigma0, (self.Q, self.Q)))
+        check(self._lib.sgp_set_prior(self._h, ptr(mu0), ptr(S0), 0), self._h, "sgp_set_prior")
+
+    def set_prior_precision(self, xi0, Lambda0):
+        xi0 = as_f64(np.reshape(xi0, (self.Q,)))
+        L0 = as_f64(np.reshape(Lambda0, (self.Q, self.Q)))
+        check(self._lib.sgp_set_prior(self._h, ptr(xi0), ptr(L0), 1), self._h, "sgp_set_prior")
+
+    def set_prior_isotropic(self, variance: float):
+        v = as_f64([variance])
+        check(self._lib.sgp_set_prior(self._h, None, ptr(v), 2), self._h, "sgp_set_prior")
+
+    def set_noise(self, W, E_log_w: Optional[float] = None):
+        W = as_f64(np.reshape(W, (self.d_out, self.d_out)))
+        if E_log_w is None:
+            E_log_w = float(np.log(W[0, 0])) if self.d_out == 1 else float(np.linalg.slogdet(W)[1])
+        check(self._lib.sgp_set_noise(self._h, ptr(as_f64(W.T)), float(E_log_w)), self._h, "sgp_set_noise")
+
+    # ---- sweep
+    def sweep_local(self, stream: int = 0):
+        check(self._lib.sgp_sweep_local(self._h, C.c_void_p(stream)), self._h, "sgp_sweep_local")
+
+    def sweep_finish(self, stream: int = 0):
+        check(self._lib.sgp_sweep_finish(self._h, C.c_void_p(stream)), self._h, "sgp_sweep_finish")
+
+    def sweep(self, stream: int = 0):
+        check(self._lib.sgp_sweep(self._h, C.c_void_p(stream)), self._h, "sgp_sweep")
+
+    def stats_layout(self):
+        p, cnt, mp = C.c_void_p(), C.c_int64(), C.c_int32()
+        check(self._lib.sgp_stats_layout(self._h, C.byref(p), C.byref(cnt), C.byref(mp)), self._h, "sgp_stats_layout")
+        return p.value, cnt.value, mp.value
+
+    def bind_stats(self, dev_ptr: int):
+        check(self._lib.sgp_bind_stats(self._h, C.c_void_p(dev_ptr)), self._h, "sgp_bind_stats")
+
+    # ---- results
+    def posterior(self, want_cov: bool = True, want_uv: bool = True):
+        mu = np.empty(self.Q)
+        Sig = np.empty((self.Q, self.Q)) if want_cov else None
+        Uv = np.empty((self.Q, self.Q)) if want_uv else None
+        check(self._lib.sgp_get_posterior(self._h, ptr(mu), ptr(Sig), ptr(Uv)), self._h, "sgp_get_posterior")
+        # column-major upper-triangular Uv arrives as the C-order transpose
+        return mu, Sig, (None if Uv is None else Uv.T.copy())
+
+    def scalars(self) -> SweepScalars:
+        out = np.empty(_lib.SGP_R_COUNT)
+        check(self._lib.sgp_get_scalars(self._h, ptr(out)), self._h, "sgp_get_scalars")
+        return SweepScalars(out[0], out[1], out[2], int(out[3]), int(out[4]), out[6], out[7])
+
+    def stats(self):
+        Psi2 = np.empty((self.M, self.M))
+        B = np.empty((self.d_out, self.M))
+        sc = np.empty(_lib.SGP_S_COUNT)
+        check(self._lib.sgp_get_stats(self._h, ptr(Psi2), ptr(B), ptr(sc)), self._h, "sgp_get_stats")
+        return Psi2, B.T.copy(), sc
+
+    def kuu_chol(self):
+        L = np.empty((self.M, self.M))
+        check(self._lib.sgp_get_kuu_chol(self._h, ptr(L)), self._h, "sgp_get_kuu_chol")
+        return L.T.copy()          # column-major lower -> C-order array holding L
+
+    def wishart_invscale(self):
+        S = np.empty((self.d_out, self.d_out))
+        check(self._lib.sgp_get_wishart_invscale(self._h, ptr(S)), self._h, "sgp_get_wishart_invscale")
+        return S.T.copy()
+
+    def w_stats(self):
+        I1, I2 = np.empty(self.n), np.empty(self.n)
+        check(self._lib.sgp_w_stats(self._h, ptr(I1), ptr(I2), None), self._h, "sgp_w_stats")
+        return I1, I2
+
+    def predict(self, Xstar, mu_v=None):
+        Xs = as_f64(np.reshape(Xstar, (-1, self.D)))
+        ns = Xs.shape[0]
+        out = np.empty((self.d_out, ns))
+        mu = None if mu_v is None else as_f64(np.reshape(mu_v, (self.Q,)))
+        check(self._lib.sgp_predict(self._h, ptr(Xs), ns, ptr(mu), ptr(out)), self._h, "sgp_predict")
+        return out[0] if self.d_out == 1 else out.T.copy()
+
+    def theta_objective(self):
+        v = C.c_double()
+        check(self._lib.sgp_theta_objective(self._h, C.cast(C.byref(v), C.POINTER(C.c_double)), None), self._h,
+              "sgp_theta_objective")
+        return v.value
+
+    def timestamps(self):
+        out = (C.c_int64 * (2 * _lib.SGP_T_COUNT))()
+        check(self._lib.sgp_get_timestamps(self._h, out), self._h, "sgp_get_timestamps")
+        return np.array(out[:], dtype=np.int64).reshape(_lib.SGP_T_COUNT, 2)
+
+
+# ---- stand-alone building blocks -------------------------------------------------------------
+def kernelmatrix(A, B, sigma2: float, ell, device: int = 0):
+    """K(A, B) on the device: sigma2 * exp(-0.5 |(a-b)/ell|^2); A (na, D), B (nb, D) -> (na, nb)."""
+    lib = _lib.load()
+    A = as_f64(np.atleast_2d(A))
+    B = as_f64(np.atleast_2d(B))
+    ell = as_f64(np.atleast_1d(ell))
+    K = np.empty((B.shape[0], A.shape[0]))            # column-major na x nb
+    check(lib.sgp_kernelmatrix(device, ptr(A), A.shape[0], ptr(B), B.shape[0], A.shape[1], float(sigma2), ptr(ell),
+                               int(ell.size), ptr(K)), None, "sgp_kernelmatrix")
+    return K.T.copy()
+
+
+def potrf(A, device: int = 0):
+    """Lower Cholesky factor on the device (fastcholesky(A).L)."""
+    lib = _lib.load()
+    A = as_f64(A)
+    n = A.shape[0]
+    L = np.empty((n, n))
+    check(lib.sgp_potrf(device, ptr(as_f64(A.T)), n, ptr(L)), None, "sgp_potrf")
+    return L.T.copy()
+
+
+def potri(A, device: int = 0):
+    """Inverse of an SPD matrix through its Cholesky factor on the device (cholinv(A))."""
+    lib = _lib.load()
+    A = as_f64(A)
+    n = A.shape[0]
+    out = np.empty((n, n))
+    check(lib.sgp_potri(device, ptr(as_f64(A.T)), n, ptr(out)), None, "sgp_potri")
+    return out.T.copy()

@@ -1,0 +1,163 @@
+/* sgp_hip.h -- C ABI of the MI355X (gfx950) sparse-GP VMP hot path.
+ *
+ * Drop-in boundary for the UniSGP / MultiSGP factor nodes of biaslab/GaussianProcessNode.
+ * The reference evaluates the node per data point inside ReactiveMP message rules; this library
+ * evaluates the same mathematics batched on the GPU.  Every entry point
+ * below names the reference interface it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, no C++/torch/HIP types in signatures; `void* stream` is a hipStream_t (NULL = the
+ *     library's own stream), `*_dev` pointers are raw device pointers (e.g. pointer(::ROCArray)
+ *     from AMDGPU.jl or torch.Tensor.data_ptr()).
+ *   - all matrices are Float64, column-major (Julia layout).  Points are packed D x N (one point per
+ *     column), i.e. the memory of a C-ordered NumPy (N, D) array.
+ *   - every function returns 0 on success; k > 0 = "leading minor k not positive definite"
+ *     (LAPACK potrf convention; the Julia shim rethrows PosDefException(k)); negative = error
+ *     (see SGP_ERR_*).  sgp_last_error() gives the text.
+ *   - a handle is NOT re-entrant (the reference's meta is mutated in place too,
+ *     helper_functions/gp_helperfunction.jl:33-44); one handle = one GPU = one process.
+ */
+#ifndef SGP_HIP_H
+#define SGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGP_ABI_VERSION 1
+
+#define SGP_ERR_ARG      (-1)   /* bad argument / state */
+#define SGP_ERR_HIP      (-2)   /* HIP runtime error */
+#define SGP_ERR_NODEVICE (-3)   /* no gfx950 device visible */
+#define SGP_ERR_NOMEM    (-4)
+
+/* flags for sgp_config.flags */
+#define SGP_FLAG_NO_GRAPH   1   /* launch kernels eagerly instead of replaying a captured hipGraph */
+#define SGP_FLAG_KEEP_KUF   2   /* keep K_uf resident for the per-point outputs (sgp_w_stats per_point) */
+
+typedef struct sgp_handle sgp_handle;
+
+typedef struct sgp_config {
+    int64_t n_max;    /* capacity in points of this handle (this rank's shard) */
+    int32_t m;        /* inducing points M                 */
+    int32_t d;        /* input dimension D (1..32)         */
+    int32_t d_out;    /* outputs: 1 = UniSGP, >1 = MultiSGP (shared kernel) */
+    int32_t device;   /* HIP device ordinal                */
+    int32_t flags;    /* SGP_FLAG_*                        */
+    int32_t reserved;
+} sgp_config;
+
+/* statistics slots appended after Psi2 and B in the packed statistics buffer (sgp_stats_layout) */
+enum { SGP_S_YY = 0,      /* sum_n omega_n (mu_y^2 + v_y)   (d_out = 1; MultiSGP keeps Ryy separately) */
+       SGP_S_W = 1,       /* sum_n omega_n                  (s_kk = sigma2 * S_W)                      */
+       SGP_S_N = 2,       /* number of factor nodes                                                     */
+       SGP_S_COUNT = 8 };
+
+/* result scalars of a sweep (sgp_get_scalars) */
+enum { SGP_R_SUM_I1 = 0,  /* sum_n I1_n = s_kk - tr(Kuu^-1 Psi2)                */
+       SGP_R_SUM_I2 = 1,  /* sum_n I2_n                                          */
+       SGP_R_ENERGY = 2,  /* sum_n average energy                                */
+       SGP_R_INFO_KUU = 3,/* potrf info of K_uu (0 ok, k = failing minor)        */
+       SGP_R_INFO_LAMBDA = 4, /* potrf info of Lambda                            */
+       SGP_R_INFO_PRIOR = 5,  /* potrf info of Sigma0 when the prior is a covariance */
+       SGP_R_LOGDET_KUU = 6,
+       SGP_R_LOGDET_LAMBDA = 7,
+       SGP_R_COUNT = 8 };
+
+/* ---- lifetime ------------------------------------------------------------------------------
+ * replaces: construction of UniSGPMeta / MultiSGPMeta and their scratch buffers
+ * (helper_functions/gp_helperfunction.jl:33-44,55-64; GPCache :16-20,78-90). */
+int sgp_abi_version(void);
+int sgp_create(const sgp_config* cfg, sgp_handle** out);
+int sgp_destroy(sgp_handle* h);
+const char* sgp_last_error(const sgp_handle* h);   /* h may be NULL: last error of a failed sgp_create */
+
+/* ---- inputs --------------------------------------------------------------------------------
+ * sgp_set_inducing: meta.Xu (helper_functions/gp_helperfunction.jl:35; Vector{Vector} packed D x M). */
+int sgp_set_inducing(sgp_handle* h, const double* Xu);
+/* sgp_set_data: the data of one `infer` call -- x[i], y[i] of `y[i] ~ UniSGP(x[i], v, w, theta)`
+ * (experiments/regression_kin40k.ipynb:147-152).  X is D x n; y_mean is n x d_out (column-major);
+ * y_var (n, may be NULL) is var(q_out) of the classification rules (GPnode/UniSGPnode.jl:161-173,219-238);
+ * pt_weight (n, may be NULL) are cubature weights omega of uncertain inputs (GPnode/UniSGPnode.jl:11-33,
+ * GPnode/MultiSGPnode.jl:11-35); n_nodes = number of factor nodes the n points belong to (n if no cubature). */
+int sgp_set_data(sgp_handle* h, const double* X, const double* y_mean, const double* y_var,
+                 const double* pt_weight, int64_t n, double n_nodes);
+/* sgp_set_kernel: kernel(theta) = sigma2 * with_lengthscale(SEKernel(), ell)
+ * (GPtest.jl:21; experiments/regression_kin40k.ipynb:108).  n_ell = 1 (isotropic) or D (ARD).
+ * jitter is added to diag(K_uu) (0 in kin40k training :183, 1e-8 at prediction :297 and in banana). */
+int sgp_set_kernel(sgp_handle* h, double sigma2, const double* ell, int32_t n_ell, double jitter);
+/* sgp_set_prior: `v ~ MvNormalMeanCovariance(mu_v, Sigma_v)` (experiments/regression_kin40k.ipynb:148).
+ * form: 0 = mean + covariance, 1 = weighted mean xi0 + precision Lambda0, 2 = isotropic N(0, s I) with
+ * s = mat[0] (the notebook's per-epoch reset 50 I, :203-204).  Vectors have d_out*M entries. */
+int sgp_set_prior(sgp_handle* h, const double* vec, const double* mat, int32_t form);
+/* sgp_set_noise: mean(q_w).  UniSGP: W[0] = w_bar and E_log_w = E[log w] (log w_bar for a PointMass,
+ * GPnode/UniSGPnode.jl:340,414).  MultiSGP: W is d_out x d_out (mean of the Wishart), E_log_w = E[logdet W]. */
+int sgp_set_noise(sgp_handle* h, const double* W, double E_log_w);
+
+/* ---- the sweep -----------------------------------------------------------------------------
+ * One VMP sweep over the resident data = what ReactiveMP does for `infer(iterations = 1)`:
+ *   phase 1 (local):  K_uu + chol (experiments/regression_kin40k.ipynb:183-184), K_uf and the summed
+ *                     :v messages  Psi2 = sum k_n k_n^T, b = sum mu_y k_n   (GPnode/UniSGPnode.jl:144-173)
+ *   [multi-GPU: sum-all-reduce of the packed statistics buffer, see sgp_stats_layout]
+ *   phase 2 (replicated): the N-fold product + marginal (GPnode/UniSGPnode.jl:62-73): Lambda, Sigma_v,
+ *                     mu_v, Uv; the summed :w messages (GPnode/UniSGPnode.jl:196-238) and the summed
+ *                     average energy (GPnode/UniSGPnode.jl:337-387,411-436).
+ * All calls are asynchronous on `stream`; results are fetched with sgp_get_*.  */
+int sgp_sweep_local(sgp_handle* h, void* stream);
+int sgp_sweep_finish(sgp_handle* h, void* stream);
+int sgp_sweep(sgp_handle* h, void* stream);                 /* local + finish (single GPU) */
+
+/* packed statistics buffer (device): [Psi2: Mp*Mp | B: Mp*d_out | scalars: SGP_S_COUNT (+ d_out*d_out Ryy)]
+ * Mp = M rounded up to the tile size; count = total doubles to all-reduce. */
+int sgp_stats_layout(const sgp_handle* h, void** stats_dev, int64_t* count, int32_t* mp);
+/* let the caller own the statistics buffer (e.g. a torch tensor that torch.distributed all-reduces) */
+int sgp_bind_stats(sgp_handle* h, void* stats_dev);
+
+/* ---- results -------------------------------------------------------------------------------
+ * sgp_get_posterior: mean_cov(qv) + meta.Uv (GPnode/UniSGPnode.jl:66-69).  Any pointer may be NULL.
+ * mu_v: d_out*M; Sigma_v, Uv: (d_out*M)^2 column-major; Uv upper-triangular with Uv' Uv = Sigma_v + mu mu'. */
+int sgp_get_posterior(sgp_handle* h, double* mu_v, double* Sigma_v, double* Uv);
+int sgp_get_scalars(sgp_handle* h, double* out /* SGP_R_COUNT */);
+/* sgp_get_stats: the reduced statistics (tests, theta-gradient): Psi2 M x M, B M x d_out, scalars SGP_S_COUNT */
+int sgp_get_stats(sgp_handle* h, double* Psi2, double* B, double* scalars);
+/* sgp_get_kuu_chol: meta.KuuL (helper_functions/gp_helperfunction.jl:39), lower, M x M */
+int sgp_get_kuu_chol(sgp_handle* h, double* KuuL);
+/* MultiSGP: inverse scale sum_t (I1_t + I2_t) of the Wishart messages (GPnode/MultiSGPnode.jl:391-404), d_out^2 */
+int sgp_get_wishart_invscale(sgp_handle* h, double* S);
+
+/* sgp_w_stats: per-point :w rule quantities (GPnode/UniSGPnode.jl:196-238):
+ * I1_n = k_nn - |L^-1 k_n|^2 (the Q_ff diagonal term) and I2_n.  Needs SGP_FLAG_KEEP_KUF and a finished sweep.
+ * Either output may be NULL. */
+int sgp_w_stats(sgp_handle* h, double* I1 /* n */, double* I2 /* n */, void* stream);
+
+/* sgp_predict: batched @call_rule UniSGP(:out) (GPnode/UniSGPnode.jl:96-104; loop
+ * experiments/regression_kin40k.ipynb:288-304): mean[s] = K(x*_s, Xu) mu_v^(d).  Xstar is D x ns (host),
+ * mu_v (host, d_out*M) or NULL to use the handle's current posterior; mean is ns x d_out. */
+int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const double* mu_v, double* mean);
+
+/* sgp_theta_objective: neg_log_backwardmess_fast (helper_functions/derivative_helper.jl:23-39) at the
+ * handle's kernel/posterior, and (grad != NULL) its gradient w.r.t. (sigma2, ell_1..ell_n_ell). */
+int sgp_theta_objective(sgp_handle* h, double* value, double* grad);
+
+/* ---- building blocks exposed for tests / other callers (host pointers, blocking) ------------
+ * K = sigma2 * exp(-0.5 |(a-b)/ell|^2): kernelmatrix(kernel(theta), A, B) of KernelFunctions.jl as called at
+ * GPnode/UniSGPnode.jl:102,153; A is D x na, B is D x nb, K is na x nb column-major. */
+int sgp_kernelmatrix(int32_t device, const double* A, int64_t na, const double* B, int64_t nb, int32_t d,
+                     double sigma2, const double* ell, int32_t n_ell, double* K);
+/* dense FP64 factorisations on the device (fastcholesky / cholinv call sites: GPnode/UniSGPnode.jl:68,
+ * experiments/regression_kin40k.ipynb:184): A is n x n column-major symmetric; L lower; Ainv full. */
+int sgp_potrf(int32_t device, const double* A, int32_t n, double* L);
+int sgp_potri(int32_t device, const double* A, int32_t n, double* Ainv);
+
+/* timing hooks for bench.py: device-side timestamps (100 MHz s_memrealtime) taken around the phases of the
+ * last sweep; out[2*i], out[2*i+1] = begin/end ticks of phase i (see SGP_T_*). */
+enum { SGP_T_SWEEP = 0, SGP_T_GRAM = 1, SGP_T_SYRK = 2, SGP_T_CHOL_LAMBDA = 3, SGP_T_INVERSE = 4,
+       SGP_T_UV = 5, SGP_T_KUU = 6, SGP_T_COUNT = 8 };
+int sgp_get_timestamps(sgp_handle* h, int64_t* out /* 2*SGP_T_COUNT */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGP_HIP_H */
