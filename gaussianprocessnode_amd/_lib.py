@@ -57,6 +57,14 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch (used for streams / torch.distributed around this library) bundles its own libamdhip64.so.7.
+    # A process must hold ONE HIP runtime: import torch first when it is installed so that this library's
+    # DT_NEEDED libamdhip64.so.7 resolves to the copy torch already loaded (loading the system runtime
+    # first leaves torch unable to see the GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = _build.LIB
     if not os.path.exists(path):
         if not build_if_missing:
