@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- VMP iterations/sec of the sparse-GP node's sweep on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload T|C2|C3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full VMP sweep over the resident synthetic data set: K_uu + Cholesky,
+K_uf, the summed :v messages (Psi2, b), q(v) incl. Sigma_v and Uv, the summed :w statistics and the summed
+average energy.  Inputs are resident in HBM before the timed region.  With N > 1 the points are sharded
+over the ranks (strong scaling: the data set is fixed) and the packed statistics are summed by one RCCL
+all-reduce per sweep.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (N, M, D)   -- BASELINE.json configs; T is the configuration the metric is quoted on
+    "T": (10000, 512, 8),
+    "C2": (10000, 256, 8),
+    "C3": (40000, 512, 8),
+}
+# trained kin40k hyper-parameters (softplus(theta_opt), experiments/regression_kin40k.ipynb:255-263)
+SIGMA2 = 0.17636613718898136
+ELL = np.array([2.994391934274809, 2.905302600576806, 1.7401945529137626, 2.2697267449222425,
+                2.0114338358466854, 1.5824668119572332, 1.533898096437981, 2.052099122165972])
+W_BAR = 1e4            # experiments/regression_kin40k.ipynb:118
+PRIOR_VAR = 50.0       # :203-204
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (AMD spec; tools/mfma_f64_probe.hip measures ~47.5 sustained)
+
+
+def synthetic(N, M, D, seed=1, n_test=2000):
+    """X ~ U(-1.745, 1.745), Xu = first M rows of a seeded permutation, y = sin(sum x) + 0.1 eps,
+    standardised."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1.745, 1.745, (N, D))
+    Xu = X[rng.permutation(N)[:M]].copy()
+    f = lambda Z: np.sin(Z.sum(axis=1))
+    y = f(X) + 0.1 * rng.normal(size=N)
+    mean, std = y.mean(), y.std()
+    y = (y - mean) / std
+    Xt = rng.uniform(-1.745, 1.745, (n_test, D))
+    yt = (f(Xt) + 0.1 * rng.normal(size=n_test) - mean) / std
+    return X, Xu, y, Xt, yt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="T", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gaussianprocessnode_amd import _lib
+    from gaussianprocessnode_amd.distributed import HipEngine, ShardedSweep, shard_bounds
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    N, M, D = WORKLOADS[args.workload]
+    X, Xu, y, Xt, yt = synthetic(N, M, D)
+    lo, hi = shard_bounds(N, world, rank)
+
+    eng = HipEngine(hi - lo, M, D, 1, device=local_rank)
+    dev = eng.dev
+    dev.set_inducing(Xu)
+    dev.set_data(X[lo:hi], y[lo:hi])
+    dev.set_kernel(SIGMA2, ELL, 0.0)
+    dev.set_prior_isotropic(PRIOR_VAR)
+    dev.set_noise([[W_BAR]])
+    sweep = ShardedSweep(eng)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sweep.sweep()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sweep.sweep()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- live per-kernel numbers (this rank's shard) ------------------------------------------------
+    stamps = dev.timestamps()                                   # 100 MHz ticks of the last timed sweep
+    tick_us = lambda i: (stamps[i, 1] - stamps[i, 0]) / 100.0
+    stream = torch.cuda.current_stream().cuda_stream
+    syrk_us = dev.time_kernel(_lib.SGP_T_SYRK, 50, stream)      # HIP events, eager launches, same stream
+    gram_us = dev.time_kernel(_lib.SGP_T_GRAM, 50, stream)
+    n_loc = hi - lo
+    syrk_flops = float(n_loc) * M * (M + 1)                     # SYRK lower half n M (M+1)
+    achieved = syrk_flops / (syrk_us * 1e-6) / 1e12
+
+    out = {
+        "metric": "VMP iterations/sec (sparse-GP node sweep, kin40k-shaped synthetic)",
+        "value": args.steps / elapsed,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: N={N} M={M} D={D} UniSGP regression, ARD-SE kernel at the trained kin40k "
+                               f"hyper-parameters, w=1e4, prior N(0,50I), jitter 0",
+                   "points_per_gpu": n_loc, "parallelism": f"data-sharded x{world}, 1 all-reduce of {eng.stats.numel()} f64"},
+        "roofline": {"kernel": "k_syrk_stream (Psi2 = K_uf K_uf^T, v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+                     "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "launch_us_hip_events": syrk_us, "launch_us_in_graph": tick_us(_lib.SGP_T_SYRK),
+                     "algorithmic_flops_per_launch": syrk_flops},
+        "phases_us": {"sweep_device": tick_us(_lib.SGP_T_SWEEP), "gram_uf_in_graph": tick_us(_lib.SGP_T_GRAM),
+                      "gram_uf_hip_events": gram_us, "syrk_in_graph": tick_us(_lib.SGP_T_SYRK)},
+    }
+
+    if rank == 0:
+        # ---- parity of what was timed + CPU baseline (rank 0; the oracle is the checker, never the product) ----
+        from oracle import sgp_oracle as O
+        mu, Sig, Uv = dev.posterior()
+        pred = dev.predict(Xt)
+        try:
+            from threadpoolctl import threadpool_limits
+        except ImportError:                                      # pragma: no cover
+            threadpool_limits = None
+        cores = min(16, os.cpu_count() or 1)
+        Lam0, xi0 = np.eye(M) / PRIOR_VAR, np.zeros(M)
+
+        def cpu_sweep():
+            return O.vmp_sweep(Xu, X, y, None, SIGMA2, ELL, W_BAR, jitter=0.0, Lambda0=Lam0, xi0=xi0)
+
+        ctx = threadpool_limits(limits=cores) if threadpool_limits else None
+        if ctx:
+            ctx.__enter__()
+        ref = cpu_sweep()
+        out["parity"] = {
+            "mu_v_rel_frobenius": float(np.linalg.norm(mu - ref.mu_v) / np.linalg.norm(ref.mu_v)),
+            "Sigma_v_rel_frobenius": float(np.linalg.norm(Sig - ref.Sigma_v) / np.linalg.norm(ref.Sigma_v)),
+            "Uv_rel_frobenius": float(np.linalg.norm(Uv - ref.Uv) / np.linalg.norm(ref.Uv)),
+            "smse_test": float(O.SMSE(yt, pred)),
+            "smse_test_oracle": float(O.SMSE(yt, O.predict_mean(Xu, Xt, ref.mu_v, SIGMA2, ELL))),
+            "tolerance": 1e-5,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            reps, t_cpu = 0, 0.0
+            while t_cpu < 10.0 and reps < 20:                    # bounded sample: ~10 s of CPU work
+                t1 = time.perf_counter()
+                cpu_sweep()
+                t_cpu += time.perf_counter() - t1
+                reps += 1
+            out["cpu_baseline"] = {"value": reps / t_cpu, "unit": "iterations/s", "cores": cores, "kind": "port",
+                                   "sample": f"{reps} full sweeps of the same workload by oracle/sgp_oracle.py "
+                                             f"(NumPy/OpenBLAS FP64, batched BLAS-3 restatement, {cores} threads)"}
+        if ctx:
+            ctx.__exit__(None, None, None)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

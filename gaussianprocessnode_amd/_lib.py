@@ -17,6 +17,7 @@ SGP_FLAG_KEEP_KUF = 2
 SGP_S_YY, SGP_S_W, SGP_S_N, SGP_S_COUNT = 0, 1, 2, 8
 (SGP_R_SUM_I1, SGP_R_SUM_I2, SGP_R_ENERGY, SGP_R_INFO_KUU, SGP_R_INFO_LAMBDA, SGP_R_INFO_PRIOR,
  SGP_R_LOGDET_KUU, SGP_R_LOGDET_LAMBDA, SGP_R_COUNT) = range(9)
+SGP_T_SWEEP, SGP_T_GRAM, SGP_T_SYRK = 0, 1, 2
 SGP_T_COUNT = 8
 
 EXPORTS = [
@@ -24,7 +25,7 @@ EXPORTS = [
     "sgp_set_kernel", "sgp_set_prior", "sgp_set_noise", "sgp_sweep_local", "sgp_sweep_finish", "sgp_sweep",
     "sgp_stats_layout", "sgp_bind_stats", "sgp_get_posterior", "sgp_get_scalars", "sgp_get_stats",
     "sgp_get_kuu_chol", "sgp_get_wishart_invscale", "sgp_w_stats", "sgp_predict", "sgp_theta_objective",
-    "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps",
+    "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_time_kernel",
 ]
 
 
@@ -99,6 +100,7 @@ def load(build_if_missing: bool = True):
     lib.sgp_potrf.argtypes = [C.c_int32, dp, C.c_int32, dp]
     lib.sgp_potri.argtypes = [C.c_int32, dp, C.c_int32, dp]
     lib.sgp_get_timestamps.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.sgp_time_kernel.argtypes = [vp, C.c_int32, C.c_int32, vp, dp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "sgp_last_error":

@@ -399,6 +399,8 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
     hipMemcpyAsync(h->dParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice, s);
     hipMemsetAsync(h->dInfo, 0, 2 * sizeof(int), s);
+    hipLaunchKernelGGL(k_stamp_reset, dim3(1), dim3(64), 0, s, h->dStamps, (int)SGP_T_COUNT);
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, s, h->dStamps + 2 * SGP_T_SWEEP);
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->dParams, M, Mp, D);
     // fork: the K_uu chain depends on theta and Xu only and runs beside the data-sized work
     hipEventRecord(h->evFork, s);
@@ -411,9 +413,10 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     // data-sized work
     if (h->n > 0) {
         hipLaunchKernelGGL(k_gram_uf, dim3(T, h->nblk), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
-                           h->dParams, M, Mp, D, h->n, h->dout);
+                           h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + 2 * SGP_T_GRAM);
         hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles, h->nchunks), dim3(256), 0, s, h->dKuf,
-                           h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk);
+                           h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk,
+                           h->dStamps + 2 * SGP_T_SYRK);
     }
     hipLaunchKernelGGL(k_assemble, dim3(T, T), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
                        h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
@@ -438,6 +441,7 @@ static void enqueue_finish(sgp_handle* h, hipStream_t s) {
                        h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS);
     // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69): factor R in place (lower), transposed on read-out
     launch_potrf(h->dR, Qp, TQ, h->dInfo + 3, Q, s);
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, s, h->dStamps + 2 * SGP_T_SWEEP + 1);
 }
 
 typedef void (*enqueue_fn)(sgp_handle*, hipStream_t);
@@ -590,6 +594,40 @@ extern "C" int sgp_get_timestamps(sgp_handle* h, int64_t* out) {
     int rc = sync_all(h);
     if (rc) return rc;
     HIPCHK(h, hipMemcpy(out, h->dStamps, 2 * SGP_T_COUNT * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HIP-event timing of one data-sized kernel of the sweep, launched eagerly `iters` times on `stream`
+// (bench.py's roofline leg; both kernels are idempotent on the resident data)
+// ------------------------------------------------------------------------------------------------
+extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void* stream, double* avg_us) {
+    if (!h || !avg_us || iters < 1) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: bad argument");
+    if (!h->swept_local || h->n == 0) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: run a sweep on non-empty data first");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    auto launch = [&]() {
+        if (which == SGP_T_GRAM)
+            hipLaunchKernelGGL(k_gram_uf, dim3(h->T, h->nblk), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
+                               h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr);
+        else
+            hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles, h->nchunks), dim3(256), 0, s, h->dKuf,
+                               h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->chunk, (int64_t*)nullptr);
+    };
+    if (which != SGP_T_GRAM && which != SGP_T_SYRK) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: which must be SGP_T_GRAM or SGP_T_SYRK");
+    launch();
+    HIPCHK(h, hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) launch();
+    HIPCHK(h, hipEventRecord(e1, s));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *avg_us = 1e3 * (double)ms / iters;
     return 0;
 }
 

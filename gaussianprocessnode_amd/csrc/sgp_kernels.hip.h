@@ -48,6 +48,17 @@ __device__ __forceinline__ int64_t realtime_ticks() { return (int64_t)__builtin_
 __global__ void k_stamp(int64_t* slot) {
     if (threadIdx.x == 0) *slot = realtime_ticks();
 }
+// first-block-in / last-block-out stamps of a multi-block kernel: stamps[0] = min entry, stamps[1] = max exit
+__device__ __forceinline__ void stamp_enter(int64_t* stamps) {
+    if (stamps && threadIdx.x == 0) atomicMin(reinterpret_cast<long long*>(stamps), (long long)realtime_ticks());
+}
+__device__ __forceinline__ void stamp_exit(int64_t* stamps) {
+    if (stamps && threadIdx.x == 0) atomicMax(reinterpret_cast<long long*>(stamps + 1), (long long)realtime_ticks());
+}
+__global__ void k_stamp_reset(int64_t* stamps, int nslots) {
+    int i = threadIdx.x;
+    if (i < nslots) { stamps[2 * i] = 0x7fffffffffffffffLL; stamps[2 * i + 1] = 0; }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Xu (D x M, AoS) -> Xus (SoA, scaled by 1/ell, padded to Mp with zeros)
@@ -97,8 +108,9 @@ __global__ void __launch_bounds__(256) k_gram_uu(const double* __restrict__ Xus,
 __global__ void __launch_bounds__(256) k_gram_uf(const double* __restrict__ Xus, const double* __restrict__ X,
                                                  const double* __restrict__ Yw, double* __restrict__ Kuf,
                                                  double* __restrict__ bpart, const Params* __restrict__ P,
-                                                 int M, int Mp, int D, int64_t N, int d_out) {
+                                                 int M, int Mp, int D, int64_t N, int d_out, int64_t* stamps) {
     __shared__ double us[MAXD * TB];
+    stamp_enter(stamps);
     __shared__ double xs[MAXD * TB];
     __shared__ double ys[MAXO * TB];
     __shared__ double red[16 * TB];
@@ -168,6 +180,7 @@ __global__ void __launch_bounds__(256) k_gram_uf(const double* __restrict__ Xus,
             bpart[((size_t)blockIdx.y * d_out + o) * Mp + I + threadIdx.x] = s;
         }
     }
+    stamp_exit(stamps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -246,8 +259,10 @@ __device__ __forceinline__ void tile_from_index(int t, int& I, int& J) {
 }
 
 __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
-                                                     double* __restrict__ slabs, int Mp, int64_t N, int chunk) {
+                                                     double* __restrict__ slabs, int Mp, int64_t N, int chunk,
+                                                     int64_t* stamps) {
     __shared__ double lds[2 * 2 * KB * PS];           // [buf][panel A|B][KB][PS]
+    stamp_enter(stamps);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     int I, J;
     tile_from_index(blockIdx.x, I, J);
@@ -309,6 +324,7 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 out[acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj)] = acc.t[ti][tj][r];
+    stamp_exit(stamps);
 }
 
 // ------------------------------------------------------------------------------------------------

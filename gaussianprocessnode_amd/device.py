@@ -169,6 +169,13 @@ class SGPDevice:
               "sgp_theta_objective")
         return v.value
 
+    def time_kernel(self, which: int, iters: int = 20, stream: int = 0) -> float:
+        """Average launch duration (microseconds, HIP events) of the Gram or streaming-SYRK kernel."""
+        v = C.c_double()
+        check(self._lib.sgp_time_kernel(self._h, int(which), int(iters), C.c_void_p(stream),
+                                        C.cast(C.byref(v), C.POINTER(C.c_double))), self._h, "sgp_time_kernel")
+        return v.value
+
     def timestamps(self):
         out = (C.c_int64 * (2 * _lib.SGP_T_COUNT))()
         check(self._lib.sgp_get_timestamps(self._h, out), self._h, "sgp_get_timestamps")

@@ -1,0 +1,116 @@
+"""Data-sharded VMP sweep: one process per GPU, points block-partitioned over the ranks, ONE
+sum-all-reduce of the packed M x M statistics per sweep.
+
+The reference has no counterpart (it is single-process); additivity of the statistics is what its
+N-fold message product (GPnode/UniSGPnode.jl:62-63) and its sequential minibatch carry
+(experiments/regression_kin40k.ipynb:205-212) already rely on.
+
+`torch.distributed` is plumbing here: with backend "nccl" the all-reduce IS RCCL over xGMI.  The local
+statistics and the replicated tail come from an *engine*; the product engine is `HipEngine` (the C ABI
+on this rank's MI355X).  Tests inject a CPU engine to cover sharding, packing and the collective under
+gloo -- there is no CPU fallback in the product: `HipEngine` raises without the HIP library / a GPU.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+TILE = 64
+S_COUNT = 8          # SGP_S_COUNT of include/sgp_hip.h
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Block partition of n points: the first (n mod world) ranks get one extra point."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def padded(m: int) -> int:
+    return (int(m) + TILE - 1) // TILE * TILE
+
+
+def stats_count(m: int, d_out: int = 1) -> int:
+    """Doubles in the packed statistics buffer [Psi2: Mp*Mp | B: Mp*d_out | scalars | Ryy: d_out^2]."""
+    mp = padded(m)
+    return mp * mp + mp * d_out + S_COUNT + d_out * d_out
+
+
+def pack_stats(Psi2, B, s_yy: float, s_w: float, n_nodes: float, Ryy=None) -> np.ndarray:
+    """Host-side packing in the device layout (column-major, padded) -- used by CPU test engines."""
+    Psi2 = np.asarray(Psi2, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64).reshape(Psi2.shape[0], -1)
+    m, d_out = B.shape
+    mp = padded(m)
+    out = np.zeros(stats_count(m, d_out))
+    P = np.zeros((mp, mp))
+    P[:m, :m] = Psi2
+    out[:mp * mp] = P.T.reshape(-1)                      # column-major
+    Bp = np.zeros((d_out, mp))
+    Bp[:, :m] = B.T
+    out[mp * mp:mp * mp + mp * d_out] = Bp.reshape(-1)
+    sc = out[mp * mp + mp * d_out:]
+    sc[0], sc[1], sc[2] = s_yy, s_w, n_nodes
+    if Ryy is not None:
+        sc[S_COUNT:S_COUNT + d_out * d_out] = np.asarray(Ryy, dtype=np.float64).T.reshape(-1)
+    elif d_out == 1:
+        sc[S_COUNT] = s_yy
+    return out
+
+
+def unpack_stats(buf, m: int, d_out: int = 1):
+    """Inverse of pack_stats: (Psi2 (M,M), B (M,d_out), s_yy, s_w, n_nodes, Ryy (d_out,d_out))."""
+    buf = np.asarray(buf, dtype=np.float64)
+    mp = padded(m)
+    Psi2 = buf[:mp * mp].reshape(mp, mp).T[:m, :m].copy()
+    B = buf[mp * mp:mp * mp + mp * d_out].reshape(d_out, mp)[:, :m].T.copy()
+    sc = buf[mp * mp + mp * d_out:]
+    Ryy = sc[S_COUNT:S_COUNT + d_out * d_out].reshape(d_out, d_out).T.copy()
+    return Psi2, B, float(sc[0]), float(sc[1]), float(sc[2]), Ryy
+
+
+class HipEngine:
+    """This rank's shard on its MI355X: local statistics and the replicated tail through the C ABI."""
+
+    def __init__(self, n_max: int, m: int, d: int, d_out: int = 1, device: int = 0, use_graph: bool = True):
+        import torch
+        from .device import SGPDevice
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipEngine needs a gfx950 GPU (the product path has no CPU fallback)")
+        torch.cuda.set_device(device)
+        self.torch = torch
+        self.dev = SGPDevice(n_max, m, d, d_out, device=device, use_graph=use_graph)
+        self.stats = torch.zeros(stats_count(m, d_out), dtype=torch.float64, device=f"cuda:{device}")
+        self.dev.bind_stats(self.stats.data_ptr())
+
+    def _stream(self) -> int:
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def sweep_local(self):
+        self.dev.sweep_local(self._stream())
+
+    def sweep_finish(self):
+        self.dev.sweep_finish(self._stream())
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+
+class ShardedSweep:
+    """local statistics -> all-reduce(sum) -> replicated tail.  `engine` provides sweep_local(),
+    sweep_finish() and a torch tensor `stats`; `group` is a torch.distributed process group (None = default;
+    no collective is issued when torch.distributed is not initialised or the world has one rank)."""
+
+    def __init__(self, engine, group=None):
+        self.engine = engine
+        self.group = group
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def sweep(self):
+        self.engine.sweep_local()
+        if self.world > 1:
+            self.dist.all_reduce(self.engine.stats, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.engine.sweep_finish()

@@ -151,11 +151,15 @@ int sgp_kernelmatrix(int32_t device, const double* A, int64_t na, const double* 
 int sgp_potrf(int32_t device, const double* A, int32_t n, double* L);
 int sgp_potri(int32_t device, const double* A, int32_t n, double* Ainv);
 
-/* timing hooks for bench.py: device-side timestamps (100 MHz s_memrealtime) taken around the phases of the
- * last sweep; out[2*i], out[2*i+1] = begin/end ticks of phase i (see SGP_T_*). */
+/* timing hooks for bench.py: device-side timestamps (100 MHz s_memrealtime) of the last sweep:
+ * out[2*i], out[2*i+1] = begin/end ticks of phase i (SGP_T_SWEEP: whole sweep; SGP_T_GRAM / SGP_T_SYRK:
+ * first-block-in / last-block-out of the K_uf and streaming-SYRK kernels). */
 enum { SGP_T_SWEEP = 0, SGP_T_GRAM = 1, SGP_T_SYRK = 2, SGP_T_CHOL_LAMBDA = 3, SGP_T_INVERSE = 4,
        SGP_T_UV = 5, SGP_T_KUU = 6, SGP_T_COUNT = 8 };
 int sgp_get_timestamps(sgp_handle* h, int64_t* out /* 2*SGP_T_COUNT */);
+/* HIP-event timing of one data-sized kernel (which = SGP_T_GRAM or SGP_T_SYRK) launched eagerly `iters` times on
+ * `stream` with the resident data of the last sweep; returns the average launch duration in microseconds. */
+int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void* stream, double* avg_us);
 
 #ifdef __cplusplus
 }
