@@ -91,9 +91,8 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // ------------------------------------------------------------------------------------------------
 static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, hipStream_t s) {
     for (int j = 0; j < Tn; ++j) {
-        hipLaunchKernelGGL(k_potrf_panel, dim3(Tn - j), dim3(256), 0, s, A, ld, j, info, n_valid);
-        int nt = Tn - 1 - j;
-        if (nt > 0) hipLaunchKernelGGL(k_potrf_trail, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, A, ld, j);
+        int nt = Tn - j;
+        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, A, ld, j, info, n_valid);
     }
 }
 static void launch_trtri(const double* L, double* W, int ld, int Tn, hipStream_t s) {
@@ -418,7 +417,7 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
                            h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk,
                            h->dStamps + 2 * SGP_T_SYRK);
     }
-    hipLaunchKernelGGL(k_assemble, dim3(T, T), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
+    hipLaunchKernelGGL(k_assemble, dim3(T, T, 4), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
                        h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
                        SGP_S_COUNT + h->dout * h->dout);
     hipStreamWaitEvent(s, h->evSide, 0);     // join (also keeps the side chain inside a captured graph)

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 namespace sgp {
 
@@ -24,6 +25,7 @@ constexpr int PS = 80;          // LDS panel row stride (doubles): 2*PS*2 dwords
 constexpr int KB = 16;          // points (k extent) per LDS stage of the streaming SYRK
 constexpr int MAXD = 32;        // max input dimension
 constexpr int MAXO = 4;         // max outputs of a MultiSGP node
+constexpr int LT = TB + 1;      // row stride of a 64 x 64 LDS tile
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -334,32 +336,67 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
 __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ slabs, const double* __restrict__ bpart,
                                                   const double* __restrict__ data_scalars, double* __restrict__ stats,
                                                   int Mp, int ntiles, int nchunks, int nblk, int d_out, int nscal) {
-    __shared__ double tile[TB * (TB + 1)];
-    const int I = blockIdx.x, J = blockIdx.y;
+    // grid (T, T, 4): block z sums rows [16 z, 16 z + 16) of the slab tile (I, J), I >= J, and writes both mirror images
+    __shared__ double tile[16 * LT];
+    const int I = blockIdx.x, J = blockIdx.y, z = blockIdx.z;
     const int tid = threadIdx.x;
     if (I >= J) {
         const int t = I * (I + 1) / 2 + J;
-        for (int e = tid; e < TB * TB; e += 256) {      // e = i * 64 + j (slab order, coalesced)
-            double s = 0.0;
-            for (int c = 0; c < nchunks; ++c) s += slabs[((size_t)c * ntiles + t) * (TB * TB) + e];
-            tile[(e >> 6) * (TB + 1) + (e & 63)] = s;   // tile[i][j]
+        const double* base = slabs + (size_t)t * (TB * TB) + z * 16 * TB;
+        const size_t cstride = (size_t)ntiles * (TB * TB);
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        int c = 0;
+        for (; c + 4 <= nchunks; c += 4) {                 // 16 independent loads in flight per thread
+            double v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = base[(size_t)(c + u) * cstride + e * 256 + tid];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)                      // fixed summation order: chunk 0, 1, 2, ...
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] += v[u][e];
+        }
+        for (; c < nchunks; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += base[(size_t)c * cstride + e * 256 + tid];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int idx = e * 256 + tid;                         // = i_local * 64 + j
+            tile[(idx >> 6) * LT + (idx & 63)] = s[e];
         }
         __syncthreads();
-        for (int e = tid; e < TB * TB; e += 256) {
-            int j = e >> 6, i = e & 63;                 // coalesced along i
-            stats[(size_t)(J * TB + j) * Mp + I * TB + i] = tile[i * (TB + 1) + j];
-            if (I != J) stats[(size_t)(I * TB + i) * Mp + J * TB + j] = tile[i * (TB + 1) + j];
+        for (int e = tid; e < 16 * TB; e += 256) {
+            int j = e >> 4, il = e & 15;                     // 16 consecutive i per column j
+            stats[(size_t)(J * TB + j) * Mp + I * TB + z * 16 + il] = tile[il * LT + j];
         }
+        if (I != J)
+            for (int e = tid; e < 16 * TB; e += 256) {
+                int il = e >> 6, j = e & 63;                 // mirror: 64 consecutive j per row i
+                stats[(size_t)(I * TB + z * 16 + il) * Mp + J * TB + j] = tile[il * LT + j];
+            }
     }
-    if (I == 0 && J == 0) {
+    // B = sum of the per-block partials: blocks (I, 0, z) take outputs o = z, z + 4, ...; 4 threads per entry walk
+    // the partials with a stride of 4 (independent loads in flight), combined in a fixed order through LDS
+    if (J == 0) {
+        __shared__ double red[4 * TB];
         double* B = stats + (size_t)Mp * Mp;
-        for (int e = tid; e < Mp * d_out; e += 256) {
-            int o = e / Mp, m = e % Mp;
-            double s = 0.0;
-            for (int b = 0; b < nblk; ++b) s += bpart[((size_t)b * d_out + o) * Mp + m];
-            B[e] = s;
+        const int m = tid & 63, part = tid >> 6;
+        for (int o = z; o < d_out; o += 4) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            int b = part;
+            for (; b + 12 < nblk; b += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] += bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + I * TB + m];
+            }
+            for (; b < nblk; b += 4) acc[0] += bpart[((size_t)b * d_out + o) * Mp + I * TB + m];
+            __syncthreads();
+            red[part * TB + m] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            __syncthreads();
+            if (part == 0) B[(size_t)o * Mp + I * TB + m] = (red[m] + red[TB + m]) + (red[2 * TB + m] + red[3 * TB + m]);
         }
-        for (int e = tid; e < nscal; e += 256) B[(size_t)Mp * d_out + e] = data_scalars[e];
+        if (I == 0 && z == 0)
+            for (int e = tid; e < nscal; e += 256) B[(size_t)Mp * d_out + e] = data_scalars[e];
     }
 }
 
@@ -398,135 +435,247 @@ __global__ void __launch_bounds__(256) k_form_lambda(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Blocked right-looking Cholesky (lower), tile 64.
-//   k_potrf_panel(j): block b of the grid owns row-block i = j + b of block column j.  Every block factors
-//   the 64 x 64 diagonal tile itself in LDS (redundant compute instead of an inter-block hand-off), block 0
-//   writes L_jj, blocks b >= 1 solve X L_jj^T = A_ij for their tile.
-//   k_potrf_trail(j): A_ik -= L_ij L_kj^T for j < k <= i on the matrix cores.
-// Thread layout of the panel kernel: 4 adjacent lanes (q = tid & 3) share one row r = tid >> 2; lane q keeps
-// the row's entries k = q (mod 4) in registers, so a row never needs another row's registers; the factor's
-// rows are exchanged through LDS.  `info` receives (global column + 1) of the first non-positive pivot.
+// Blocked right-looking Cholesky (lower), tile 64, ONE launch per block step (look-ahead by redundancy):
+//   k_potrf_step(j): block (a, b) of the trailing matrix first applies the rank-64 update of step j-1
+//   (A_ik -= L_i,j-1 L_k,j-1^T on the matrix cores).  Blocks of the first trailing column (b = 0) then
+//   continue with step j without leaving the kernel: each of them ALSO updates and factors the diagonal
+//   tile A_jj itself in LDS (redundant compute instead of an inter-block hand-off) and solves
+//   X L_jj^T = A_ij for its own tile; the block on the diagonal writes L_jj.
+// Thread layout of the sequential parts: 4 adjacent lanes (q = tid & 3) share one row r = tid >> 2 and lane q
+// keeps the row's entries c = q (mod 4) in registers (right-looking, no reductions; the quad exchanges the
+// pivot-column entry with a DPP quad broadcast).  The factorisation needs one barrier per column (the pivot
+// column travels through a double-buffered LDS vector), the triangular solve none.
+// `info` receives (global column + 1) of the first non-positive pivot (LAPACK convention).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double quad_sum(double v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    return v;
+
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
 
-// Factor the lower triangle held in S (64 x 64, row stride TB+1, S[r][c]) in place:
-// on exit S[r][c] (c <= r) holds the UNNORMALISED column sums s_rc and rinv[c] = 1/sqrt(s_cc);
-// L[r][c] = s_rc * rinv[c].
-__device__ __forceinline__ void potf2_lds(double* S, double* rinv, int* info, int col_base, int n_valid) {
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// 1/sqrt(d): v_rsq_f64 seed + two Newton steps (full double precision to a few ulp)
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
+// ---- permuted LDS layouts of the sequential tile routines --------------------------------------------------
+// A lane (row r, quarter q) owns the row's entries of columns c = q (mod 4).  Whatever it needs per pivot from
+// OTHER rows (the pivot column / a row or column of L) is stored so that its 16 values are contiguous and 16-byte
+// aligned: index (q, i) <-> column or row 4 i + q, with 32 slots per q (slots 16..31 are a dead zone read by the
+// sliding register window past column 63).  One ds_read_b128 then brings two values (ds_read_b64 needs ~4 waves
+// per SIMD to reach its rate, ds_read_b128 does with the one wave per SIMD these kernels run at).
+constexpr int QS = 34;                 // slots per quarter: 32 + 2 so that the four quarters fall on different banks
+constexpr int PR = 4 * QS;             // doubles per permuted row
+
+__device__ __forceinline__ void load16(double (&t)[16], const double* p) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        double2 v = *reinterpret_cast<const double2*>(p + 2 * u);
+        t[2 * u] = v.x;
+        t[2 * u + 1] = v.y;
+    }
+}
+
+// Factor the 64 x 64 tile S (LDS, S[r][c], stride LT, lower part valid).  On exit rinv[c] = 1 / L_cc and L is
+// written to S in place (strict upper part zero) when Lp == nullptr, else to the permuted tile
+// Lp[k * PR + (c & 3) * QS + (c >> 2)] = L[c][k] that trsm_tile reads.  colp: 2 * PR doubles.
+// Register window: a[j] is the row's entry of column 4 (g + j) + q while column groups g, g + 1 are eliminated;
+// the window slides by two groups after every eight pivots, so all register indices are static inside a genuine
+// loop (a fully unrolled 64-pivot body made the scheduler interleave pivots and spill hundreds of registers).
+// Window entries past column 63 are dead: they are updated with whatever the dead zone holds and never used.
+__device__ __forceinline__ void potf2_tile(double* S, double* Lp, double* colp, double* rinv, int* info, int col_base,
+                                           int n_valid) {
     const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
-    double Ls[16];                               // s_rk / s_kk for k = 4 i + q
+    double a[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Ls[i] = 0.0;
+    for (int i = 0; i < 16; ++i) {
+        int c = 4 * i + q;
+        a[i] = (c <= r) ? S[r * LT + c] : 0.0;
+    }
+    __syncthreads();                                    // S may be overwritten from here on
+    if (q == 0) colp[(r & 3) * QS + (r >> 2)] = a[0];   // pivot column 0, buffer 0
+#pragma unroll 1
+    for (int g = 0; g < 16; g += 2) {
+        static_for<8>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int kq = p & 3, wh = p >> 2;      // pivot k = 4 (g + wh) + kq, held in a[wh] of lane kq
+            const int k = 4 * (g + wh) + kq;
+            __syncthreads();
+            const double* col = colp + (k & 1) * PR;
+            double d = col[kq * QS + g + wh];
+            if (!(d > 0.0)) {
+                if (tid == 0 && col_base + k < n_valid) atomicCAS(info, 0, col_base + k + 1);
+                d = 1.0;
+            }
+            const double ri = rsqrt_nr(d);
+            double v = quad_bcast<kq>(a[wh]);
+            v = (r >= k) ? v : 0.0;                      // rows above the pivot take no part
+            const double f = v * (ri * ri);              // a_rk / d
+            if (q == kq) {
+                if (Lp) Lp[k * PR + (r & 3) * QS + (r >> 2)] = v * ri;
+                else S[r * LT + k] = v * ri;             // L_rk (zero above the diagonal)
+            }
+            if (tid == 0) rinv[k] = ri;
+            double t[16];
+            load16(t, col + q * QS + g);                 // pivot-column entries of columns 4 (g + j) + q
+            // the next pivot column first, so that it is published while the rest of the update runs
+            constexpr int nwh = (p + 1) >> 2, nq = (p + 1) & 3;            // (nwh may be 2: next iteration's a[0])
+            if constexpr (p == 3) {
+                a[1] = fma(-f, t[1], a[1]);
+                if (q == 0) colp[((k + 1) & 1) * PR + ((r & 3) * QS + (r >> 2))] = a[1];
+            } else if constexpr (p == 7) {
+                a[2] = fma(-f, t[2], a[2]);
+                if (q == 0 && g < 14) colp[((k + 1) & 1) * PR + ((r & 3) * QS + (r >> 2))] = a[2];
+            } else {
+                a[wh] = fma(-f, (q > kq) ? t[wh] : 0.0, a[wh]);
+                if (q == nq) colp[((k + 1) & 1) * PR + ((r & 3) * QS + (r >> 2))] = a[wh];
+            }
 #pragma unroll
-    for (int c = 0; c < TB; ++c) {
-        double part = 0.0;
+            for (int j = wh; j < 16; ++j) {
+                if (p == 3 && j == 1) continue;
+                if (p == 7 && j == 2) continue;
+                if (p != 3 && p != 7 && j == wh) continue;
+                if (j == wh) a[j] = fma(-f, (q > kq) ? t[j] : 0.0, a[j]);
+                else a[j] = fma(-f, t[j], a[j]);
+            }
+            (void)nwh;
+        });
 #pragma unroll
-        for (int i = 0; i < (c + 3) / 4; ++i) {
-            int k = 4 * i + q;
-            double sck = (k < c) ? S[c * (TB + 1) + k] : 0.0;
-            part = fma(Ls[i], sck, part);
-        }
-        double sum = quad_sum(part);
-        double s_rc = S[r * (TB + 1) + c] - sum;
-        if (r >= c && q == 0) S[r * (TB + 1) + c] = s_rc;
-        __syncthreads();
-        double scc = S[c * (TB + 1) + c];
-        if (!(scc > 0.0)) {
-            if (tid == 0 && col_base + c < n_valid) atomicCAS(info, 0, col_base + c + 1);
-            scc = 1.0;
-        }
-        double ri = 1.0 / sqrt(scc);
-        if (tid == 0) rinv[c] = ri;
-        if ((c & 3) == q) Ls[c >> 2] = (r >= c) ? s_rc * ri * ri : 0.0;
+        for (int j = 0; j < 14; ++j) a[j] = a[j + 2];
+        a[14] = 0.0;
+        a[15] = 0.0;
     }
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) k_potrf_panel(double* __restrict__ A, int ld, int j, int* __restrict__ info, int n_valid) {
-    __shared__ double S[TB * (TB + 1)];
-    __shared__ double X[TB * (TB + 1)];
-    __shared__ double rinv[TB];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    const int j0 = j * TB;
-    for (int e = tid; e < TB * TB; e += 256) {           // coalesced along rows of the column-major tile
+// Solve X L^T = B in place: X (LDS tile, stride LT) holds B on entry and X on exit; Lp is the permuted L written by
+// potf2_tile, rinv = 1 / diag(L).  Rows are independent: no barrier inside.  Same sliding window.
+__device__ __forceinline__ void trsm_tile(double* X, const double* Lp, const double* rinv) {
+    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = X[r * LT + 4 * i + q];
+#pragma unroll 1
+    for (int g = 0; g < 16; g += 2) {
+        static_for<8>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int kq = p & 3, wh = p >> 2;
+            const int k = 4 * (g + wh) + kq;
+            double t[16];
+            load16(t, Lp + k * PR + q * QS + g);                      // L_ck for c = 4 (g + j) + q
+            const double v = quad_bcast<kq>(x[wh]) * rinv[k];         // X_rk
+            if (q == kq) X[r * LT + k] = v;
+#pragma unroll
+            for (int j = wh; j < 16; ++j) {
+                if (j == wh) x[j] = fma(-v, (q > kq) ? t[j] : 0.0, x[j]);
+                else x[j] = fma(-v, t[j], x[j]);
+            }
+        });
+#pragma unroll
+        for (int j = 0; j < 14; ++j) x[j] = x[j + 2];
+        x[14] = 0.0;
+        x[15] = 0.0;
+    }
+}
+
+// coalesced copies between a column-major global tile and an LDS tile S[r][c]
+__device__ __forceinline__ void tile_g2s(double* S, const double* __restrict__ A, size_t ld, int row0, int col0) {
+    for (int e = threadIdx.x; e < TB * TB; e += 256) {
         int c = e >> 6, r = e & 63;
-        S[r * (TB + 1) + c] = A[(size_t)(j0 + c) * ld + j0 + r];
-    }
-    if (b > 0) {
-        const int i0 = (j + b) * TB;
-        for (int e = tid; e < TB * TB; e += 256) {
-            int c = e >> 6, r = e & 63;
-            X[r * (TB + 1) + c] = A[(size_t)(j0 + c) * ld + i0 + r];
-        }
-    }
-    __syncthreads();
-    potf2_lds(S, rinv, info, j0, n_valid);
-    if (b == 0) {
-        for (int e = tid; e < TB * TB; e += 256) {
-            int c = e >> 6, r = e & 63;
-            A[(size_t)(j0 + c) * ld + j0 + r] = (r >= c) ? S[r * (TB + 1) + c] * rinv[c] : 0.0;
-        }
-        return;
-    }
-    // X_rc = (A_rc - sum_{k<c} X_rk L_ck) / L_cc,  L_ck = s_ck rinv_k,  L_cc = 1 / rinv_c
-    const int r = tid >> 2, q = tid & 3;
-    double Xs[16];                                      // X_rk * rinv_k for k = 4 i + q
-#pragma unroll
-    for (int i = 0; i < 16; ++i) Xs[i] = 0.0;
-#pragma unroll
-    for (int c = 0; c < TB; ++c) {
-        double part = 0.0;
-#pragma unroll
-        for (int i = 0; i < (c + 3) / 4; ++i) {
-            int k = 4 * i + q;
-            double sck = (k < c) ? S[c * (TB + 1) + k] : 0.0;
-            part = fma(Xs[i], sck, part);
-        }
-        double sum = quad_sum(part);
-        double ri = rinv[c];
-        double x = (X[r * (TB + 1) + c] - sum) * ri;
-        if (q == 0) X[r * (TB + 1) + c] = x;
-        if ((c & 3) == q) Xs[c >> 2] = x * ri;
-    }
-    __syncthreads();
-    const int i0 = (j + b) * TB;
-    for (int e = tid; e < TB * TB; e += 256) {
-        int c = e >> 6, rr = e & 63;
-        A[(size_t)(j0 + c) * ld + i0 + rr] = X[rr * (TB + 1) + c];
+        S[r * LT + c] = A[(size_t)(col0 + c) * ld + row0 + r];
     }
 }
-
-__global__ void __launch_bounds__(256) k_potrf_trail(double* __restrict__ A, int ld, int j) {
-    __shared__ double lds[2 * TB * PS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    int a, b;
-    tile_from_index(blockIdx.x, a, b);                   // a >= b, offsets within the trailing matrix
-    const int i0 = (j + 1 + a) * TB, k0 = (j + 1 + b) * TB, j0 = j * TB;
-    double* As = lds;
-    double* Bs = lds + TB * PS;
-    load_panel_n(As, A, ld, i0, j0, TB, tid);
-    if (a != b) load_panel_n(Bs, A, ld, k0, j0, TB, tid);
-    __syncthreads();
-    Acc4 acc;
-    acc_zero(acc);
-    tile_mma(acc, As, (a != b) ? Bs : As, TB, lane, wr, wc);
+__device__ __forceinline__ void tile_s2g(const double* S, double* __restrict__ A, size_t ld, int row0, int col0) {
+    for (int e = threadIdx.x; e < TB * TB; e += 256) {
+        int c = e >> 6, r = e & 63;
+        A[(size_t)(col0 + c) * ld + row0 + r] = S[r * LT + c];
+    }
+}
+__device__ __forceinline__ void tile_sub_acc(double* S, const Acc4& acc, int lane, int wr, int wc) {
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int row = acc_row(lane, wr, ti, r), col = acc_col(lane, wc, tj);
-                if (a != b || row >= col) {
-                    size_t idx = (size_t)(k0 + col) * ld + i0 + row;
-                    A[idx] -= acc.t[ti][tj][r];
-                }
-            }
+            for (int r = 0; r < 4; ++r)
+                S[acc_row(lane, wr, ti, r) * LT + acc_col(lane, wc, tj)] -= acc.t[ti][tj][r];
+}
+
+__global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int ld, int j, int* __restrict__ info, int n_valid) {
+    // LDS: two MFMA operand panels (2 x 64 x PS) during the update, re-used afterwards as two 64 x 64 tiles;
+    // the permuted factor for the triangular solve; the permuted pivot-column double buffer
+    __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
+    __shared__ __attribute__((aligned(16))) double Lp[TB * PR];
+    __shared__ __attribute__((aligned(16))) double colp[2 * PR];
+    __shared__ double rinv[TB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    int a, b;
+    tile_from_index(blockIdx.x, a, b);                    // a >= b, tile (j + a, j + b) of the matrix
+    const int i0 = (j + a) * TB, k0 = (j + b) * TB, j0 = j * TB;
+    double* P0 = lds;
+    double* P1 = lds + TB * PS;
+    double* S = lds;                                      // diagonal tile A_jj (panel column blocks only)
+    double* X = lds + TB * LT;                            // this block's own tile
+    Acc4 accX, accD;
+    acc_zero(accX);
+    acc_zero(accD);
+    const bool panel = (b == 0);
+    if (j > 0) {
+        const int p0 = (j - 1) * TB;
+        load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
+        if (a != b) load_panel_n(P1, A, ld, k0, p0, TB, tid);   // L_{k, j-1}
+        __syncthreads();
+        const double* Pb = (a != b) ? P1 : P0;
+        tile_mma(accX, P0, Pb, TB, lane, wr, wc);
+        if (panel && a != 0) tile_mma(accD, P1, P1, TB, lane, wr, wc);   // the diagonal tile's update, redundantly
+        __syncthreads();
+    }
+    if (!panel) {
+        // plain trailing tile: A_ik -= acc, through LDS for coalesced global access
+        tile_g2s(X, A, ld, i0, k0);
+        __syncthreads();
+        tile_sub_acc(X, accX, lane, wr, wc);
+        __syncthreads();
+        tile_s2g(X, A, ld, i0, k0);
+        return;
+    }
+    if (a == 0) {
+        tile_g2s(S, A, ld, j0, j0);
+        __syncthreads();
+        tile_sub_acc(S, accX, lane, wr, wc);
+    } else {
+        tile_g2s(S, A, ld, j0, j0);
+        tile_g2s(X, A, ld, i0, j0);
+        __syncthreads();
+        tile_sub_acc(S, accD, lane, wr, wc);
+        tile_sub_acc(X, accX, lane, wr, wc);
+    }
+    __syncthreads();
+    potf2_tile(S, (a == 0) ? nullptr : Lp, colp, rinv, info, j0, n_valid);
+    if (a == 0) {
+        tile_s2g(S, A, ld, j0, j0);
+        return;
+    }
+    trsm_tile(X, Lp, rinv);
+    __syncthreads();
+    tile_s2g(X, A, ld, i0, j0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -537,37 +686,48 @@ __global__ void __launch_bounds__(256) k_potrf_trail(double* __restrict__ A, int
 //       W_ic = - W_ii * sum_{c<=k<i} L_ik W_kc          (two MFMA products per block row)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_trtri_diag(const double* __restrict__ L, double* __restrict__ W, int ld) {
-    __shared__ double S[TB * (TB + 1)];                 // S[k][c] = L_kc
-    __shared__ double Xo[TB * (TB + 1)];
+    // Lq[k][q][16 + i] = L[k][4 i + q]: slots 0..15 of every quarter are a zero dead zone (the window runs downwards)
+    __shared__ __attribute__((aligned(16))) double Lq[TB * PR];
+    __shared__ double Wt[TB * LT];
+    __shared__ double invd[TB];
     const int tid = threadIdx.x, j0 = blockIdx.x * TB;
+    for (int e = tid; e < TB * PR; e += 256) Lq[e] = 0.0;
+    __syncthreads();
     for (int e = tid; e < TB * TB; e += 256) {
-        int c = e >> 6, r = e & 63;
-        S[r * (TB + 1) + c] = L[(size_t)(j0 + c) * ld + j0 + r];
+        int c = e >> 6, k = e & 63;                      // coalesced along k (rows of the column-major tile)
+        double v = L[(size_t)(j0 + c) * ld + j0 + k];
+        Lq[k * PR + (c & 3) * QS + 16 + (c >> 2)] = (c <= k) ? v : 0.0;
+        if (c == k) invd[k] = 1.0 / v;
     }
     __syncthreads();
     const int r = tid >> 2, q = tid & 3;
-    double Wr[16];                                      // W_rk for k = 4 i + q
+    // right-hand side e_r, eliminated from the last column to the first; w[j] = entry of column 4 (g - j) + q
+    double w[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Wr[i] = 0.0;
+    for (int j = 0; j < 16; ++j) w[j] = (4 * (15 - j) + q == r) ? 1.0 : 0.0;
+#pragma unroll 1
+    for (int g = 15; g >= 0; g -= 2) {
+        static_for<8>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int kq = 3 - (p & 3), wh = p >> 2;              // pivot k = 4 (g - wh) + kq, held in w[wh]
+            const int k = 4 * (g - wh) + kq;
+            double t[16];                                             // t[u] = L[k][4 (g - 15 + u) + q]
+            load16(t, Lq + k * PR + q * QS + g + 1);
+            const double v = quad_bcast<kq>(w[wh]) * invd[k];         // W_rk (zero for k > r)
+            if (q == kq) Wt[r * LT + k] = v;
 #pragma unroll
-    for (int c = TB - 1; c >= 0; --c) {
-        double part = 0.0;
+            for (int j = wh; j < 16; ++j) {
+                if (j == wh) w[j] = fma(-v, (q < kq) ? t[15 - j] : 0.0, w[j]);
+                else w[j] = fma(-v, t[15 - j], w[j]);
+            }
+        });
 #pragma unroll
-        for (int i = c / 4; i < 16; ++i) {
-            int k = 4 * i + q;
-            double lkc = (k > c) ? S[k * (TB + 1) + c] : 0.0;
-            part = fma(Wr[i], lkc, part);               // Wr[i] is zero for k > r
-        }
-        double sum = quad_sum(part);
-        double w = (c <= r) ? (((c == r) ? 1.0 : 0.0) - sum) / S[c * (TB + 1) + c] : 0.0;
-        if (q == 0) Xo[r * (TB + 1) + c] = w;
-        if ((c & 3) == q) Wr[c >> 2] = w;
+        for (int j = 0; j < 14; ++j) w[j] = w[j + 2];
+        w[14] = 0.0;
+        w[15] = 0.0;
     }
     __syncthreads();
-    for (int e = tid; e < TB * TB; e += 256) {
-        int c = e >> 6, rr = e & 63;
-        W[(size_t)(j0 + c) * ld + j0 + rr] = Xo[rr * (TB + 1) + c];
-    }
+    tile_s2g(Wt, W, ld, j0, j0);
 }
 
 // One wave computes a 16 x 16 output tile over K = 64: rows wave*16.., operands in LDS panels.
@@ -687,7 +847,7 @@ __global__ void __launch_bounds__(256) k_form_R(const double* __restrict__ Sigma
 //              MultiSGP inverse scale S = I1 + Ryy - EY - EY^T + Psi4 (GPnode/MultiSGPnode.jl:391-404),
 //                      energy = 0.5 [ tr(W S) - n E_logdetW + n d_out log 2 pi ]   (GPnode/MultiSGPnode.jl:544-632)
 // ------------------------------------------------------------------------------------------------
-constexpr int TRACE_BLOCKS = 128;
+constexpr int TRACE_BLOCKS = 64;
 constexpr int TRACE_SLOTS = 1 + MAXO * MAXO;
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -733,10 +893,13 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
     const double* B = stats + (size_t)Mp * Mp;
     const double* sc = B + (size_t)Mp * d_out;
     const int tid = threadIdx.x;
-    if (tid < 1 + d_out * d_out) {
-        double s = 0.0;
-        for (int g = 0; g < nblocks; ++g) s += partial[g * TRACE_SLOTS + tid];
-        tr[tid] = s;
+    {   // wave w reduces slots w, w + 4, ...: lane l holds block l's partial (nblocks <= 64), butterfly sum
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int slot = wave; slot < 1 + d_out * d_out; slot += 4) {
+            double v = (lane < nblocks) ? partial[lane * TRACE_SLOTS + slot] : 0.0;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) tr[slot] = v;
+        }
     }
     __syncthreads();
     const double s_kk = P->sigma2 * sc[1];

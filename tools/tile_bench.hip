@@ -1,0 +1,72 @@
+// Micro-benchmark of the sequential 64 x 64 tile routines (one block, as on the critical path of the
+// blocked Cholesky): potf2_tile, trsm_tile, k_trtri_diag and one k_potrf_step launch.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tile_bench tile_bench.hip
+#include "../gaussianprocessnode_amd/csrc/sgp_kernels.hip.h"
+#include <cstdio>
+#include <vector>
+#include <cmath>
+using namespace sgp;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+__global__ void __launch_bounds__(256) k_potf2_only(double* A, int ld, int reps, int* info) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
+    __shared__ __attribute__((aligned(16))) double colp[2 * PR];
+    __shared__ double rinv[TB];
+    for (int it = 0; it < reps; ++it) {
+        tile_g2s(lds, A, ld, 0, 0);
+        __syncthreads();
+        potf2_tile(lds, nullptr, colp, rinv, info, 0, 64);
+    }
+    tile_s2g(lds, A + 64 * 64, ld, 0, 0);
+}
+__global__ void __launch_bounds__(256) k_trsm_only(double* A, int ld, int reps, int* info) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
+    __shared__ __attribute__((aligned(16))) double Lp[TB * PR];
+    __shared__ __attribute__((aligned(16))) double colp[2 * PR];
+    __shared__ double rinv[TB];
+    tile_g2s(lds, A, ld, 0, 0);
+    __syncthreads();
+    potf2_tile(lds, Lp, colp, rinv, info, 0, 64);
+    double* X = lds + TB * LT;
+    for (int it = 0; it < reps; ++it) {
+        tile_g2s(X, A, ld, 0, 0);
+        __syncthreads();
+        trsm_tile(X, Lp, rinv);
+        __syncthreads();
+    }
+    tile_s2g(X, A + 64 * 64, ld, 0, 0);
+}
+__global__ void __launch_bounds__(256) k_copy_only(double* A, int ld, int reps) {
+    __shared__ double lds[2 * TB * PS];
+    for (int it = 0; it < reps; ++it) {
+        tile_g2s(lds, A, ld, 0, 0);
+        __syncthreads();
+    }
+    tile_s2g(lds, A + 64 * 64, ld, 0, 0);
+}
+
+int main() {
+    const int n = 64;
+    std::vector<double> A(2 * n * n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[j * n + i] = (i == j ? 2.0 : 0.0) + 1.0 / (1.0 + std::abs(i - j));
+    double* dA; int* dInfo;
+    CK(hipMalloc(&dA, 2 * n * n * 8)); CK(hipMalloc(&dInfo, 4)); CK(hipMemset(dInfo, 0, 4));
+    CK(hipMemcpy(dA, A.data(), 2 * n * n * 8, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 200;
+    auto run = [&](const char* name, auto launch) {
+        launch(); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-24s %8.2f us per tile  (%6.0f cycles/pivot @2.4GHz)\n", name, 1e3 * ms / reps, 1e3 * ms / reps * 2400 / 64);
+    };
+    run("copy g2s only", [&] { k_copy_only<<<1, 256>>>(dA, n, reps); });
+    run("potf2_tile (+copy)", [&] { k_potf2_only<<<1, 256>>>(dA, n, reps, dInfo); });
+    run("trsm_tile (+copy)", [&] { k_trsm_only<<<1, 256>>>(dA, n, reps, dInfo); });
+    // k_trtri_diag and k_potrf_step single launches
+    float ms;
+    k_trtri_diag<<<1, 256>>>(dA, dA + n * n, n); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0)); for (int i = 0; i < 50; ++i) k_trtri_diag<<<1, 256>>>(dA, dA + n * n, n); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1)); printf("k_trtri_diag launch      %8.2f us\n", 1e3 * ms / 50);
+    return 0;
+}
