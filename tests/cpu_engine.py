@@ -1,0 +1,95 @@
+"""Test doubles: CPU engines with the `SGPDevice` / distributed-engine interface, computing through the oracle.
+They exist so that the HOST logic (counter hook, packing, sharding, the all-reduce path under gloo) can be
+exercised in the GPU-less container.  They live under tests/ on purpose: the product has no CPU fallback."""
+import math
+
+import numpy as np
+
+from gaussianprocessnode_amd.device import SweepScalars
+from gaussianprocessnode_amd.distributed import pack_stats, stats_count, unpack_stats
+from oracle import sgp_oracle as O
+
+
+class OracleDevice:
+    """Same methods as gaussianprocessnode_amd.SGPDevice, NumPy inside."""
+
+    def __init__(self, n_max, m, d, d_out=1, **kw):
+        self.n_max, self.M, self.D, self.d_out = n_max, m, d, d_out
+        self.Lambda0, self.xi0 = np.eye(m), np.zeros(m)
+        self.jitter, self.w, self.E_logw = 0.0, 1.0, 0.0
+        self.calls = []
+
+    def close(self):
+        pass
+
+    def set_inducing(self, Xu):
+        self.Xu = np.asarray(Xu, dtype=np.float64).reshape(self.M, self.D)
+
+    def set_data(self, X, y, y_var=None, weights=None, n_nodes=None):
+        self.X = np.asarray(X, dtype=np.float64).reshape(-1, self.D)
+        self.y, self.vy = np.asarray(y, dtype=np.float64), y_var
+        self.n = len(self.X)
+        self.calls.append(("set_data", self.n))
+
+    def set_kernel(self, sigma2, ell, jitter=0.0):
+        self.s2, self.ell, self.jitter = sigma2, np.asarray(ell, dtype=np.float64), jitter
+
+    def set_prior_meancov(self, mu0, S0):
+        self.Lambda0 = O.cholinv(S0)
+        self.xi0 = self.Lambda0 @ mu0
+
+    def set_prior_precision(self, xi0, L0):
+        self.Lambda0, self.xi0 = np.asarray(L0), np.asarray(xi0)
+
+    def set_prior_isotropic(self, var):
+        self.Lambda0, self.xi0 = np.eye(self.M) / var, np.zeros(self.M)
+
+    def set_noise(self, W, E_log_w=None):
+        self.w = float(np.asarray(W).ravel()[0])
+        self.E_logw = math.log(self.w) if E_log_w is None else E_log_w
+
+    def sweep(self, stream=0):
+        self.calls.append(("sweep", self.n))
+        self.res = O.vmp_sweep(self.Xu, self.X, self.y, self.vy, self.s2, self.ell, self.w, E_logw=self.E_logw,
+                               jitter=self.jitter, Lambda0=self.Lambda0, xi0=self.xi0)
+
+    def posterior(self, want_cov=True, want_uv=True):
+        return self.res.mu_v, self.res.Sigma_v, self.res.Uv
+
+    def kuu_chol(self):
+        return self.res.KuuL
+
+    def scalars(self):
+        r = self.res
+        return SweepScalars(r.sum_I1, r.sum_I2, r.energy, 0, 0, 0.0, 0.0)
+
+    def w_stats(self):
+        return O.w_stats_perpoint(self.Xu, self.X, self.y, self.vy, self.s2, self.ell, self.res.KuuL, self.res.mu_v,
+                                  self.res.Uv)
+
+    def predict(self, Xstar, mu_v=None):
+        return O.predict_mean(self.Xu, Xstar, self.res.mu_v if mu_v is None else mu_v, self.s2, self.ell)
+
+
+class OracleShardEngine:
+    """Engine for gaussianprocessnode_amd.distributed.ShardedSweep on the CPU (gloo tests): local statistics of this
+    rank's shard packed in the device layout into a torch CPU tensor, replicated tail from the reduced buffer."""
+
+    def __init__(self, Xu, X, y, s2, ell, w, prior_var, jitter=0.0):
+        import torch
+        self.Xu, self.X, self.y = Xu, X, y
+        self.s2, self.ell, self.w, self.prior_var, self.jitter = s2, ell, w, prior_var, jitter
+        self.M = Xu.shape[0]
+        self.stats = torch.zeros(stats_count(self.M, 1), dtype=torch.float64)
+
+    def sweep_local(self):
+        import torch
+        st = O.suff_stats(self.Xu, self.X, self.y, None, self.s2, self.ell)
+        buf = pack_stats(st.Psi2, st.b, float(st.s_yy[0, 0]), st.s_kk / self.s2, st.n)
+        self.stats.copy_(torch.from_numpy(buf))
+
+    def sweep_finish(self):
+        Psi2, B, s_yy, s_w, n, _ = unpack_stats(self.stats.numpy(), self.M, 1)
+        st = O.SuffStats(Psi2, B, np.array([[s_yy]]), self.s2 * s_w, n)
+        self.res = O.vmp_sweep(self.Xu, None, None, None, self.s2, self.ell, self.w, jitter=self.jitter,
+                               Lambda0=np.eye(self.M) / self.prior_var, xi0=np.zeros(self.M), stats=st)

@@ -1,0 +1,115 @@
+"""The reference's own rule tests (GPtest.jl "Test Univariate SGP", PointMass-input testsets) run against the
+host-side mirror with the HIP engine behind it.  Ground truths are the analytic dense formulas GPtest.jl
+writes inline; sizes and parameters are GPtest.jl's (Nu = 10, theta = [1, 1])."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from gaussianprocessnode_amd import meta as Mt
+from gaussianprocessnode_amd import unisgp as U
+from gaussianprocessnode_amd.distributions import GammaShapeRate, MvNormalMeanCovariance, NormalMeanVariance, PointMass
+from oracle import sgp_oracle as O
+
+THETA = np.array([1.0, 1.0])                 # GPtest.jl:16
+XU = np.arange(1.0, 11.0)                    # GPtest.jl:19
+KERNEL = Mt.SEARDKernel()                    # GPtest.jl:21
+
+
+def kmat(A, B):
+    return O.kernelmatrix(1.0, 1.0, np.reshape(A, (-1, 1)), np.reshape(B, (-1, 1)))
+
+
+@pytest.fixture()
+def graph():
+    """A graph with N UniSGP nodes sharing v: y[i] ~ UniSGP(x[i], v, w, theta) (experiments/regression_kin40k.ipynb:147-152)."""
+    rng = np.random.default_rng(11)
+    N = 7
+    x = np.concatenate([[1.0], rng.uniform(0.0, 11.0, N - 1)])     # the tests' input 1.0 is one of the points
+    y = np.concatenate([[2.0], rng.normal(size=N - 1)])
+    q_w = GammaShapeRate(1.0, 1.0)                                   # GPtest.jl:116
+    prior = MvNormalMeanCovariance(np.sin(rng.random(10)), np.eye(10))   # GPtest.jl:117
+    meta = Mt.make_uni_meta(None, XU, KERNEL, N, jitter=1e-8)
+    q_theta = PointMass(THETA)
+    return dict(N=N, x=x, y=y, q_w=q_w, prior=prior, meta=meta, q_theta=q_theta)
+
+
+def run_v(g, q_outs):
+    msgs = [U.rule_v(q_outs[i], PointMass(g["x"][i]), g["q_w"], g["q_theta"], g["meta"]) for i in range(g["N"])]
+    q = g["prior"]
+    for m in msgs:
+        q = U.prod(q, m)
+    return q
+
+
+def test_rules_for_v_and_the_product(graph):
+    """GPtest.jl:183-217: each message is N_wmp(w Psi1' y, w Psi2); folded with the prior (GPnode/UniSGPnode.jl:62-73)."""
+    g = graph
+    q_v = run_v(g, [PointMass(v) for v in g["y"]])
+    assert isinstance(q_v, MvNormalMeanCovariance)
+    w = g["q_w"].mean()
+    Lam = np.linalg.inv(g["prior"].S)
+    xi = Lam @ g["prior"].m
+    for xi_, yi in zip(g["x"], g["y"]):
+        Psi1 = kmat([xi_], XU)                                # 1 x Nu
+        Lam = Lam + w * (Psi1.T @ Psi1)                       # gt precision of one message: mean(q_w) * Psi2
+        xi = xi + w * yi * Psi1[0]
+    gt_cov = np.linalg.inv(Lam)
+    np.testing.assert_allclose(q_v.cov(), gt_cov, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(q_v.mean(), gt_cov @ xi, rtol=1e-9, atol=1e-12)
+    Rv = gt_cov + np.outer(gt_cov @ xi, gt_cov @ xi)
+    np.testing.assert_allclose(g["meta"].Uv.T @ g["meta"].Uv, Rv, rtol=1e-9, atol=1e-12)     # meta.Uv side channel
+    assert g["meta"].counter == 0
+
+
+def test_rule_for_out_pointmass(graph):
+    """GPtest.jl:163-169"""
+    g = graph
+    q_v = run_v(g, [PointMass(v) for v in g["y"]])
+    nu = U.rule_out(PointMass(1.0), q_v, g["q_w"], g["q_theta"], g["meta"])
+    Psi1 = kmat([1.0], XU)
+    assert math.isclose(nu.mean(), float((Psi1 @ q_v.mean())[0]), rel_tol=1e-12)
+    assert math.isclose(nu.var(), 1.0 / g["q_w"].mean())
+
+
+@pytest.mark.parametrize("classification", [False, True])
+def test_rules_for_w_and_average_energy(graph, classification):
+    """GPtest.jl:231-253 (w) and :295-323 (average energy, Gamma w), PointMass input 1.0."""
+    g = graph
+    q_out0 = NormalMeanVariance(1.0, 2.0) if classification else PointMass(2.0)      # GPtest.jl:115 Normal(1, 2)
+    q_outs = [q_out0] + [(NormalMeanVariance(v, 0.3) if classification else PointMass(v)) for v in g["y"][1:]]
+    q_v = run_v(g, q_outs)
+    mu_v = q_v.mean()
+    R_v = q_v.cov() + np.outer(mu_v, mu_v)
+    Kuu_inverse = np.linalg.inv(kmat(XU, XU) + 1e-8 * np.eye(10))
+    Psi0 = 1.0
+    Psi1 = kmat([1.0], XU)
+    Psi2 = Psi1.T @ Psi1
+    my, vy = q_out0.mean(), (q_out0.var() if classification else 0.0)
+    I1 = Psi0 - np.trace(Kuu_inverse @ Psi2)
+    I2 = my ** 2 + vy - 2 * my * float((Psi1 @ mu_v)[0]) + np.trace(R_v @ Psi2)
+    nu_w = U.rule_w(q_out0, PointMass(1.0), q_v, g["q_theta"], g["meta"])
+    assert nu_w.shape() == 1.5
+    assert math.isclose(nu_w.rate(), 0.5 * (I1 + I2), rel_tol=0, abs_tol=1e-5)       # GPtest.jl's atol
+    assert math.isclose(nu_w.rate(), 0.5 * (I1 + I2), rel_tol=1e-7, abs_tol=1e-7)    # and what FP64 actually gives
+    E_logw = g["q_w"].mean_log()
+    U_gt = 0.5 * math.log(2 * math.pi) - 0.5 * E_logw + 0.5 * g["q_w"].mean() * (I1 + I2)
+    U_node = U.average_energy(q_out0, PointMass(1.0), q_v, g["q_w"], g["q_theta"], g["meta"])
+    assert math.isclose(U_node, U_gt, rel_tol=0, abs_tol=1e-5)
+    # the summed forms agree with the per-point ones
+    tot = sum(U.average_energy(q_outs[i], PointMass(g["x"][i]), q_v, g["q_w"], g["q_theta"], g["meta"])
+              for i in range(g["N"]))
+    assert math.isclose(U.average_energy_summed(g["meta"]), tot, rel_tol=1e-8, abs_tol=1e-7)
+    qw = U.rule_w_summed(g["meta"], GammaShapeRate(0.01, 0.01))
+    rates = sum(U.rule_w(q_outs[i], PointMass(g["x"][i]), q_v, g["q_theta"], g["meta"]).rate() for i in range(g["N"]))
+    assert math.isclose(qw.a, 0.01 + g["N"] / 2) and math.isclose(qw.b, 0.01 + rates, rel_tol=1e-8, abs_tol=1e-7)
+
+
+def test_not_positive_definite_raises_like_cholesky(graph):
+    import gaussianprocessnode_amd as G
+    g = graph
+    g["q_w"] = PointMass(-5.0)
+    with pytest.raises(G.PosDefException):
+        run_v(g, [PointMass(v) for v in g["y"]])
