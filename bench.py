@@ -186,6 +186,44 @@ def main():
             out["cpu_baseline"] = {"value": reps / t_cpu, "unit": "iterations/s", "cores": cores, "kind": "port",
                                    "sample": f"{reps} full sweeps of the same workload by oracle/sgp_oracle.py "
                                              f"(NumPy/OpenBLAS FP64, batched BLAS-3 restatement, {cores} threads)"}
+            # the reference's algorithmic shape (one rank-1 M x M message + fold + TRSV per point, one thread):
+            # oracle/sgp_oracle.c on two bounded samples, extrapolated linearly in N to the full workload
+            try:
+                from oracle import c_oracle
+                ts = []
+                for ns in (100, 250):
+                    t1 = time.perf_counter()
+                    c_oracle.vmp_sweep_perpoint(Xu, X[:ns], y[:ns], None, SIGMA2, ELL, 0.0, W_BAR, math.log(W_BAR),
+                                                np.zeros(M), PRIOR_VAR * np.eye(M))
+                    ts.append(time.perf_counter() - t1)
+                slope = (ts[1] - ts[0]) / 150.0
+                full = ts[0] + slope * (N - 100)
+                out["cpu_baseline_per_point"] = {"value": 1.0 / full, "unit": "iterations/s", "cores": 1, "kind": "port",
+                                                 "sample": f"oracle/sgp_oracle.c (per-point rank-1 fold as in GPnode/UniSGPnode.jl:62-73,"
+                                                           f"144-158,196-216) on 100 and 250 points, M={M}; extrapolated to N={N}: "
+                                                           f"{1e3 * slope:.3f} ms/point"}
+            except Exception as e:                                   # pragma: no cover
+                out["cpu_baseline_per_point"] = {"error": repr(e)}
+            # SMSE on the real kin40k data (tests/golden): one sweep with the reference's Xu / theta_opt, first M inducing points
+            try:
+                gold = os.path.join(ROOT, "tests", "golden")
+                fx, kd = np.load(os.path.join(gold, "kin40k_fixture.npz")), np.load(os.path.join(gold, "kin40k_data.npz"))
+                s2k, ellk = O.kernel_from_theta(fx["theta_opt"], softplus_params=True)
+                Mk = min(M, fx["Xu"].shape[0])
+                from gaussianprocessnode_amd import SGPDevice
+                with SGPDevice(len(kd["ytrain"]), Mk, D) as dk:
+                    dk.set_inducing(fx["Xu"][:Mk])
+                    dk.set_data(kd["xtrain"], kd["ytrain"])
+                    dk.set_kernel(s2k, ellk, 0.0)
+                    dk.set_prior_isotropic(PRIOR_VAR)
+                    dk.set_noise([[W_BAR]])
+                    dk.sweep()
+                    pk = dk.predict(kd["xtest"])
+                out["parity"]["smse_kin40k_real"] = {"value": float(O.SMSE(kd["ytest"], pk)), "M": int(Mk),
+                                                     "note": "one full-batch sweep on the real kin40k training set at the "
+                                                             "reference's theta_opt; the reference reports 0.0834 with M=600"}
+            except Exception as e:                                   # pragma: no cover
+                out["parity"]["smse_kin40k_real"] = {"error": repr(e)}
         if ctx:
             ctx.__exit__(None, None, None)
         print(json.dumps(out))
