@@ -22,7 +22,7 @@ SGP_T_COUNT = 8
 
 EXPORTS = [
     "sgp_abi_version", "sgp_create", "sgp_destroy", "sgp_last_error", "sgp_set_inducing", "sgp_set_data",
-    "sgp_set_kernel", "sgp_set_prior", "sgp_set_noise", "sgp_sweep_local", "sgp_sweep_finish", "sgp_sweep",
+    "sgp_set_kernel", "sgp_set_output_cov_sum", "sgp_set_prior", "sgp_set_noise", "sgp_sweep_local", "sgp_sweep_finish", "sgp_sweep",
     "sgp_stats_layout", "sgp_bind_stats", "sgp_get_posterior", "sgp_get_scalars", "sgp_get_stats",
     "sgp_get_kuu_chol", "sgp_get_wishart_invscale", "sgp_w_stats", "sgp_predict", "sgp_theta_objective",
     "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_time_kernel",
@@ -81,6 +81,7 @@ def load(build_if_missing: bool = True):
     lib.sgp_last_error.restype = C.c_char_p
     lib.sgp_set_inducing.argtypes = [vp, dp]
     lib.sgp_set_data.argtypes = [vp, dp, dp, dp, dp, C.c_int64, C.c_double]
+    lib.sgp_set_output_cov_sum.argtypes = [vp, dp]
     lib.sgp_set_kernel.argtypes = [vp, C.c_double, dp, C.c_int32, C.c_double]
     lib.sgp_set_prior.argtypes = [vp, dp, dp, C.c_int32]
     lib.sgp_set_noise.argtypes = [vp, dp, C.c_double]

@@ -65,6 +65,7 @@ struct sgp_handle {
     int64_t stats_count = 0;
     size_t slab_capacity = 0;
     Graph gLocal, gFinish;
+    double ryy_data[MAXO * MAXO] = {0};   // sum omega y y' of the current data (without the output-covariance term)
     std::string err;
 };
 
@@ -273,6 +274,7 @@ extern "C" int sgp_set_data(sgp_handle* h, const double* X, const double* y_mean
     if (dout == 1) scal[SGP_S_COUNT] = s_yy;
     scal[SGP_S_W] = s_w;
     scal[SGP_S_N] = (n_nodes > 0) ? n_nodes : (double)n;
+    for (int i = 0; i < dout * dout; ++i) h->ryy_data[i] = scal[SGP_S_COUNT + i];
     if (n > 0) {
         HIPCHK(h, hipMemcpy(h->dX, X, sizeof(double) * n * h->D, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(h->dYw, yw.data(), sizeof(double) * n * dout, hipMemcpyHostToDevice));
@@ -296,6 +298,22 @@ extern "C" int sgp_set_data(sgp_handle* h, const double* X, const double* y_mean
     if ((size_t)h->nchunks * h->ntiles * TB * TB > h->slab_capacity)
         return fail(h, SGP_ERR_ARG, "sgp_set_data: internal slab capacity exceeded");
     h->swept = h->swept_local = false;
+    return 0;
+}
+
+extern "C" int sgp_set_output_cov_sum(sgp_handle* h, const double* S) {
+    if (!h || !S) return fail(h, SGP_ERR_ARG, "sgp_set_output_cov_sum: null argument");
+    if (!h->have_data) return fail(h, SGP_ERR_ARG, "sgp_set_output_cov_sum: call sgp_set_data first");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int dd = h->dout * h->dout;
+    std::vector<double> ryy(dd);
+    HIPCHK(h, hipMemcpy(ryy.data(), h->dDataScal + SGP_S_COUNT, sizeof(double) * dd, hipMemcpyDeviceToHost));
+    for (int i = 0; i < dd; ++i) ryy[i] = h->ryy_data[i] + S[i];
+    HIPCHK(h, hipMemcpy(h->dDataScal + SGP_S_COUNT, ryy.data(), sizeof(double) * dd, hipMemcpyHostToDevice));
+    if (h->dout == 1) {
+        double syy = h->ryy_data[0] + S[0];
+        HIPCHK(h, hipMemcpy(h->dDataScal + SGP_S_YY, &syy, sizeof(double), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 

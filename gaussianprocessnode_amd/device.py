@@ -76,6 +76,10 @@ class SGPDevice:
                                      float(-1.0 if n_nodes is None else n_nodes)), self._h, "sgp_set_data")
         self.n = n
 
+    def set_output_cov_sum(self, S):
+        S = as_f64(np.reshape(S, (self.d_out, self.d_out)))
+        check(self._lib.sgp_set_output_cov_sum(self._h, ptr(as_f64(S.T))), self._h, "sgp_set_output_cov_sum")
+
     def set_kernel(self, sigma2: float, ell, jitter: float = 0.0):
         ell = as_f64(np.atleast_1d(ell))
         check(self._lib.sgp_set_kernel(self._h, float(sigma2), ptr(ell), int(ell.size), float(jitter)), self._h,

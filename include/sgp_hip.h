@@ -84,6 +84,10 @@ int sgp_set_inducing(sgp_handle* h, const double* Xu);
  * GPnode/MultiSGPnode.jl:11-35); n_nodes = number of factor nodes the n points belong to (n if no cubature). */
 int sgp_set_data(sgp_handle* h, const double* X, const double* y_mean, const double* y_var,
                  const double* pt_weight, int64_t n, double n_nodes);
+/* sgp_set_output_cov_sum: MultiSGP with Gaussian (not PointMass) q_out: sum over the nodes of cov(q_out)
+ * (d_out x d_out), the Sigma_y term of `Ry = Sigma_y + mu_y mu_y'` (GPnode/MultiSGPnode.jl:398-401,566).  Call after
+ * sgp_set_data (which resets it to zero). */
+int sgp_set_output_cov_sum(sgp_handle* h, const double* S);
 /* sgp_set_kernel: kernel(theta) = sigma2 * with_lengthscale(SEKernel(), ell)
  * (GPtest.jl:21; experiments/regression_kin40k.ipynb:108).  n_ell = 1 (isotropic) or D (ARD).
  * jitter is added to diag(K_uu) (0 in kin40k training :183, 1e-8 at prediction :297 and in banana). */

@@ -320,3 +320,59 @@ def test_kin40k_full_training_sweep_real_data(G, golden):
     # and it lands where the reference's saved posterior is (theta drifted in its last epoch: loose)
     assert relF(mu, fx["mu_v"]) < 5e-3
     assert abs(O.SMSE(data["ytest"], pred) - 0.0834) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# MultiSGP (GPnode/MultiSGPnode.jl): cubature points as weighted data, Kronecker precision, Wishart statistics
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,M,Do,gauss_out", [(30, 48, 2, False), (17, 20, 3, True), (300, 48, 2, True)])
+def test_multisgp_sweep_matches_oracle(G, T, M, Do, gauss_out):
+    """BASELINE config 5 shape (pendulum: 300 steps, M=48, D=2, srcubature = 5 points per step)."""
+    rng = np.random.default_rng(T + M)
+    Din = 2
+    Xu = rng.uniform(-2, 2, (M, Din))
+    s2, ell = 0.8, np.array([1.3, 0.9])
+    means = rng.normal(size=(T, Din))
+    covs = [np.diag(rng.uniform(0.02, 0.2, Din)) for _ in range(T)]
+    cub = [O.srcubature(means[t], covs[t]) for t in range(T)]
+    pts = np.stack([c[0] for c in cub])                    # (T, S, Din)
+    wts = np.stack([c[1] for c in cub])                    # (T, S)
+    S = pts.shape[1]
+    Y = rng.normal(size=(T, Do))
+    Sig_y = np.stack([np.diag(rng.uniform(0.01, 0.1, Do)) for _ in range(T)]) if gauss_out else None
+    A = rng.normal(size=(Do, Do))
+    W = A @ A.T + Do * np.eye(Do)
+    E_logdetW = float(np.linalg.slogdet(W)[1]) - 0.1
+    Q = Do * M
+    Lam0 = np.eye(Q) / 10.0
+    xi0 = 0.01 * rng.normal(size=Q)
+
+    ms = O.multi_suff_stats(Xu, pts, wts, Y, Sig_y, s2, ell)
+    mu_ref, Sig_ref = O.multi_v_update(ms, W, Lam0, xi0)
+    Kinv = O.cholinv(O.kernelmatrix(s2, ell, Xu) + 1e-10 * np.eye(M))
+    S_ref = O.multi_w_update(ms, mu_ref, Sig_ref, Kinv)
+    U_ref = 0.0
+    for t in range(T):
+        P0, P1, P2 = O.psi_statistics(Xu, pts[t], wts[t], s2, ell)
+        U_ref += O.multi_average_energy(P0, P1, P2, Y[t], None if Sig_y is None else Sig_y[t], mu_ref, Sig_ref, W,
+                                        E_logdetW, Kinv)
+
+    with G.SGPDevice(T * S, M, Din, d_out=Do) as dev:
+        dev.set_inducing(Xu)
+        dev.set_data(pts.reshape(T * S, Din), np.repeat(Y, S, axis=0), None, wts.reshape(-1), n_nodes=T)
+        if gauss_out:
+            dev.set_output_cov_sum(Sig_y.sum(axis=0))
+        dev.set_kernel(s2, ell, 1e-10)
+        dev.set_prior_precision(xi0, Lam0)
+        dev.set_noise(W, E_logdetW)
+        dev.sweep()
+        Psi2, B, sc = dev.stats()
+        mu, Sig, Uv = dev.posterior()
+        Sw = dev.wishart_invscale()
+        energy = dev.scalars().energy
+    assert relF(Psi2, ms.Psi2) < 1e-12 and relF(B, ms.B) < 1e-12
+    assert sc[2] == T and math.isclose(sc[1], T, rel_tol=1e-12)
+    assert relF(mu, mu_ref) < 1e-8 and relF(Sig, Sig_ref) < 1e-8
+    np.testing.assert_allclose(Uv.T @ Uv, Sig_ref + np.outer(mu_ref, mu_ref), rtol=1e-7, atol=1e-10)
+    assert relF(Sw, S_ref) < 1e-7, relF(Sw, S_ref)
+    assert math.isclose(energy, U_ref, rel_tol=1e-7), (energy, U_ref)
