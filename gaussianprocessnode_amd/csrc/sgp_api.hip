@@ -143,7 +143,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     const size_t Mp = h->Mp, Qp = h->Qp, nmax = (size_t)h->n_max;
     h->stats_count = (int64_t)(Mp * Mp + Mp * h->dout + SGP_S_COUNT + (size_t)h->dout * h->dout);
     // worst-case slab count: enough chunks to put ~2 blocks on each of the 256 CUs
-    int max_chunks = std::max(1, (2 * 256 + h->ntiles - 1) / h->ntiles);
+    int max_chunks = (std::max(1, (2 * 256 + h->ntiles - 1) / h->ntiles) + 7) / 8 * 8 + 8;
     h->slab_capacity = (size_t)max_chunks * h->ntiles * TB * TB;
     const size_t nblk_max = (nmax + TB - 1) / TB;
 
@@ -291,10 +291,12 @@ extern "C" int sgp_set_data(sgp_handle* h, const double* X, const double* y_mean
     h->nblk = (int)((n + TB - 1) / TB);
     // split the point axis so that tiles x chunks ~ 2 blocks per CU, chunk a multiple of the stage size
     int want = std::max(1, (2 * 256 + h->ntiles - 1) / h->ntiles);
+    want = (want + 7) / 8 * 8;                                   // a multiple of the 8 XCDs (see k_syrk_stream)
     int64_t per = (n + want - 1) / want;
     per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);
     h->chunk = (int)per;
     h->nchunks = (int)std::max<int64_t>(1, (n + per - 1) / per);
+    if (h->nchunks > 8) h->nchunks = (h->nchunks + 7) / 8 * 8;    // trailing chunks may be empty (zero slabs)
     if ((size_t)h->nchunks * h->ntiles * TB * TB > h->slab_capacity)
         return fail(h, SGP_ERR_ARG, "sgp_set_data: internal slab capacity exceeded");
     h->swept = h->swept_local = false;
@@ -431,8 +433,8 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     if (h->n > 0) {
         hipLaunchKernelGGL(k_gram_uf, dim3(T, h->nblk), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                            h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + 2 * SGP_T_GRAM);
-        hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles, h->nchunks), dim3(256), 0, s, h->dKuf,
-                           h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk,
+        hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
+                           h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, h->ntiles, h->nchunks,
                            h->dStamps + 2 * SGP_T_SYRK);
     }
     hipLaunchKernelGGL(k_assemble, dim3(T, T, 4), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
@@ -631,8 +633,9 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
             hipLaunchKernelGGL(k_gram_uf, dim3(h->T, h->nblk), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr);
         else
-            hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles, h->nchunks), dim3(256), 0, s, h->dKuf,
-                               h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->chunk, (int64_t*)nullptr);
+            hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
+                               h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->chunk, h->ntiles, h->nchunks,
+                               (int64_t*)nullptr);
     };
     if (which != SGP_T_GRAM && which != SGP_T_SYRK) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: which must be SGP_T_GRAM or SGP_T_SYRK");
     launch();

@@ -262,14 +262,26 @@ __device__ __forceinline__ void tile_from_index(int t, int& I, int& J) {
 
 __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
                                                      double* __restrict__ slabs, int Mp, int64_t N, int chunk,
-                                                     int64_t* stamps) {
+                                                     int ntiles, int nchunks, int64_t* stamps) {
     __shared__ double lds[2 * 2 * KB * PS];           // [buf][panel A|B][KB][PS]
     stamp_enter(stamps);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    // XCD-aware block -> (tile, chunk) map: workgroups are dealt round-robin over the 8 XCDs, so ids congruent mod 8
+    // share an L2.  All tiles of one point-chunk read the same K_uf columns: give every chunk to ONE XCD so that its
+    // columns are fetched into one L2 once (nchunks is a multiple of 8 whenever there is enough work; speed only).
+    int tile_id, chunk_id;
+    if ((nchunks & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        chunk_id = xcd + 8 * (j / ntiles);
+        tile_id = j % ntiles;
+    } else {
+        chunk_id = blockIdx.x / ntiles;
+        tile_id = blockIdx.x % ntiles;
+    }
     int I, J;
-    tile_from_index(blockIdx.x, I, J);
+    tile_from_index(tile_id, I, J);
     const bool diag = (I == J);
-    const int64_t nbeg = (int64_t)blockIdx.y * chunk;
+    const int64_t nbeg = (int64_t)chunk_id * chunk;
     int64_t nend = nbeg + chunk;
     if (nend > N) nend = N;
     const int stages = (int)((nend - nbeg + KB - 1) / KB);
@@ -318,7 +330,7 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
         if (s + 1 < stages) lstore(buf ^ 1);
         __syncthreads();
     }
-    double* out = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (TB * TB);
+    double* out = slabs + ((size_t)chunk_id * ntiles + tile_id) * (TB * TB);
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
