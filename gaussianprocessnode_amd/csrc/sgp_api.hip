@@ -54,17 +54,19 @@ struct sgp_handle {
     double *dKuu = nullptr, *dWk = nullptr, *dKinv = nullptr;
     double *dLam = nullptr, *dWl = nullptr, *dSigma = nullptr, *dR = nullptr, *dXi = nullptr, *dMu = nullptr;
     double *dLambda0 = nullptr, *dXi0 = nullptr, *dOut = nullptr, *dWishart = nullptr, *dTrace = nullptr, *dTmp = nullptr;
-    double *dPa = nullptr, *dPb = nullptr;
+    double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr;
     int* dInfo = nullptr;
     int64_t* dStamps = nullptr;
     Params* hParams = nullptr;     // pinned
     Params* dParams = nullptr;
+    Params* dParamsK = nullptr;    // the K_uu chain's own copy (it runs on the side stream)
+    double* dXusK = nullptr;
     hipStream_t own = nullptr, side = nullptr;
     hipEvent_t evFork = nullptr, evSide = nullptr;
     int nchunks = 1, chunk = 0, nblk = 0, ntiles = 0;
     int64_t stats_count = 0;
     size_t slab_capacity = 0;
-    Graph gLocal, gFinish;
+    Graph gLocal, gFinish, gFinish2, gKuu;
     double ryy_data[MAXO * MAXO] = {0};   // sum omega y y' of the current data (without the output-covariance term)
     std::string err;
 };
@@ -90,18 +92,18 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // ------------------------------------------------------------------------------------------------
 // dense building blocks (launch sequences)
 // ------------------------------------------------------------------------------------------------
-static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, hipStream_t s) {
+static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, double* scratch, hipStream_t s) {
     for (int j = 0; j < Tn; ++j) {
         int nt = Tn - j;
-        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, A, ld, j, info, n_valid);
+        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, A, ld, j, Tn, info, n_valid, scratch);
     }
 }
 static void launch_trtri(const double* L, double* W, int ld, int Tn, hipStream_t s) {
     hipLaunchKernelGGL(k_trtri_diag, dim3(Tn), dim3(256), 0, s, L, W, ld);
     if (Tn > 1) hipLaunchKernelGGL(k_trtri_col, dim3(Tn - 1, 4), dim3(256), 0, s, L, W, ld, Tn);
 }
-static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s) {
-    hipLaunchKernelGGL(k_ata_lower, dim3(Tn * (Tn + 1) / 2), dim3(256), 0, s, W, C, ld, Tn);
+static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s, int rev = 0) {
+    hipLaunchKernelGGL(k_ata_lower, dim3(Tn * (Tn + 1) / 2), dim3(256), 0, s, W, C, ld, Tn, rev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -121,6 +123,8 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     *out = nullptr;
     if (cfg->m < 1 || cfg->d < 1 || cfg->d > MAXD || cfg->d_out < 1 || cfg->d_out > MAXO || cfg->n_max < 1)
         return fail(nullptr, SGP_ERR_ARG, "sgp_create: need m >= 1, 1 <= d <= 32, 1 <= d_out <= 4, n_max >= 1");
+    if ((int64_t)cfg->m * cfg->d_out > CU_MAXQ - TB)
+        return fail(nullptr, SGP_ERR_ARG, "sgp_create: d_out * m is limited to 4032 in this build");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, SGP_ERR_NODEVICE, "sgp_create: no HIP device visible (the HIP path has no CPU fallback)");
@@ -176,6 +180,8 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dSigma, Qp * Qp);
     ALLOC(h->dR, Qp * Qp);
     ALLOC(h->dTmp, Qp * Qp);
+    ALLOC(h->dUvT, Qp * Qp);
+    ALLOC(h->dScratch, 3 * TB * TB);
     ALLOC(h->dLambda0, Qp * Qp);
     ALLOC(h->dXi, Qp);
     ALLOC(h->dMu, Qp);
@@ -186,6 +192,8 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dInfo, 4);
     ALLOC(h->dStamps, 2 * SGP_T_COUNT);
     ALLOC(h->dParams, 1);
+    ALLOC(h->dParamsK, 1);
+    ALLOC(h->dXusK, Mp * h->D);
     if (cfg->flags & SGP_FLAG_KEEP_KUF) {
         ALLOC(h->dPa, (size_t)h->T * nmax);
         ALLOC(h->dPb, (size_t)h->T * nmax);
@@ -225,9 +233,12 @@ extern "C" int sgp_destroy(sgp_handle* h) {
     hipDeviceSynchronize();
     h->gLocal.reset();
     h->gFinish.reset();
+    h->gFinish2.reset();
+    h->gKuu.reset();
     void* bufs[] = {h->dXu, h->dXus, h->dX, h->dYw, h->dY, h->dYv, h->dOmega, h->dKuf, h->dBpart, h->dSlabs, h->dStatsOwn,
                     h->dDataScal, h->dKuu, h->dWk, h->dKinv, h->dLam, h->dWl, h->dSigma, h->dR, h->dTmp, h->dLambda0,
-                    h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb};
+                    h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
+                    h->dUvT, h->dScratch, h->dParamsK, h->dXusK};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evFork) hipEventDestroy(h->evFork);
@@ -381,7 +392,7 @@ extern "C" int sgp_set_prior(sgp_handle* h, const double* vec, const double* mat
     if (rc) return rc;
     hipStream_t s = h->own;
     HIPCHK(h, hipMemsetAsync(h->dInfo + 2, 0, sizeof(int), s));
-    launch_potrf(h->dTmp, h->Qp, h->TQ, h->dInfo + 2, h->Q, s);
+    launch_potrf(h->dTmp, h->Qp, h->TQ, h->dInfo + 2, h->Q, h->dScratch + 2 * TB * TB, s);
     launch_trtri(h->dTmp, h->dWl, h->Qp, h->TQ, s);
     launch_ata(h->dWl, h->dLambda0, h->Qp, h->TQ, s);
     HIPCHK(h, hipMemcpyAsync(h->dMu, v.data(), Qp * sizeof(double), hipMemcpyHostToDevice, s));
@@ -408,28 +419,37 @@ extern "C" int sgp_bind_stats(sgp_handle* h, void* stats_dev) {
     h->dStats = stats_dev ? static_cast<double*>(stats_dev) : h->dStatsOwn;
     h->gLocal.valid = false;
     h->gFinish.valid = false;
+    h->gFinish2.valid = false;
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // launch sequences
 // ------------------------------------------------------------------------------------------------
+// The sweep is four launch sequences, each captured once into a hipGraph and replayed:
+//   K  (side stream) : K_uu chain -- theta and Xu only: K_uu, its Cholesky factor, inverse factor and inverse
+//   L  (main stream) : data-sized work -- K_uf, Psi2 / B partials, packed statistics          [sgp_sweep_local]
+//   F1 (main stream) : Lambda chain -- Lambda, Cholesky, inverse, mu, R, Uv                   [sgp_sweep_finish]
+//   F2 (main stream) : traces and scalars, after the join with the side stream
+// The two chains are latency-bound pivot sequences that use a handful of CUs each; they overlap only when they sit on
+// different streams (parallel branches inside ONE captured graph were observed to execute back to back).
+static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
+    const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
+    hipMemcpyAsync(h->dParamsK, h->hParams, sizeof(Params), hipMemcpyHostToDevice, s);
+    hipMemsetAsync(h->dInfo, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->dParamsK, M, Mp, D);
+    hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
+    launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s);
+    launch_trtri(h->dKuu, h->dWk, Mp, T, s);
+    launch_ata(h->dWk, h->dKinv, Mp, T, s);
+}
+
 static void enqueue_local(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
     hipMemcpyAsync(h->dParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice, s);
-    hipMemsetAsync(h->dInfo, 0, 2 * sizeof(int), s);
     hipLaunchKernelGGL(k_stamp_reset, dim3(1), dim3(64), 0, s, h->dStamps, (int)SGP_T_COUNT);
     hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, s, h->dStamps + 2 * SGP_T_SWEEP);
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->dParams, M, Mp, D);
-    // fork: the K_uu chain depends on theta and Xu only and runs beside the data-sized work
-    hipEventRecord(h->evFork, s);
-    hipStreamWaitEvent(h->side, h->evFork, 0);
-    hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, h->side, h->dXus, h->dKuu, h->dParams, M, Mp, D);
-    launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->side);
-    launch_trtri(h->dKuu, h->dWk, Mp, T, h->side);
-    launch_ata(h->dWk, h->dKinv, Mp, T, h->side);
-    hipEventRecord(h->evSide, h->side);
-    // data-sized work
     if (h->n > 0) {
         hipLaunchKernelGGL(k_gram_uf, dim3(T, h->nblk), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                            h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + 2 * SGP_T_GRAM);
@@ -440,26 +460,32 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_assemble, dim3(T, T, 4), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
                        h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
                        SGP_S_COUNT + h->dout * h->dout);
-    hipStreamWaitEvent(s, h->evSide, 0);     // join (also keeps the side chain inside a captured graph)
 }
 
-static void enqueue_finish(sgp_handle* h, hipStream_t s) {
+static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp, TQ = h->TQ;
     hipMemsetAsync(h->dInfo + 1, 0, sizeof(int), s);
-    hipMemsetAsync(h->dInfo + 3, 0, sizeof(int), s);
+    // Lambda is factored in index-reversed order (P Lambda P = L' L'^T): its inverse factor W' = L'^-1 then IS the upper
+    // Cholesky factor of Sigma_v up to the reversal, and Uv follows by a rank-1 update instead of a third potrf.
+    hipMemsetAsync(h->dUvT, 0, sizeof(double) * Qp * Qp, s);
     hipLaunchKernelGGL(k_form_lambda, dim3(TQ, TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dLam, h->dXi,
-                       h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form);
-    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Q, s);
+                       h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form, 1);
+    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s);
     launch_trtri(h->dLam, h->dWl, Qp, TQ, s);
-    launch_ata(h->dWl, h->dSigma, Qp, TQ, s);
+    launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1);
     hipLaunchKernelGGL(k_symv, dim3((Qp + 3) / 4), dim3(256), 0, s, h->dSigma, h->dXi, h->dMu, Qp, Qp);
     hipLaunchKernelGGL(k_form_R, dim3(TQ, TQ), dim3(256), 0, s, h->dSigma, h->dMu, h->dR, Q, Qp);
+    // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69)
+    hipLaunchKernelGGL(k_transpose, dim3(TQ, TQ), dim3(256), 0, s, h->dWl, h->dTmp, Qp);
+    hipLaunchKernelGGL(k_cholupdate, dim3(1), dim3(512), 0, s, h->dTmp, h->dMu, h->dUvT, Qp);
+}
+
+static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
+    const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
     hipLaunchKernelGGL(k_trace_partial, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dR, h->dTrace, M, Mp,
                        h->dout, Qp);
     hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, h->dTrace, h->dMu, h->dKuu, h->dLam, h->dInfo,
-                       h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS);
-    // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69): factor R in place (lower), transposed on read-out
-    launch_potrf(h->dR, Qp, TQ, h->dInfo + 3, Q, s);
+                       h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS, Qp - Q);
     hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, s, h->dStamps + 2 * SGP_T_SWEEP + 1);
 }
 
@@ -497,6 +523,12 @@ extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) {
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
+    // fork: the K_uu chain starts on the side stream once everything earlier on `s` (the previous sweep) is done
+    HIPCHK(h, hipEventRecord(h->evFork, s));
+    HIPCHK(h, hipStreamWaitEvent(h->side, h->evFork, 0));
+    rc = run_sequence(h, h->gKuu, enqueue_kuu, h->side);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->evSide, h->side));
     rc = run_sequence(h, h->gLocal, enqueue_local, s);
     if (rc) return rc;
     h->swept_local = true;
@@ -508,7 +540,10 @@ extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
     if (!h->swept_local) return fail(h, SGP_ERR_ARG, "sgp_sweep_finish: call sgp_sweep_local first");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
-    int rc = run_sequence(h, h->gFinish, enqueue_finish, s);
+    int rc = run_sequence(h, h->gFinish, enqueue_finish1, s);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamWaitEvent(s, h->evSide, 0));          // join with the K_uu chain
+    rc = run_sequence(h, h->gFinish2, enqueue_finish2, s);
     if (rc) return rc;
     h->swept = true;
     return 0;
@@ -541,7 +576,12 @@ extern "C" int sgp_get_scalars(sgp_handle* h, double* out) {
     if (rc) return rc;
     HIPCHK(h, hipMemcpy(out, h->dOut, SGP_R_COUNT * sizeof(double), hipMemcpyDeviceToHost));
     if (out[SGP_R_INFO_KUU] > 0) { h->err = "K_uu is not positive definite"; return (int)out[SGP_R_INFO_KUU]; }
-    if (out[SGP_R_INFO_LAMBDA] > 0) { h->err = "Lambda is not positive definite"; return (int)out[SGP_R_INFO_LAMBDA]; }
+    if (out[SGP_R_INFO_LAMBDA] > 0) {
+        // Lambda is factored from its last row upwards: report the natural index of the failing pivot
+        out[SGP_R_INFO_LAMBDA] = (double)(h->Qp - (int)out[SGP_R_INFO_LAMBDA] + 1);
+        h->err = "Lambda is not positive definite";
+        return (int)std::max(1.0, out[SGP_R_INFO_LAMBDA]);
+    }
     return 0;
 }
 
@@ -553,12 +593,12 @@ extern "C" int sgp_get_posterior(sgp_handle* h, double* mu_v, double* Sigma_v, d
     int info[4];
     HIPCHK(h, hipMemcpy(info, h->dInfo, sizeof info, hipMemcpyDeviceToHost));
     if (info[0] > 0) { h->err = "K_uu is not positive definite"; return info[0]; }
-    if (info[1] > 0) { h->err = "Lambda is not positive definite"; return info[1]; }
+    if (info[1] > 0) { h->err = "Lambda is not positive definite"; return std::max(1, h->Qp - info[1] + 1); }
     const int Q = h->Q, Qp = h->Qp;
     if (mu_v) HIPCHK(h, hipMemcpy(mu_v, h->dMu, sizeof(double) * Q, hipMemcpyDeviceToHost));
     if (Sigma_v) { rc = download_square(h, h->dSigma, Qp, Q, Sigma_v); if (rc) return rc; }
     if (Uv) {
-        hipLaunchKernelGGL(k_transpose, dim3(h->TQ, h->TQ), dim3(256), 0, h->own, h->dR, h->dTmp, Qp);
+        hipLaunchKernelGGL(k_transpose, dim3(h->TQ, h->TQ), dim3(256), 0, h->own, h->dUvT, h->dTmp, Qp);
         HIPCHK(h, hipStreamSynchronize(h->own));
         rc = download_square(h, h->dTmp, Qp, Q, Uv);
         if (rc) return rc;
@@ -586,7 +626,7 @@ extern "C" int sgp_get_stats(sgp_handle* h, double* Psi2, double* B, double* sca
 
 extern "C" int sgp_get_kuu_chol(sgp_handle* h, double* KuuL) {
     if (!h || !KuuL) return fail(h, SGP_ERR_ARG, "sgp_get_kuu_chol: null argument");
-    if (!h->swept_local) return fail(h, SGP_ERR_ARG, "sgp_get_kuu_chol: no sweep yet");
+    if (!h->swept) return fail(h, SGP_ERR_ARG, "sgp_get_kuu_chol: no finished sweep");
     int rc = sync_all(h);
     if (rc) return rc;
     rc = download_square(h, h->dKuu, h->Mp, h->M, KuuL);
@@ -669,7 +709,7 @@ extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) 
     HIPCHK(h, hipDeviceSynchronize());
     // |L^-1 k_n|^2 with the explicit inverse factor W_k, |Uv k_n|^2 = |L_R^T k_n|^2
     hipLaunchKernelGGL(k_quadform_cols, dim3(h->T, h->nblk), dim3(256), 0, s, h->dWk, h->dKuf, h->dPa, h->Mp, h->T, n, 0);
-    hipLaunchKernelGGL(k_quadform_cols, dim3(h->T, h->nblk), dim3(256), 0, s, h->dR, h->dKuf, h->dPb, h->Mp, h->T, n, 1);
+    hipLaunchKernelGGL(k_quadform_cols, dim3(h->T, h->nblk), dim3(256), 0, s, h->dUvT, h->dKuf, h->dPb, h->Mp, h->T, n, 1);
     hipLaunchKernelGGL(k_w_point_finish, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, h->dPa, h->dPb, h->dKuf, h->dMu,
                        h->dY, h->has_yv ? h->dYv : nullptr, dI1, dI2, h->dParams, h->M, h->Mp, h->T, n);
     HIPCHK(h, hipStreamSynchronize(s));
@@ -798,7 +838,9 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dInfo), sizeof(int)));
     HIPCHK(h, hipMemset(dInfo, 0, sizeof(int)));
     HIPCHK(h, hipMemcpy(dA, tmp.data(), sizeof(double) * np * np, hipMemcpyHostToDevice));
-    launch_potrf(dA, np, Tn, dInfo, n, 0);
+    double* dScr = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dScr), sizeof(double) * TB * TB));
+    launch_potrf(dA, np, Tn, dInfo, n, dScr, 0);
     const double* result = dA;
     if (inverse) {
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dW), sizeof(double) * np * np));
@@ -815,7 +857,7 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
     if (!inverse)
         for (int j = 0; j < n; ++j)
             for (int i = 0; i < j; ++i) out[(size_t)j * n + i] = 0.0;
-    hipFree(dA); hipFree(dInfo);
+    hipFree(dA); hipFree(dInfo); hipFree(dScr);
     if (dW) hipFree(dW);
     if (dC) hipFree(dC);
     if (info > 0) { g_create_error = "matrix is not positive definite"; return info; }

@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
 __global__ void __launch_bounds__(256) k_form_lambda(const double* __restrict__ stats, const double* __restrict__ Lambda0,
                                                      const double* __restrict__ xi0, double* __restrict__ Lam,
                                                      double* __restrict__ xi, const Params* __restrict__ P,
-                                                     int M, int Mp, int d_out, int Q, int Qp, int prior_form) {
+                                                     int M, int Mp, int d_out, int Q, int Qp, int prior_form, int rev) {
     const int gi = blockIdx.x * TB + (threadIdx.x & 63);
     const int jg = threadIdx.x >> 6;
     const double* Psi2 = stats;
@@ -433,7 +433,10 @@ __global__ void __launch_bounds__(256) k_form_lambda(const double* __restrict__ 
             double prior = (prior_form == 1) ? Lambda0[(size_t)gj * Qp + gi] : (gi == gj ? P->prior_iso : 0.0);
             v = prior + P->W[a + b * d_out] * Psi2[(size_t)j * Mp + i];
         } else v = (gi == gj) ? 1.0 : 0.0;
-        Lam[(size_t)gj * Qp + gi] = v;
+        // rev: write P Lambda P (index reversal).  Its lower Cholesky factor L' gives chol(Sigma_v).U = P L'^-1 P for free,
+        // from which Uv follows by a rank-1 update instead of a third factorisation (see k_cholupdate).
+        if (rev) Lam[(size_t)(Qp - 1 - gj) * Qp + (Qp - 1 - gi)] = v;
+        else Lam[(size_t)gj * Qp + gi] = v;
     }
     if (blockIdx.y == 0 && threadIdx.x < TB) {
         double v = 0.0;
@@ -630,7 +633,11 @@ __device__ __forceinline__ void tile_sub_acc(double* S, const Acc4& acc, int lan
                 S[acc_row(lane, wr, ti, r) * LT + acc_col(lane, wc, tj)] -= acc.t[ti][tj][r];
 }
 
-__global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int ld, int j, int* __restrict__ info, int n_valid) {
+// Hazard handled here: every block of the panel column reads the UNFACTORED diagonal tile A_jj from global memory, so
+// the diagonal block must not overwrite it in place during the same launch.  It parks L_jj in `scratch` (one tile) and
+// the next step's block (0, 0) moves it into place (kernel boundary = all readers done).  The last step has no readers.
+__global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
+                                                    int n_valid, double* __restrict__ scratch) {
     // LDS: two MFMA operand panels (2 x 64 x PS) during the update, re-used afterwards as two 64 x 64 tiles;
     // the permuted factor for the triangular solve; the permuted pivot-column double buffer
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
@@ -649,6 +656,10 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     acc_zero(accX);
     acc_zero(accD);
     const bool panel = (b == 0);
+    if (j > 0 && a == 0 && b == 0) {                      // move the previous step's L_{j-1,j-1} into place
+        const int q0 = (j - 1) * TB;
+        for (int e = tid; e < TB * TB; e += 256) A[(size_t)(q0 + (e >> 6)) * ld + q0 + (e & 63)] = scratch[e];
+    }
     if (j > 0) {
         const int p0 = (j - 1) * TB;
         load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
@@ -682,7 +693,9 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     __syncthreads();
     potf2_tile(S, (a == 0) ? nullptr : Lp, colp, rinv, info, j0, n_valid);
     if (a == 0) {
-        tile_s2g(S, A, ld, j0, j0);
+        if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);       // no other block reads A_jj in the last step
+        else
+            for (int e = tid; e < TB * TB; e += 256) scratch[e] = S[(e & 63) * LT + (e >> 6)];   // column-major tile
         return;
     }
     trsm_tile(X, Lp, rinv);
@@ -795,7 +808,7 @@ __global__ void __launch_bounds__(256) k_trtri_col(const double* __restrict__ L,
 // C = W^T W for lower-triangular W (inverse from the Cholesky factor: Sigma = L^-T L^-1), full symmetric out.
 // Tile (I, J), I >= J: sum over block rows k = I .. T-1.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ata_lower(const double* __restrict__ W, double* __restrict__ C, int ld, int T) {
+__global__ void __launch_bounds__(256) k_ata_lower(const double* __restrict__ W, double* __restrict__ C, int ld, int T, int rev) {
     __shared__ double lds[2 * TB * PS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     int I, J;
@@ -819,6 +832,7 @@ __global__ void __launch_bounds__(256) k_ata_lower(const double* __restrict__ W,
             for (int r = 0; r < 4; ++r) {
                 int row = I * TB + acc_row(lane, wr, ti, r), col = J * TB + acc_col(lane, wc, tj);
                 double v = acc.t[ti][tj][r];
+                if (rev) { row = ld - 1 - row; col = ld - 1 - col; }          // undo the index reversal of k_form_lambda
                 C[(size_t)col * ld + row] = v;
                 if (I != J) C[(size_t)row * ld + col] = v;
             }
@@ -847,6 +861,104 @@ __global__ void __launch_bounds__(256) k_form_R(const double* __restrict__ Sigma
         double v = Sigma[(size_t)gj * Qp + gi];
         if (gi < Q && gj < Q) v = fma(mu[gi], mu[gj], v);
         R[(size_t)gj * Qp + gi] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69) as a rank-1 UPDATE of V = chol(Sigma_v).U.
+//   Vt holds W'^T column-major, W' = L'^-1 the inverse factor of the index-reversed Lambda, so that
+//   V[k][j] = W'[Qp-1-k][Qp-1-j] = Vt[(Qp-1-j) + (Qp-1-k) * Qp]   (a row of V is contiguous, descending).
+//   Row k of the update:  r = sqrt(V_kk^2 + x_k^2);  U_kj = (V_kk V_kj + x_k x_j) / r;  x_j <- (r x_j - x_k U_kj) / V_kk.
+//   Output LR = Uv^T (lower, column-major: column k = row k of Uv), the layout potrf(R) would have produced.
+// One workgroup of 8 waves, 64 pivots per iteration:
+//   wave 0    : the 64 x 64 diagonal block sequentially, entirely in registers (v_readlane broadcasts, no barrier),
+//               publishing per pivot the four scalars A = V_kk/r, B = x_k/r, C = r/V_kk, D = x_k/V_kk;
+//               after the barrier it applies them to the next block's 64 columns (which it needs next);
+//   wave 1    : applies the PREVIOUS block's rotations to the block after the next one;
+//   waves 2-7 : apply the previous block's rotations to all later columns.
+// Every column thus receives the rotations in pivot order with one barrier per 64 pivots.
+// ------------------------------------------------------------------------------------------------
+constexpr int CU_MAXQ = 4096;
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// apply the 64 rotations `cs` (4 scalars per pivot) of pivot block bb to column j
+__device__ __forceinline__ void cholupdate_column(const double* __restrict__ Vt, double* __restrict__ LR, double* xs,
+                                                  const double* cs, int Qp, int bb, int j) {
+    double x = xs[j];
+    const double* vp = Vt + (size_t)(Qp - 1 - 64 * bb) * Qp + (Qp - 1 - j);       // V[64 bb + kk][j] = vp[-kk * Qp]
+    double* up = LR + (size_t)(64 * bb) * Qp + j;
+#pragma unroll 1
+    for (int k0 = 0; k0 < 64; k0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = vp[-(ptrdiff_t)(k0 + u) * Qp];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const double4 c = *reinterpret_cast<const double4*>(cs + 4 * (k0 + u));
+            const double uu = fma(c.y, x, c.x * v[u]);
+            x = fma(c.z, x, -c.w * uu);
+            up[(size_t)(k0 + u) * Qp] = uu;
+        }
+    }
+    xs[j] = x;
+}
+
+__global__ void __launch_bounds__(512) k_cholupdate(const double* __restrict__ Vt, const double* __restrict__ mu,
+                                                    double* __restrict__ LR, int Qp) {
+    __shared__ double xs[CU_MAXQ];
+    __shared__ __attribute__((aligned(32))) double cs[2][64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = Qp / 64;
+    for (int e = tid; e < Qp; e += 512) xs[e] = mu[e];
+    __syncthreads();
+#pragma unroll 1
+    for (int i = 0; i < nb; ++i) {
+        if (wave == 0) {
+            // ---- diagonal block i: 64 sequential pivots in registers
+            const int base = 64 * i, j = base + lane;
+            double vr[64];
+            const double* vp = Vt + (size_t)(Qp - 1 - base) * Qp + (Qp - 1 - j);
+#pragma unroll
+            for (int kk = 0; kk < 64; ++kk) vr[kk] = vp[-(ptrdiff_t)kk * Qp];      // V[base + kk][j]; zero below the diagonal
+            double xa = xs[j];
+            double dg = 0.0;
+            static_for<64>([&](auto kc) { constexpr int kk = decltype(kc)::value; if (lane == kk) dg = vr[kk]; });
+            const double iv = 1.0 / dg;
+            double* csw = cs[i & 1];
+            static_for<64>([&](auto kc) {
+                constexpr int kk = decltype(kc)::value;
+                const double vkk = readlane_f64(vr[kk], kk);
+                const double xk = readlane_f64(xa, kk);
+                const double ivk = readlane_f64(iv, kk);
+                const double t = fma(xk, xk, vkk * vkk);
+                const double ir = rsqrt_nr(t);
+                const double r = t * ir;
+                const double A = vkk * ir, B = xk * ir, C = r * ivk, D = xk * ivk;
+                const double uu = fma(B, xa, A * vr[kk]);
+                xa = fma(C, xa, -D * uu);
+                LR[(size_t)(base + kk) * Qp + j] = (lane >= kk) ? uu : 0.0;
+                if (lane == 0) *reinterpret_cast<double4*>(csw + 4 * kk) = make_double4(A, B, C, D);
+            });
+        } else if (i > 0) {
+            // ---- rotations of block i-1 on later columns
+            const double* csr = cs[(i - 1) & 1];
+            if (wave == 1) {
+                const int j = 64 * (i + 1) + lane;
+                if (j < Qp) cholupdate_column(Vt, LR, xs, csr, Qp, i - 1, j);
+            } else {
+                for (int j = 64 * (i + 2) + (tid - 128); j < Qp; j += 384) cholupdate_column(Vt, LR, xs, csr, Qp, i - 1, j);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int j = 64 * (i + 1) + lane;
+            if (j < Qp) cholupdate_column(Vt, LR, xs, cs[i & 1], Qp, i, j);
+        }
     }
 }
 
@@ -899,7 +1011,7 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
                                                  const double* __restrict__ Llam, const int* __restrict__ info,
                                                  const Params* __restrict__ P, double* __restrict__ out,
                                                  double* __restrict__ wishart, int M, int Mp, int d_out, int Q, int Qp,
-                                                 int nblocks) {
+                                                 int nblocks, int lam_off) {
     __shared__ double red[4];
     __shared__ double tr[TRACE_SLOTS];
     const double* B = stats + (size_t)Mp * Mp;
@@ -919,7 +1031,7 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
     const double sum_I1 = s_kk - tr[0];
     double ld_k = 0.0, ld_l = 0.0;
     for (int e = tid; e < M; e += 256) ld_k += log(Lkuu[(size_t)e * Mp + e]);
-    for (int e = tid; e < Q; e += 256) ld_l += log(Llam[(size_t)e * Qp + e]);
+    for (int e = tid; e < Q; e += 256) ld_l += log(Llam[(size_t)(e + lam_off) * Qp + e + lam_off]);
     ld_k = 2.0 * block_sum(ld_k, red);
     ld_l = 2.0 * block_sum(ld_l, red);
     const double LOG2PI = 1.8378770664093454835606594728112;
