@@ -508,106 +508,135 @@ __device__ __forceinline__ void load16(double (&t)[16], const double* p) {
     }
 }
 
-// Factor the 64 x 64 tile S (LDS, S[r][c], stride LT, lower part valid).  On exit rinv[c] = 1 / L_cc and L is
-// written to S in place (strict upper part zero) when Lp == nullptr, else to the permuted tile
-// Lp[k * PR + (c & 3) * QS + (c >> 2)] = L[c][k] that trsm_tile reads.  colp: 2 * PR doubles.
-// Register window: a[j] is the row's entry of column 4 (g + j) + q while column groups g, g + 1 are eliminated;
-// the window slides by two groups after every eight pivots, so all register indices are static inside a genuine
-// loop (a fully unrolled 64-pivot body made the scheduler interleave pivots and spill hundreds of registers).
-// Window entries past column 63 are dead: they are updated with whatever the dead zone holds and never used.
-__device__ __forceinline__ void potf2_tile(double* S, double* Lp, double* colp, double* rinv, int* info, int col_base,
-                                           int n_valid) {
-    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
-    double a[16];
+// Factor the 64 x 64 tile S (LDS, S[r][c], stride LT, lower part valid) in place: on exit S holds L (strict upper part
+// zero) and rinv[c] = 1 / L_cc.  colw: 16 doubles of LDS.  Blocked by 16 columns, wave w owns rows 16 w .. 16 w + 15:
+//   (1) every wave w >= cb subtracts the contribution of the block columns to the left from its 16 x 16 block (one MFMA
+//       product, K = 16 cb, wave-local);
+//   (2) wave cb factors its diagonal 16 x 16 block: 4 lanes per row, entries in registers, the pivot column exchanged
+//       through a 16-entry LDS vector -- all inside ONE wave, so the 16 pivots need no workgroup barrier;
+//   (3) after a barrier the waves below solve their 16 x 16 block against it (rows independent, in registers).
+// Two workgroup barriers per 16 pivots instead of one per pivot.
+__device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv, int* info, int col_base, int n_valid) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = 16 * wave;
+    const int li = lane & 15, lk = lane >> 4;
+    const int rr = lane >> 2, q = lane & 3;
+    static_for<4>([&](auto cbc) {
+        constexpr int cb = decltype(cbc)::value;
+        if constexpr (cb > 0) {
+            if (wave >= cb) {
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+                const double* ap = S + (r0 + li) * LT + lk;              // A[i][k] = L[r0 + i][k]
+                const double* bp = S + (16 * cb + li) * LT + lk;         // B[k][j] = L[16 cb + j][k]
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int c = 4 * i + q;
-        a[i] = (c <= r) ? S[r * LT + c] : 0.0;
-    }
-    __syncthreads();                                    // S may be overwritten from here on
-    if (q == 0) colp[(r & 3) * QS + (r >> 2)] = a[0];   // pivot column 0, buffer 0
-#pragma unroll 1
-    for (int g = 0; g < 16; g += 2) {
-        static_for<8>([&](auto pc) {
-            constexpr int p = decltype(pc)::value;
-            constexpr int kq = p & 3, wh = p >> 2;      // pivot k = 4 (g + wh) + kq, held in a[wh] of lane kq
-            const int k = 4 * (g + wh) + kq;
-            __syncthreads();
-            const double* col = colp + (k & 1) * PR;
-            double d = col[kq * QS + g + wh];
-            if (!(d > 0.0)) {
-                if (tid == 0 && col_base + k < n_valid) atomicCAS(info, 0, col_base + k + 1);
-                d = 1.0;
-            }
-            const double ri = rsqrt_nr(d);
-            double v = quad_bcast<kq>(a[wh]);
-            v = (r >= k) ? v : 0.0;                      // rows above the pivot take no part
-            const double f = v * (ri * ri);              // a_rk / d
-            if (q == kq) {
-                if (Lp) Lp[k * PR + (r & 3) * QS + (r >> 2)] = v * ri;
-                else S[r * LT + k] = v * ri;             // L_rk (zero above the diagonal)
-            }
-            if (tid == 0) rinv[k] = ri;
-            double t[16];
-            load16(t, col + q * QS + g);                 // pivot-column entries of columns 4 (g + j) + q
-            // the next pivot column first, so that it is published while the rest of the update runs
-            constexpr int nwh = (p + 1) >> 2, nq = (p + 1) & 3;            // (nwh may be 2: next iteration's a[0])
-            if constexpr (p == 3) {
-                a[1] = fma(-f, t[1], a[1]);
-                if (q == 0) colp[((k + 1) & 1) * PR + ((r & 3) * QS + (r >> 2))] = a[1];
-            } else if constexpr (p == 7) {
-                a[2] = fma(-f, t[2], a[2]);
-                if (q == 0 && g < 14) colp[((k + 1) & 1) * PR + ((r & 3) * QS + (r >> 2))] = a[2];
-            } else {
-                a[wh] = fma(-f, (q > kq) ? t[wh] : 0.0, a[wh]);
-                if (q == nq) colp[((k + 1) & 1) * PR + ((r & 3) * QS + (r >> 2))] = a[wh];
-            }
+                for (int s4 = 0; s4 < 4 * cb; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s4], bp[4 * s4], acc, 0, 0, 0);
 #pragma unroll
-            for (int j = wh; j < 16; ++j) {
-                if (p == 3 && j == 1) continue;
-                if (p == 7 && j == 2) continue;
-                if (p != 3 && p != 7 && j == wh) continue;
-                if (j == wh) a[j] = fma(-f, (q > kq) ? t[j] : 0.0, a[j]);
-                else a[j] = fma(-f, t[j], a[j]);
+                for (int r = 0; r < 4; ++r) S[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= acc[r];
             }
-            (void)nwh;
-        });
+        }
+        if (wave == cb) {
+            double a[4], lo[4];
 #pragma unroll
-        for (int j = 0; j < 14; ++j) a[j] = a[j + 2];
-        a[14] = 0.0;
-        a[15] = 0.0;
-    }
-    __syncthreads();
+            for (int i = 0; i < 4; ++i) {
+                int c = 4 * i + q;
+                a[i] = (c <= rr) ? S[(r0 + rr) * LT + 16 * cb + c] : 0.0;
+                lo[i] = 0.0;
+            }
+            static_for<16>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int kq = k & 3, ki = k >> 2;
+                double v = quad_bcast<kq>(a[ki]);
+                v = (rr >= k) ? v : 0.0;                      // rows above the pivot take no part
+                if (q == kq) colw[rr] = v;                    // pivot column (unnormalised), wave-local exchange
+                // Scheduling fence: without it hipcc (ROCm 7.2) sinks the previous pivot's colw[] reads below this store
+                // (it defers their FMAs and the loads with them) and the update uses the NEXT pivot's column.  Verified
+                // on hardware with tools/tile_bench.hip: 4.8e-1 error without, 7e-16 with.
+                __builtin_amdgcn_wave_barrier();
+                double d = colw[k];
+                if (!(d > 0.0)) {
+                    if (lane == 0 && col_base + 16 * cb + k < n_valid) atomicCAS(info, 0, col_base + 16 * cb + k + 1);
+                    d = 1.0;
+                }
+                const double ri = rsqrt_nr(d);
+                const double f = v * (ri * ri);               // a_rk / d
+                if (q == kq) lo[ki] = v * ri;                 // L_rk
+                if (lane == 0) rinv[16 * cb + k] = ri;
+#pragma unroll
+                for (int i = ki; i < 4; ++i) {
+                    const int c = 4 * i + q;
+                    double t = (c > k) ? colw[c] : 0.0;
+                    a[i] = fma(-f, t, a[i]);
+                }
+            });
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = lo[i];
+        }
+        __syncthreads();
+        if (wave > cb) {
+            double x[4], xo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = S[(r0 + rr) * LT + 16 * cb + 4 * i + q]; xo[i] = 0.0; }
+            static_for<16>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int kq = k & 3, ki = k >> 2;
+                const double v = quad_bcast<kq>(x[ki]) * rinv[16 * cb + k];
+                if (q == kq) xo[ki] = v;
+#pragma unroll
+                for (int i = ki; i < 4; ++i) {
+                    const int c = 4 * i + q;
+                    double t = (c > k) ? S[(16 * cb + c) * LT + 16 * cb + k] : 0.0;
+                    x[i] = fma(-v, t, x[i]);
+                }
+            });
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = xo[i];
+        } else if (wave < cb) {
+            // rows of finished waves: the strict upper part of this block column is zero
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = 0.0;
+        }
+        __syncthreads();
+    });
 }
 
-// Solve X L^T = B in place: X (LDS tile, stride LT) holds B on entry and X on exit; Lp is the permuted L written by
-// potf2_tile, rinv = 1 / diag(L).  Rows are independent: no barrier inside.  Same sliding window.
-__device__ __forceinline__ void trsm_tile(double* X, const double* Lp, const double* rinv) {
-    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
-    double x[16];
+// Solve X L^T = B in place: X (LDS tile, stride LT) holds B on entry and X on exit; S holds L (normal layout, as written
+// by potf2_tile with Lp == nullptr), rinv = 1 / diag(L).  Blocked by 16 columns and entirely WAVE-LOCAL (wave w owns rows
+// 16 w .. 16 w + 15, no workgroup barrier): for each 16-column block the contribution of the blocks to its left is one
+// MFMA product per wave (K = 16 cb), the 16 x 16 triangle is then solved with 4 lanes per row in registers.
+__device__ __forceinline__ void trsm_tile(double* X, const double* S, const double* rinv) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = 16 * wave;
+    const int li = lane & 15, lk = lane >> 4;            // MFMA operand coordinates
+    const int rr = lane >> 2, q = lane & 3;              // solve coordinates: row r0 + rr, quarter q
+    static_for<4>([&](auto cbc) {
+        constexpr int cb = decltype(cbc)::value;
+        if constexpr (cb > 0) {
+            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+            const double* ap = X + (r0 + li) * LT + lk;              // A[i][k] = X[r0 + i][k]
+            const double* bp = S + (16 * cb + li) * LT + lk;         // B[k][j] = L[16 cb + j][k]
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = X[r * LT + 4 * i + q];
-#pragma unroll 1
-    for (int g = 0; g < 16; g += 2) {
-        static_for<8>([&](auto pc) {
-            constexpr int p = decltype(pc)::value;
-            constexpr int kq = p & 3, wh = p >> 2;
-            const int k = 4 * (g + wh) + kq;
-            double t[16];
-            load16(t, Lp + k * PR + q * QS + g);                      // L_ck for c = 4 (g + j) + q
-            const double v = quad_bcast<kq>(x[wh]) * rinv[k];         // X_rk
-            if (q == kq) X[r * LT + k] = v;
+            for (int s4 = 0; s4 < 4 * cb; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s4], bp[4 * s4], acc, 0, 0, 0);
 #pragma unroll
-            for (int j = wh; j < 16; ++j) {
-                if (j == wh) x[j] = fma(-v, (q > kq) ? t[j] : 0.0, x[j]);
-                else x[j] = fma(-v, t[j], x[j]);
+            for (int r = 0; r < 4; ++r) X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= acc[r];
+        }
+        double x[4], xo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q]; xo[i] = 0.0; }
+        static_for<16>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int kq = k & 3, ki = k >> 2;
+            const double v = quad_bcast<kq>(x[ki]) * rinv[16 * cb + k];          // X_rk
+            if (q == kq) xo[ki] = v;
+#pragma unroll
+            for (int i = ki; i < 4; ++i) {
+                const int c = 4 * i + q;
+                double t = (c > k) ? S[(16 * cb + c) * LT + 16 * cb + k] : 0.0;    // L_ck inside the diagonal 16 x 16 block
+                x[i] = fma(-v, t, x[i]);
             }
         });
 #pragma unroll
-        for (int j = 0; j < 14; ++j) x[j] = x[j + 2];
-        x[14] = 0.0;
-        x[15] = 0.0;
-    }
+        for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = xo[i];
+    });
 }
 
 // coalesced copies between a column-major global tile and an LDS tile S[r][c]
@@ -638,11 +667,9 @@ __device__ __forceinline__ void tile_sub_acc(double* S, const Acc4& acc, int lan
 // the next step's block (0, 0) moves it into place (kernel boundary = all readers done).  The last step has no readers.
 __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
                                                     int n_valid, double* __restrict__ scratch) {
-    // LDS: two MFMA operand panels (2 x 64 x PS) during the update, re-used afterwards as two 64 x 64 tiles;
-    // the permuted factor for the triangular solve; the permuted pivot-column double buffer
+    // LDS: two MFMA operand panels (2 x 64 x PS) during the update, re-used afterwards as two 64 x 64 tiles
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
-    __shared__ __attribute__((aligned(16))) double Lp[TB * PR];
-    __shared__ __attribute__((aligned(16))) double colp[2 * PR];
+    __shared__ double colw[16];
     __shared__ double rinv[TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     int a, b;
@@ -691,14 +718,14 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
         tile_sub_acc(X, accX, lane, wr, wc);
     }
     __syncthreads();
-    potf2_tile(S, (a == 0) ? nullptr : Lp, colp, rinv, info, j0, n_valid);
+    potf2_tile(S, colw, rinv, info, j0, n_valid);
     if (a == 0) {
         if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);       // no other block reads A_jj in the last step
         else
             for (int e = tid; e < TB * TB; e += 256) scratch[e] = S[(e & 63) * LT + (e >> 6)];   // column-major tile
         return;
     }
-    trsm_tile(X, Lp, rinv);
+    trsm_tile(X, S, rinv);
     __syncthreads();
     tile_s2g(X, A, ld, i0, j0);
 }

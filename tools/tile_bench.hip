@@ -10,28 +10,27 @@ using namespace sgp;
 
 __global__ void __launch_bounds__(256) k_potf2_only(double* A, int ld, int reps, int* info) {
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
-    __shared__ __attribute__((aligned(16))) double colp[2 * PR];
+    __shared__ double colp[16];
     __shared__ double rinv[TB];
     for (int it = 0; it < reps; ++it) {
         tile_g2s(lds, A, ld, 0, 0);
         __syncthreads();
-        potf2_tile(lds, nullptr, colp, rinv, info, 0, 64);
+        potf2_tile(lds, colp, rinv, info, 0, 64);
     }
     tile_s2g(lds, A + 64 * 64, ld, 0, 0);
 }
 __global__ void __launch_bounds__(256) k_trsm_only(double* A, int ld, int reps, int* info) {
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
-    __shared__ __attribute__((aligned(16))) double Lp[TB * PR];
-    __shared__ __attribute__((aligned(16))) double colp[2 * PR];
+    __shared__ double colp[16];
     __shared__ double rinv[TB];
     tile_g2s(lds, A, ld, 0, 0);
     __syncthreads();
-    potf2_tile(lds, Lp, colp, rinv, info, 0, 64);
+    potf2_tile(lds, colp, rinv, info, 0, 64);
     double* X = lds + TB * LT;
     for (int it = 0; it < reps; ++it) {
         tile_g2s(X, A, ld, 0, 0);
         __syncthreads();
-        trsm_tile(X, Lp, rinv);
+        trsm_tile(X, lds, rinv);
         __syncthreads();
     }
     tile_s2g(X, A + 64 * 64, ld, 0, 0);
@@ -63,6 +62,26 @@ int main() {
     run("copy g2s only", [&] { k_copy_only<<<1, 256>>>(dA, n, reps); });
     run("potf2_tile (+copy)", [&] { k_potf2_only<<<1, 256>>>(dA, n, reps, dInfo); });
     run("trsm_tile (+copy)", [&] { k_trsm_only<<<1, 256>>>(dA, n, reps, dInfo); });
+    // validation of potf2_tile against a host Cholesky
+    {
+        CK(hipMemset(dInfo, 0, 4));
+        k_potf2_only<<<1, 256>>>(dA, n, 1, dInfo); CK(hipDeviceSynchronize());
+        std::vector<double> L(n * n), R(n * n);
+        CK(hipMemcpy(L.data(), dA + n * n, n * n * 8, hipMemcpyDeviceToHost));
+        int info; CK(hipMemcpy(&info, dInfo, 4, hipMemcpyDeviceToHost));
+        R = std::vector<double>(A.begin(), A.begin() + n * n);
+        for (int j = 0; j < n; ++j) {
+            double d = R[j * n + j]; for (int k = 0; k < j; ++k) d -= R[k * n + j] * R[k * n + j];
+            d = std::sqrt(d); R[j * n + j] = d;
+            for (int i = j + 1; i < n; ++i) { double v = R[j * n + i]; for (int k = 0; k < j; ++k) v -= R[k * n + i] * R[k * n + j]; R[j * n + i] = v / d; }
+        }
+        double err = 0; int wi = -1, wj = -1;
+        for (int j = 0; j < n; ++j) for (int i = j; i < n; ++i) { double e = std::abs(L[j * n + i] - R[j * n + i]); if (e > err) { err = e; wi = i; wj = j; } }
+        printf("potf2 validation: info %d max |L - L_ref| = %.3e at (%d,%d); L[0..4][0..4]:\n", info, err, wi, wj);
+        for (int i = 0; i < 5; ++i) { for (int j = 0; j < 5; ++j) printf(" %10.6f/%10.6f", L[j * n + i], i >= j ? R[j * n + i] : 0.0); printf("\n"); }
+        printf("diag:"); for (int i = 0; i < 24; ++i) printf(" %.4f/%.4f", L[i * n + i], R[i * n + i]); printf("\n");
+        printf("row 8:"); for (int j = 0; j <= 8; ++j) printf(" %.4f/%.4f", L[j * n + 8], R[j * n + 8]); printf("\n");
+    }
     // k_trtri_diag and k_potrf_step single launches
     float ms;
     k_trtri_diag<<<1, 256>>>(dA, dA + n * n, n); CK(hipDeviceSynchronize());
