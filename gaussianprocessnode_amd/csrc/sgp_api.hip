@@ -98,12 +98,20 @@ static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, doub
         hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, A, ld, j, Tn, info, n_valid, scratch);
     }
 }
-static void launch_trtri(const double* L, double* W, int ld, int Tn, hipStream_t s) {
+// W = L^-1 by recursive doubling: diagonal tiles first, then for block sizes s = 1, 2, 4, ... tiles
+//   W21 = -W22 (L21 W11)   for every pair of adjacent diagonal blocks -- two tile-GEMM launches per level,
+// log2(Tn) levels instead of a Tn-long chain of dependent block rows.  `scratch` (ld x ld) holds L21 W11.
+static void launch_trtri(const double* L, double* W, double* scratch, int ld, int Tn, hipStream_t s) {
     hipLaunchKernelGGL(k_trtri_diag, dim3(Tn), dim3(256), 0, s, L, W, ld);
-    if (Tn > 1) hipLaunchKernelGGL(k_trtri_col, dim3(Tn - 1, 4), dim3(256), 0, s, L, W, ld, Tn);
+    for (int sz = 1; sz < Tn; sz *= 2) {
+        int npairs = (Tn + 2 * sz - 1) / (2 * sz);
+        hipLaunchKernelGGL(k_gemm32, dim3(sz * sz * 4, npairs), dim3(256), 0, s, L, (const double*)W, scratch, ld, Tn, 1, sz, 0);
+        hipLaunchKernelGGL(k_gemm32, dim3(sz * sz * 4, npairs), dim3(256), 0, s, (const double*)W, (const double*)scratch, W,
+                           ld, Tn, 2, sz, 0);
+    }
 }
 static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s, int rev = 0) {
-    hipLaunchKernelGGL(k_ata_lower, dim3(Tn * (Tn + 1) / 2), dim3(256), 0, s, W, C, ld, Tn, rev);
+    hipLaunchKernelGGL(k_gemm32, dim3(Tn * (Tn + 1) / 2 * 4), dim3(256), 0, s, W, W, C, ld, Tn, 0, 0, rev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -393,7 +401,7 @@ extern "C" int sgp_set_prior(sgp_handle* h, const double* vec, const double* mat
     hipStream_t s = h->own;
     HIPCHK(h, hipMemsetAsync(h->dInfo + 2, 0, sizeof(int), s));
     launch_potrf(h->dTmp, h->Qp, h->TQ, h->dInfo + 2, h->Q, h->dScratch + 2 * TB * TB, s);
-    launch_trtri(h->dTmp, h->dWl, h->Qp, h->TQ, s);
+    launch_trtri(h->dTmp, h->dWl, h->dLambda0, h->Qp, h->TQ, s);
     launch_ata(h->dWl, h->dLambda0, h->Qp, h->TQ, s);
     HIPCHK(h, hipMemcpyAsync(h->dMu, v.data(), Qp * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_symv, dim3((h->Qp + 3) / 4), dim3(256), 0, s, h->dLambda0, h->dMu, h->dXi0, h->Qp, h->Qp);
@@ -440,7 +448,7 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->dParamsK, M, Mp, D);
     hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
     launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s);
-    launch_trtri(h->dKuu, h->dWk, Mp, T, s);
+    launch_trtri(h->dKuu, h->dWk, h->dKinv, Mp, T, s);
     launch_ata(h->dWk, h->dKinv, Mp, T, s);
 }
 
@@ -471,7 +479,7 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_form_lambda, dim3(TQ, TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dLam, h->dXi,
                        h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form, 1);
     launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s);
-    launch_trtri(h->dLam, h->dWl, Qp, TQ, s);
+    launch_trtri(h->dLam, h->dWl, h->dSigma, Qp, TQ, s);
     launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1);
     hipLaunchKernelGGL(k_symv, dim3((Qp + 3) / 4), dim3(256), 0, s, h->dSigma, h->dXi, h->dMu, Qp, Qp);
     hipLaunchKernelGGL(k_form_R, dim3(TQ, TQ), dim3(256), 0, s, h->dSigma, h->dMu, h->dR, Q, Qp);
@@ -845,7 +853,7 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
     if (inverse) {
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dW), sizeof(double) * np * np));
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dC), sizeof(double) * np * np));
-        launch_trtri(dA, dW, np, Tn, 0);
+        launch_trtri(dA, dW, dC, np, Tn, 0);
         launch_ata(dW, dC, np, Tn, 0);
         result = dC;
     }

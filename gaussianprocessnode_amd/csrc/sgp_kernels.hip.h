@@ -866,6 +866,86 @@ __global__ void __launch_bounds__(256) k_ata_lower(const double* __restrict__ W,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tile GEMM with 32 x 32 output per block (4 waves x one 16 x 16 MFMA tile): the products of the recursive triangular
+// inverse and the inverse-from-factor product, where the 64 x 64 tiling leaves too few blocks for 256 CUs.
+//   mode 0  C(I,J) = sum_{k >= I} W(k,I)^T W(k,J)          lower tiles, mirrored; optional index reversal    (Sigma = W^T W)
+//   mode 1  T(i,j) = sum_{k=j}^{lo+s-1} L(i,k) W(k,j)      i in [lo+s, lo+2s), j in [lo, lo+s), lo = 2 s p   (L21 W11)
+//   mode 2  W(i,j) = - sum_{k=lo+s}^{i} W(i,k) T(k,j)      same tiles                                        (-W22 T)
+// (i, j, k are 64-tile indices; W11 / W22 lower triangular, so the k ranges skip the structural zeros.)
+// ------------------------------------------------------------------------------------------------
+constexpr int PS32 = 48;        // LDS panel row stride for 32-wide panels: 2 * PS32 dwords = 32 (mod 64)
+
+// panel[k][i] = G[(row0 + i) + (col0 + k) * ld], i < 32, k < 64
+__device__ __forceinline__ void load_panel32_n(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0, int tid) {
+    for (int t = tid; t < 64 * 8; t += 256) {
+        int k = t >> 3, rq = t & 7;
+        const double* src = G + (size_t)(col0 + k) * ld + row0 + rq * 4;
+        double2 v0 = *reinterpret_cast<const double2*>(src);
+        double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+        double* dst = panel + k * PS32 + rq * 4;
+        dst[0] = v0.x; dst[1] = v0.y; dst[2] = v1.x; dst[3] = v1.y;
+    }
+}
+// panel[k][i] = G[(row0 + k) + (col0 + i) * ld], i < 32, k < 64  (transposing load: lanes walk the 32 columns so that
+// the four LDS rows written by one instruction land on different banks)
+__device__ __forceinline__ void load_panel32_t(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0, int tid) {
+    for (int t = tid; t < 32 * 16; t += 256) {
+        int i = t & 31, g = t >> 5;
+        const double* src = G + (size_t)(col0 + i) * ld + row0 + g * 4;
+        double2 v0 = *reinterpret_cast<const double2*>(src);
+        double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+        panel[(g * 4 + 0) * PS32 + i] = v0.x;
+        panel[(g * 4 + 1) * PS32 + i] = v0.y;
+        panel[(g * 4 + 2) * PS32 + i] = v1.x;
+        panel[(g * 4 + 3) * PS32 + i] = v1.y;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
+                                                int ld, int Tn, int mode, int s, int rev) {
+    __shared__ double As[64 * PS32];
+    __shared__ double Bs[64 * PS32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int quad = blockIdx.x & 3, qi = quad >> 1, qj = quad & 1;
+    int I, J, kbeg, kend;
+    if (mode == 0) {
+        tile_from_index(blockIdx.x >> 2, I, J);
+        kbeg = I; kend = Tn;
+    } else {
+        const int t = blockIdx.x >> 2, lo = 2 * s * blockIdx.y;
+        I = lo + s + t / s; J = lo + t % s;
+        if (I >= Tn) return;
+        if (mode == 1) { kbeg = J; kend = lo + s; } else { kbeg = lo + s; kend = I + 1; }
+    }
+    const int r0 = I * TB + qi * 32, c0 = J * TB + qj * 32;
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+    const int li = lane & 15, lk = lane >> 4;
+    for (int k = kbeg; k < kend; ++k) {
+        __syncthreads();
+        if (mode == 0) load_panel32_t(As, A, ld, k * TB, r0, tid);      // As[kk][i] = W[k*64+kk, r0+i]
+        else load_panel32_n(As, A, ld, r0, k * TB, tid);                  // As[kk][i] = A[r0+i, k*64+kk]
+        load_panel32_t(Bs, B, ld, k * TB, c0, tid);                       // Bs[kk][j] = B[k*64+kk, c0+j]
+        __syncthreads();
+        const double* ap = As + lk * PS32 + wr * 16 + li;
+        const double* bp = Bs + lk * PS32 + wc * 16 + li;
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k4 * 4 * PS32], bp[k4 * 4 * PS32], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int row = r0 + wr * 16 + lk + 4 * r, col = c0 + wc * 16 + li;
+        double v = acc[r];
+        if (mode == 0) {
+            if (rev) { row = ld - 1 - row; col = ld - 1 - col; }
+            C[(size_t)col * ld + row] = v;
+            C[(size_t)row * ld + col] = v;       // mirror (on diagonal tiles two quadrants write the same bits twice)
+        } else {
+            C[(size_t)col * ld + row] = (mode == 2) ? -v : v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // mu = Sigma xi (one wave per row, Sigma symmetric so a row is read as a contiguous column)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_symv(const double* __restrict__ S, const double* __restrict__ x,
