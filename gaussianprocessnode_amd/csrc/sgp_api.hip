@@ -89,6 +89,12 @@ static int fail(sgp_handle* h, int code, const char* msg) {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// streaming-SYRK grid: tiles x point-chunks.  ~4.5 blocks per CU (3 resident, the rest dispatched as CUs free up) evens
+// out the 2-vs-3 blocks-per-CU imbalance a 2-blocks-per-CU grid leaves; the price is more partial slabs to sum.
+#ifndef SYRK_BLOCKS_PER_CU
+#define SYRK_BLOCKS_PER_CU 4
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // dense building blocks (launch sequences)
 // ------------------------------------------------------------------------------------------------
@@ -155,7 +161,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     const size_t Mp = h->Mp, Qp = h->Qp, nmax = (size_t)h->n_max;
     h->stats_count = (int64_t)(Mp * Mp + Mp * h->dout + SGP_S_COUNT + (size_t)h->dout * h->dout);
     // worst-case slab count: enough chunks to put ~2 blocks on each of the 256 CUs
-    int max_chunks = (std::max(1, (2 * 256 + h->ntiles - 1) / h->ntiles) + 7) / 8 * 8 + 8;
+    int max_chunks = (std::max(1, (SYRK_BLOCKS_PER_CU * 256 + h->ntiles - 1) / h->ntiles) + 7) / 8 * 8 + 8;
     h->slab_capacity = (size_t)max_chunks * h->ntiles * TB * TB;
     const size_t nblk_max = (nmax + TB - 1) / TB;
 
@@ -309,7 +315,7 @@ extern "C" int sgp_set_data(sgp_handle* h, const double* X, const double* y_mean
     h->have_data = true;
     h->nblk = (int)((n + TB - 1) / TB);
     // split the point axis so that tiles x chunks ~ 2 blocks per CU, chunk a multiple of the stage size
-    int want = std::max(1, (2 * 256 + h->ntiles - 1) / h->ntiles);
+    int want = std::max(1, (SYRK_BLOCKS_PER_CU * 256 + h->ntiles - 1) / h->ntiles);
     want = (want + 7) / 8 * 8;                                   // a multiple of the 8 XCDs (see k_syrk_stream)
     int64_t per = (n + want - 1) / want;
     per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);

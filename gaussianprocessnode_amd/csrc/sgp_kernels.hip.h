@@ -485,7 +485,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ __forceinline__ double rsqrt_nr(double d) {
     double y = __builtin_amdgcn_rsq(d);
     const double h = 0.5 * d;
+#ifndef SGP_RSQRT_ONE_STEP
     y = y * fma(-h * y, y, 1.5);
+#endif
     y = y * fma(-h * y, y, 1.5);
     return y;
 }
@@ -548,11 +550,14 @@ __device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv
                 double v = quad_bcast<kq>(a[ki]);
                 v = (rr >= k) ? v : 0.0;                      // rows above the pivot take no part
                 if (q == kq) colw[rr] = v;                    // pivot column (unnormalised), wave-local exchange
+                // the pivot itself comes straight from the owning lane (row k, quarter kq), so that 1/sqrt starts while the
+                // column is still on its way through LDS
+                double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[ki]), 4 * k + kq),
+                                            __builtin_amdgcn_readlane(__double2loint(a[ki]), 4 * k + kq));
                 // Scheduling fence: without it hipcc (ROCm 7.2) sinks the previous pivot's colw[] reads below this store
                 // (it defers their FMAs and the loads with them) and the update uses the NEXT pivot's column.  Verified
                 // on hardware with tools/tile_bench.hip: 4.8e-1 error without, 7e-16 with.
                 __builtin_amdgcn_wave_barrier();
-                double d = colw[k];
                 if (!(d > 0.0)) {
                     if (lane == 0 && col_base + 16 * cb + k < n_valid) atomicCAS(info, 0, col_base + 16 * cb + k + 1);
                     d = 1.0;
