@@ -54,7 +54,7 @@ struct sgp_handle {
     double *dKuu = nullptr, *dWk = nullptr, *dKinv = nullptr;
     double *dLam = nullptr, *dWl = nullptr, *dSigma = nullptr, *dR = nullptr, *dXi = nullptr, *dMu = nullptr;
     double *dLambda0 = nullptr, *dXi0 = nullptr, *dOut = nullptr, *dWishart = nullptr, *dTrace = nullptr, *dTmp = nullptr;
-    double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr;
+    double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr, *dOut2 = nullptr;
     int* dInfo = nullptr;
     int64_t* dStamps = nullptr;
     Params* hParams = nullptr;     // pinned
@@ -196,6 +196,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dTmp, Qp * Qp);
     ALLOC(h->dUvT, Qp * Qp);
     ALLOC(h->dScratch, 3 * TB * TB);
+    ALLOC(h->dOut2, SGP_R_COUNT);
     ALLOC(h->dLambda0, Qp * Qp);
     ALLOC(h->dXi, Qp);
     ALLOC(h->dMu, Qp);
@@ -252,7 +253,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
     void* bufs[] = {h->dXu, h->dXus, h->dX, h->dYw, h->dY, h->dYv, h->dOmega, h->dKuf, h->dBpart, h->dSlabs, h->dStatsOwn,
                     h->dDataScal, h->dKuu, h->dWk, h->dKinv, h->dLam, h->dWl, h->dSigma, h->dR, h->dTmp, h->dLambda0,
                     h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
-                    h->dUvT, h->dScratch, h->dParamsK, h->dXusK};
+                    h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evFork) hipEventDestroy(h->evFork);
@@ -781,18 +782,62 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
     return 0;
 }
 
-extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
-    if (!h || !value) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: null argument");
-    if (grad) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: gradient not implemented in this round");
-    if (!h->swept || h->dout != 1) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: needs a finished UniSGP sweep");
+// F(theta) = -sum_n [ -w/2 k_nn + w/2 |L^-1 k_n|^2 - w/2 |Uv k_n|^2 + w y_n mu_v'k_n ]  (derivative_helper.jl:23-39)
+//          = w/2 [ s_kk - tr(Kuu^-1 Psi2) + tr(R Psi2) ] - w b'mu_v
+// evaluated at the CURRENT kernel parameters with q(v) (mu_v, R = Sigma_v + mu mu') held fixed at the last finished
+// sweep -- exactly how the notebooks call it (experiments/regression_kin40k.ipynb:212-221: q(v) from the sweep, then the
+// gradient step on theta).  Re-uses the sweep's kernels: K_uu chain + Gram/SYRK at theta, then the trace kernels.
+static int theta_objective_eval(sgp_handle* h, hipStream_t s, double* value) {
+    enqueue_kuu(h, s);
+    enqueue_local(h, s);
+    const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
+    hipLaunchKernelGGL(k_trace_partial, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dR, h->dTrace, M, Mp,
+                       h->dout, Qp);
+    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, h->dTrace, h->dMu, h->dKuu, h->dLam, h->dInfo,
+                       h->dParams, h->dOut2, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS, Qp - Q);
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
     double out[SGP_R_COUNT], sc[SGP_S_COUNT];
-    int rc = sgp_get_scalars(h, out);
-    if (rc) return rc;
-    rc = sgp_get_stats(h, nullptr, nullptr, sc);
-    if (rc) return rc;
-    // -sum_n [ -w/2 k_nn + w/2 |alpha_n|^2 - w/2 |beta_n|^2 + w y_n k_n.mu ] = w/2 (sum I1 + sum I2 - s_yy)
+    HIPCHK(h, hipMemcpy(out, h->dOut2, sizeof out, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(sc, h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, sizeof sc, hipMemcpyDeviceToHost));
+    if (out[SGP_R_INFO_KUU] > 0) { h->err = "K_uu is not positive definite"; return (int)out[SGP_R_INFO_KUU]; }
     *value = 0.5 * h->hParams->W[0] * (out[SGP_R_SUM_I1] + out[SGP_R_SUM_I2] - sc[SGP_S_YY]);
     return 0;
+}
+
+extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
+    if (!h || !value) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: null argument");
+    if (!h->swept || h->dout != 1) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: needs a finished UniSGP sweep (q(v))");
+    if (!h->have_data || !h->have_kernel) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: data and kernel must be set");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    hipStream_t s = h->own;
+    int rc = theta_objective_eval(h, s, value);
+    if (rc || !grad) { h->swept_local = true; return rc; }
+    // gradient w.r.t. (sigma2, ell_1 .. ell_n_ell) by central differences on the device objective (2 (1 + n_ell) more
+    // evaluations, ~0.3 ms each at kin40k size).  The analytic kernel-derivative contraction is the planned replacement.
+    Params saved = *h->hParams;
+    const int np = 1 + h->n_ell;
+    for (int p = 0; p < np; ++p) {
+        double base = (p == 0) ? saved.sigma2 : 1.0 / saved.inv_ell[p - 1];
+        double step = 1e-5 * std::max(std::fabs(base), 1e-3);
+        double f[2];
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            *h->hParams = saved;
+            double v = base + (sgn ? -step : step);
+            if (p == 0) h->hParams->sigma2 = v;
+            else if (h->n_ell == 1) for (int d = 0; d < h->D; ++d) h->hParams->inv_ell[d] = 1.0 / v;
+            else h->hParams->inv_ell[p - 1] = 1.0 / v;
+            rc = theta_objective_eval(h, s, &f[sgn]);
+            if (rc) { *h->hParams = saved; return rc; }
+        }
+        grad[p] = (f[0] - f[1]) / (2.0 * step);
+    }
+    *h->hParams = saved;
+    double dummy;
+    rc = theta_objective_eval(h, s, &dummy);      // leave the device statistics at the unperturbed theta
+    h->swept_local = true;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

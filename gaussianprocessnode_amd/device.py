@@ -167,11 +167,14 @@ class SGPDevice:
         check(self._lib.sgp_predict(self._h, ptr(Xs), ns, ptr(mu), ptr(out)), self._h, "sgp_predict")
         return out[0] if self.d_out == 1 else out.T.copy()
 
-    def theta_objective(self):
+    def theta_objective(self, want_grad: bool = False, n_ell: Optional[int] = None):
+        """neg_log_backwardmess_fast at the current kernel with q(v) fixed at the last sweep; optionally its gradient
+        w.r.t. (sigma2, ell...)."""
         v = C.c_double()
-        check(self._lib.sgp_theta_objective(self._h, C.cast(C.byref(v), C.POINTER(C.c_double)), None), self._h,
+        g = np.empty(1 + (self.D if n_ell is None else n_ell)) if want_grad else None
+        check(self._lib.sgp_theta_objective(self._h, C.cast(C.byref(v), C.POINTER(C.c_double)), ptr(g)), self._h,
               "sgp_theta_objective")
-        return v.value
+        return (v.value, g) if want_grad else v.value
 
     def time_kernel(self, which: int, iters: int = 20, stream: int = 0) -> float:
         """Average launch duration (microseconds, HIP events) of the Gram or streaming-SYRK kernel."""

@@ -141,8 +141,10 @@ int sgp_w_stats(sgp_handle* h, double* I1 /* n */, double* I2 /* n */, void* str
  * mu_v (host, d_out*M) or NULL to use the handle's current posterior; mean is ns x d_out. */
 int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const double* mu_v, double* mean);
 
-/* sgp_theta_objective: neg_log_backwardmess_fast (helper_functions/derivative_helper.jl:23-39) at the
- * handle's kernel/posterior, and (grad != NULL) its gradient w.r.t. (sigma2, ell_1..ell_n_ell). */
+/* sgp_theta_objective: neg_log_backwardmess_fast (helper_functions/derivative_helper.jl:23-39) evaluated at the CURRENT
+ * kernel parameters (sgp_set_kernel) with q(v) -- mu_v and Uv'Uv -- held at the last finished sweep, as the notebooks use
+ * it (experiments/regression_kin40k.ipynb:212-221).  grad (may be NULL): d/d(sigma2, ell_1..ell_n_ell), 1 + n_ell
+ * entries (grad_llh_new!, derivative_helper.jl:59-63; here by central differences of the device objective). */
 int sgp_theta_objective(sgp_handle* h, double* value, double* grad);
 
 /* ---- building blocks exposed for tests / other callers (host pointers, blocking) ------------

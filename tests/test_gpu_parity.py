@@ -400,3 +400,30 @@ def test_repeated_sweeps_on_real_data_are_bitwise_identical(G, golden):
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
         assert o[3] == outs[0][3]
+
+
+def test_theta_objective_and_gradient_at_fixed_posterior(G):
+    """neg_log_backwardmess_fast / grad_llh_new! (helper_functions/derivative_helper.jl:23-39,59-63) at a
+    NEW theta with q(v) held at the last sweep -- the call pattern of experiments/regression_kin40k.ipynb:212-221."""
+    N, M, D = 600, 48, 3
+    X, Xu, y, _ = synth(N, M, D, seed=13)
+    s2, ell, w = 0.9, np.array([1.4, 2.0, 1.1]), 200.0
+    ref = O.vmp_sweep(Xu, X, y, None, s2, ell, w, jitter=0.0, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
+    s2n, elln = 1.05, np.array([1.3, 2.2, 1.0])              # the optimiser's next theta
+    f = lambda p: O.theta_objective(Xu, X, y, p[0], p[1:], ref.mu_v, ref.Uv, w)
+    p0 = np.concatenate([[s2n], elln])
+    g_ref = np.array([(f(p0 + 1e-6 * e) - f(p0 - 1e-6 * e)) / 2e-6 for e in np.eye(4)])
+    with G.SGPDevice(N, M, D) as dev:
+        dev.set_inducing(Xu)
+        dev.set_data(X, y)
+        dev.set_kernel(s2, ell, 0.0)
+        dev.set_prior_isotropic(50.0)
+        dev.set_noise([[w]])
+        dev.sweep()
+        mu0, _, _ = dev.posterior(want_cov=False, want_uv=False)
+        dev.set_kernel(s2n, elln, 0.0)
+        val, grad = dev.theta_objective(want_grad=True)
+        mu1, _, _ = dev.posterior(want_cov=False, want_uv=False)
+    assert np.array_equal(mu0, mu1)                              # q(v) untouched
+    assert math.isclose(val, f(p0), rel_tol=1e-8), (val, f(p0))
+    np.testing.assert_allclose(grad, g_ref, rtol=2e-4, atol=1e-4 * np.abs(g_ref).max())

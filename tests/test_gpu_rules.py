@@ -113,3 +113,60 @@ def test_not_positive_definite_raises_like_cholesky(graph):
     g["q_w"] = PointMass(-5.0)
     with pytest.raises(G.PosDefException):
         run_v(g, [PointMass(v) for v in g["y"]])
+
+
+# ------------------------------------------------------------------------------------------------
+# MultiSGP mirror (GPtest.jl:352-539, the MvNormal-input testsets) -- srcubature is restated, parity unpinned
+# ------------------------------------------------------------------------------------------------
+def test_multisgp_mirror_rules(graph):
+    from gaussianprocessnode_amd import multisgp as MS
+    from gaussianprocessnode_amd.cubature import srcubature
+    from gaussianprocessnode_amd.distributions import MvNormalMeanCovariance as MvN, WishartFast
+    rng = np.random.default_rng(3)
+    Xu2 = np.array([[i, j] for j in range(1, 6) for i in range(1, 6)], dtype=np.float64)        # GPtest.jl:20
+    M, D = 25, 2
+    q_theta = PointMass(THETA)
+    W = 10 * 50.0 * np.eye(2)                                                                    # mean of Wishart(10, 50 I)
+    meta = Mt.MultiSGPMeta(srcubature(), Xu2, None, None, None, None, Mt.SEARDKernel(), Mt.GPCache(), jitter=1e-12)
+    q_in = MvN(np.array([1.0, 2.7]), np.eye(2))                                                  # GPtest.jl:354
+    q_out = MvN(np.array([0.5, 1.4]), np.eye(2))                                                 # GPtest.jl:353
+    q_v = MvN(np.sin(rng.random(2 * M)), np.eye(2 * M))
+    pts, w = O.srcubature(q_in.m, q_in.S)
+    P0, P1, P2 = O.psi_statistics(Xu2, pts, w, 1.0, np.array([1.0]))
+    # :v message of one step  (GPtest.jl:432-456)
+    nu_v = MS.rule_v(q_out, q_in, PointMass(W), q_theta, meta)
+    np.testing.assert_allclose(nu_v.W, np.kron(W, P2), rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(nu_v.xi, np.kron(np.eye(2), P1[None, :]).T @ W @ q_out.m, rtol=1e-11)
+    # :out  (GPtest.jl:385-403)
+    nu_out = MS.rule_out(q_in, q_v, PointMass(W), q_theta, meta)
+    np.testing.assert_allclose(nu_out.mean(), np.kron(np.eye(2), P1[None, :]) @ q_v.m, rtol=1e-11)
+    assert np.array_equal(nu_out.precision(), W)
+    # a short sequence: q(v), Wishart statistics, energy against the per-step oracle rules
+    T = 6
+    q_ins = [MvN(rng.normal(size=2) + 2.5, np.diag(rng.uniform(0.05, 0.3, 2))) for _ in range(T)]
+    q_outs = [MvN(rng.normal(size=2), np.diag(rng.uniform(0.01, 0.1, 2))) for _ in range(T)]
+    Lam0 = np.eye(2 * M) / 10.0
+    prior = MvN(np.zeros(2 * M), 10.0 * np.eye(2 * M))
+    E_logdetW = 3.21
+    qv = MS.sweep(meta, q_outs, q_ins, PointMass(W), q_theta, prior, E_logdet_W=E_logdetW)
+    Lam, xi = Lam0.copy(), np.zeros(2 * M)
+    stats = []
+    for qi, qo in zip(q_ins, q_outs):
+        p, ww = O.srcubature(qi.m, qi.S)
+        s = O.psi_statistics(Xu2, p, ww, 1.0, np.array([1.0]))
+        stats.append(s)
+        x_t, L_t = O.multi_rule_v(s[1], s[2], qo.m, W)
+        Lam += L_t
+        xi += x_t
+    Sig_ref = np.linalg.inv(Lam)
+    mu_ref = Sig_ref @ xi
+    assert np.linalg.norm(qv.m - mu_ref) / np.linalg.norm(mu_ref) < 1e-8
+    assert np.linalg.norm(qv.S - Sig_ref) / np.linalg.norm(Sig_ref) < 1e-8
+    Kinv = O.cholinv(O.kernelmatrix(1.0, np.array([1.0]), Xu2) + 1e-12 * np.eye(M))
+    S_ref = sum(O.multi_rule_w(s[0], s[1], s[2], qo.m, qo.S, mu_ref, Sig_ref, Kinv) for s, qo in zip(stats, q_outs))
+    qW = MS.rule_w_summed(meta, 2.0, np.eye(2), T)
+    assert isinstance(qW, WishartFast) and qW.nu == 2.0 + T                                       # nu0 + N (each message D + 2)
+    np.testing.assert_allclose(qW.invS, np.eye(2) + S_ref, rtol=1e-6, atol=1e-6)
+    U_ref = sum(O.multi_average_energy(s[0], s[1], s[2], qo.m, qo.S, mu_ref, Sig_ref, W, E_logdetW, Kinv)
+                for s, qo in zip(stats, q_outs))
+    assert math.isclose(MS.average_energy_summed(meta), U_ref, rel_tol=1e-6)
