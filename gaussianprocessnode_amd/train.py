@@ -1,0 +1,64 @@
+"""Streaming minibatch driver: the loop of `PerformInference` / `my_free_energy`
+(experiments/regression_kin40k.ipynb:182-230) on the device path.
+
+Per epoch the prior is reset to N(0, prior_var I) (:203-204); each minibatch runs one VMP sweep with the previous
+minibatch's posterior as prior (:205-212), then one optimiser step on the kernel hyper-parameters with q(v) held fixed
+(:213-222, `grad_llh_new!` + `Flux.Optimise.update!`).  Host logic only -- the numbers come from the engine (C ABI)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .distributions import MvNormalMeanCovariance
+from .meta import softplus, split2batch
+
+
+@dataclass
+class AdaMax:
+    """Flux.AdaMax (eta = 0.001, beta = (0.9, 0.999), eps = 1e-8) -- the optimiser of the kin40k / banana notebooks."""
+    eta: float = 1e-3
+    beta: tuple = (0.9, 0.999)
+    eps: float = 1e-8
+    _state: dict = field(default_factory=dict, repr=False)
+
+    def update(self, x: np.ndarray, grad: np.ndarray) -> np.ndarray:
+        st = self._state.setdefault(id(x), dict(m=np.zeros_like(x), u=np.zeros_like(x), bp=np.array(self.beta, dtype=float)))
+        st["m"] = self.beta[0] * st["m"] + (1.0 - self.beta[0]) * grad
+        st["u"] = np.maximum(self.beta[1] * st["u"], np.abs(grad))
+        delta = (self.eta / (1.0 - st["bp"][0])) * st["m"] / (st["u"] + self.eps)
+        st["bp"] = st["bp"] * np.array(self.beta)
+        x -= delta
+        return x
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64)))
+
+
+def perform_inference(theta, xtrain, ytrain, Xu, engine, *, batch_size=500, epochs=1, w_val=1e4, prior_var=50.0,
+                      jitter=0.0, optimizer=None, learn_theta=True):
+    """Returns (q_v of the last minibatch, theta) like `PerformInference` (:196-230).  `theta` is the raw
+    (pre-softplus) parameter vector of `kernel_gp` (:108); `engine` an SGPDevice sized for `batch_size` points."""
+    theta = np.array(theta, dtype=np.float64)
+    xtrain = np.asarray(xtrain, dtype=np.float64).reshape(len(ytrain), -1)
+    Xu = np.asarray(Xu, dtype=np.float64).reshape(-1, xtrain.shape[1])
+    M = Xu.shape[0]
+    optimizer = optimizer or AdaMax()
+    xb, yb = split2batch((xtrain, np.asarray(ytrain, dtype=np.float64)), batch_size)
+    engine.set_inducing(Xu)
+    engine.set_noise([[w_val]])
+    mu, Sigma = np.zeros(M), prior_var * np.eye(M)
+    for _ in range(epochs):
+        mu, Sigma = np.zeros(M), prior_var * np.eye(M)                     # :203-204
+        for xi, yi in zip(xb, yb):
+            p = softplus(theta)
+            engine.set_prior_meancov(mu, Sigma)
+            engine.set_data(xi, yi)
+            engine.set_kernel(float(p[0]), p[1:], jitter)                  # :183-184 (no jitter in training)
+            engine.sweep()                                                 # :185-192  infer(iterations = 1)
+            mu, Sigma, _ = engine.posterior(want_uv=False)                 # :212
+            if learn_theta:
+                _, g = engine.theta_objective(want_grad=True, n_ell=len(p) - 1)    # :214-221
+                optimizer.update(theta, g * sigmoid(theta))                # chain rule through softplus; :222
+    return MvNormalMeanCovariance(mu, Sigma), theta

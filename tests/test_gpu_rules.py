@@ -170,3 +170,34 @@ def test_multisgp_mirror_rules(graph):
     U_ref = sum(O.multi_average_energy(s[0], s[1], s[2], qo.m, qo.S, mu_ref, Sig_ref, W, E_logdetW, Kinv)
                 for s, qo in zip(stats, q_outs))
     assert math.isclose(MS.average_energy_summed(meta), U_ref, rel_tol=1e-6)
+
+
+def test_streaming_driver_matches_oracle_loop():
+    """PerformInference (experiments/regression_kin40k.ipynb:196-230) -- posterior carry over ragged
+    minibatches and AdaMax steps on theta, against the same loop written with the oracle."""
+    import gaussianprocessnode_amd as G
+    from gaussianprocessnode_amd.train import AdaMax, perform_inference, sigmoid
+    rng = np.random.default_rng(2)
+    N, M, D, bs = 230, 16, 2, 100
+    X = rng.uniform(-1.7, 1.7, (N, D))
+    Xu = X[:M].copy()
+    y = np.sin(X.sum(axis=1)) + 0.1 * rng.normal(size=N)
+    theta0 = O.invsoftplus(np.array([1.0, 1.5, 1.2]))
+    w = 50.0
+    with G.SGPDevice(bs, M, D) as eng:
+        qv, theta = perform_inference(theta0, X, y, Xu, eng, batch_size=bs, epochs=2, w_val=w, optimizer=AdaMax(eta=0.01))
+    # oracle loop
+    th, opt = theta0.copy(), AdaMax(eta=0.01)
+    for _ in range(2):
+        mu, Sig = np.zeros(M), 50.0 * np.eye(M)
+        for lo in range(0, N, bs):
+            xi, yi = X[lo:lo + bs], y[lo:lo + bs]
+            p = O.softplus(th)
+            r = O.vmp_sweep(Xu, xi, yi, None, p[0], p[1:], w, mu0=mu, Sigma0=Sig)
+            mu, Sig = r.mu_v, r.Sigma_v
+            f = lambda q: O.theta_objective(Xu, xi, yi, q[0], q[1:], r.mu_v, r.Uv, w)
+            g = np.array([(f(p + 1e-6 * e) - f(p - 1e-6 * e)) / 2e-6 for e in np.eye(3)])
+            opt.update(th, g * sigmoid(th))
+    np.testing.assert_allclose(theta, th, rtol=1e-5, atol=1e-7)
+    assert np.linalg.norm(qv.m - mu) / np.linalg.norm(mu) < 1e-5
+    assert np.linalg.norm(qv.S - Sig) / np.linalg.norm(Sig) < 1e-5
