@@ -4,9 +4,10 @@ error behaviour, batched on the device.
 The reference's rules run once per data point and the N-fold Gaussian product folds N rank-1 M x M messages
 (GPnode/UniSGPnode.jl:62-73,144-173).  Here the per-point `:v` rule returns an O(1) token and the product runs
 ONE device sweep when the N-th token is folded -- the same `counter == N` hook the reference uses to refresh
-`meta.Uv` (:64-71).  The PointMass-input rules (`q_in::PointMass`) are the hot path and are implemented; the
-uncertain-input variants (:85-93,107-140,177-192,290-313) and the `:theta` closures (:242-287) raise
-NotImplementedError (next).
+`meta.Uv` (:64-71).  The PointMass-input rules (`q_in::PointMass`) are the hot path; of the uncertain-input variants the
+`:v` (:125-140) and `:out` (:85-93) rules run on the device as cubature-weighted data.  The per-node clamped `:w` /
+average-energy variants (:177-192,290-313), `:in` and the `:theta` closures (:242-287) raise NotImplementedError
+(next).
 
 Nothing here computes the node's mathematics on the CPU: every number comes from `meta.engine`
 (`SGPDevice`, the C ABI).  Without the HIP library and a gfx950 GPU the first sweep raises.
@@ -82,20 +83,29 @@ def _engine(meta: UniSGPMeta, n: int):
 # :v  (GPnode/UniSGPnode.jl:144-158 regression, :161-173 classification)
 # ------------------------------------------------------------------------------------------------
 def rule_v(q_out, q_in, q_w, q_theta, meta: UniSGPMeta) -> BufferUniSGP:
-    if not _is_pointmass(q_in):
-        raise NotImplementedError("UniSGP(:v) with an uncertain input (GPnode/UniSGPnode.jl:125-140) is not on the "
-                                  "device path yet")
     if not _is_pointmass(q_theta):
         raise TypeError("q_theta must be a PointMass")
     mu_y = float(q_out.mean())
     v_y = 0.0 if _is_pointmass(q_out) else float(q_out.var())
-    x = np.atleast_1d(np.asarray(q_in.mean(), dtype=np.float64))
+    if not _is_pointmass(q_in):
+        # uncertain input (GPnode/UniSGPnode.jl:125-140): the Psi-statistics are cubature sums, i.e. the same
+        # statistics over the cubature points with their weights; the rule also adds 1e-8 I to every Psi2 (:135)
+        if meta.method is None:
+            raise ValueError("UniSGP(:v) with an uncertain input needs meta.method (a cubature rule)")
+        pts, wts = meta.method.points_weights(q_in.mean(), q_in.var())
+        x = (np.asarray(pts, dtype=np.float64), np.asarray(wts, dtype=np.float64))
+        meta._batch["uncertain"] = True
+    else:
+        x = np.atleast_1d(np.asarray(q_in.mean(), dtype=np.float64))
+        if meta._pending and meta._batch.get("uncertain"):
+            raise NotImplementedError("PointMass and uncertain inputs mixed in one graph")
     w = _mean_w(q_w)
     theta = np.atleast_1d(np.asarray(q_theta.mean(), dtype=np.float64))
     if meta._pending and (meta._batch.get("w") != w or not np.array_equal(meta._batch.get("theta"), theta)):
         raise ValueError("all UniSGP nodes of one graph share q_w and q_theta")
     if not meta._pending:
-        meta._batch.update(w=w, theta=theta, E_logw=_elog_w(q_w), classification=False)
+        meta._batch.update(w=w, theta=theta, E_logw=_elog_w(q_w), classification=False,
+                           uncertain=not _is_pointmass(q_in))
     if not _is_pointmass(q_out):
         meta._batch["classification"] = True
     meta._pending.append((x, mu_y, v_y))
@@ -120,15 +130,33 @@ def prod(left, right: BufferUniSGP):
         raise RuntimeError(f"meta.N = {meta.N} but {len(meta._pending)} UniSGP(:v) messages were produced; meta.N must "
                            "equal the number of UniSGP nodes in the graph (experiments/regression_kin40k.ipynb:155)")
     # ---- the N-th message: one device sweep for the whole batch
-    X = np.stack([p[0] for p in meta._pending])
-    y = np.array([p[1] for p in meta._pending])
-    vy = np.array([p[2] for p in meta._pending]) if meta._batch["classification"] else None
-    eng = _engine(meta, meta.N)
+    uncertain = bool(meta._batch.get("uncertain"))
+    extra_precision = 0.0
+    if uncertain:
+        X = np.concatenate([p[0][0] for p in meta._pending])
+        wts = np.concatenate([p[0][1] for p in meta._pending])
+        y = np.concatenate([np.full(len(p[0][1]), p[1]) for p in meta._pending])
+        vy = None
+        extra_precision = 1e-8 * meta._batch["w"] * meta.N             # N messages, each with Psi2 + 1e-8 I (:135,138)
+    else:
+        X = np.stack([p[0] for p in meta._pending])
+        y = np.array([p[1] for p in meta._pending])
+        vy = np.array([p[2] for p in meta._pending]) if meta._batch["classification"] else None
+        wts = None
+    eng = _engine(meta, len(y))
     sigma2, ell = meta.kernel(meta._batch["theta"])
-    eng.set_data(X, y, vy)
+    eng.set_data(X, y, vy, wts, n_nodes=meta.N)
     eng.set_kernel(sigma2, ell, meta.jitter)
     eng.set_noise([[meta._batch["w"]]], meta._batch["E_logw"])
     prior = meta._prior
+    if extra_precision:
+        from .device import potri
+        if isinstance(prior, MvNormalMeanCovariance):
+            L0 = potri(prior.S, meta.device)
+            prior = MvNormalWeightedMeanPrecision(L0 @ prior.m, L0)
+        elif isinstance(prior, MvNormalMeanPrecision):
+            prior = MvNormalWeightedMeanPrecision(prior.W @ prior.m, prior.W)
+        prior = MvNormalWeightedMeanPrecision(prior.xi, prior.W + extra_precision * np.eye(len(prior.xi)))
     if isinstance(prior, MvNormalMeanCovariance):
         eng.set_prior_meancov(prior.m, prior.S)
     elif isinstance(prior, MvNormalWeightedMeanPrecision):
@@ -142,7 +170,8 @@ def prod(left, right: BufferUniSGP):
     meta.Uv = Uv                                   # :69
     meta.KuuL = eng.kuu_chol()
     meta.counter = 0                               # :70
-    meta._batch.update(X=X, y=y, vy=vy, index={x.tobytes(): i for i, x in enumerate(X)}, I=None, mu_v=mu_v)
+    index = {} if uncertain else {x.tobytes(): i for i, x in enumerate(X)}
+    meta._batch.update(X=X, y=y, vy=vy, index=index, I=None, mu_v=mu_v)
     meta._pending = []
     return MvNormalMeanCovariance(mu_v, Sigma_v)
 
@@ -187,8 +216,10 @@ def rule_w_summed(meta: UniSGPMeta, prior: GammaShapeRate) -> GammaShapeRate:
 # ------------------------------------------------------------------------------------------------
 def rule_out(q_in, q_v, q_w, q_theta, meta: UniSGPMeta) -> NormalMeanPrecision:
     if not _is_pointmass(q_in):
-        raise NotImplementedError("UniSGP(:out) with an uncertain input (GPnode/UniSGPnode.jl:85-93) is not on the "
-                                  "device path yet")
+        # GPnode/UniSGPnode.jl:85-93: Psi1 = sum_s omega_s K(Xu, x_s), mean = Psi1 . mu_v
+        pts, wts = meta.method.points_weights(q_in.mean(), q_in.var())
+        f = predict(np.asarray(pts, dtype=np.float64), q_v, q_theta, meta)
+        return NormalMeanPrecision(float(np.dot(wts, f)), _mean_w(q_w))
     m = predict(np.atleast_2d(np.asarray(q_in.mean(), dtype=np.float64)), q_v, q_theta, meta)[0]
     return NormalMeanPrecision(float(m), _mean_w(q_w))
 

@@ -201,3 +201,35 @@ def test_streaming_driver_matches_oracle_loop():
     np.testing.assert_allclose(theta, th, rtol=1e-5, atol=1e-7)
     assert np.linalg.norm(qv.m - mu) / np.linalg.norm(mu) < 1e-5
     assert np.linalg.norm(qv.S - Sig) / np.linalg.norm(Sig) < 1e-5
+
+
+def test_uncertain_input_v_and_out_rules():
+    """GPtest.jl:153-161,184-192 (q_in::Normal): Psi-statistics by ghcubature(21), `Psi2 + 1e-8 I` per message
+    (GPnode/UniSGPnode.jl:134-139); here all N messages are folded with the prior in one sweep."""
+    from gaussianprocessnode_amd.cubature import ghcubature
+    rng = np.random.default_rng(5)
+    N, w = 6, 1.0
+    q_w, q_theta = GammaShapeRate(1.0, 1.0), PointMass(THETA)
+    meta = Mt.make_uni_meta(ghcubature(21), XU, KERNEL, N, jitter=1e-8)
+    q_ins = [NormalMeanVariance(m, v) for m, v in zip(rng.uniform(1, 10, N), rng.uniform(0.2, 1.0, N))]
+    q_outs = [NormalMeanVariance(m, 2.0) for m in rng.normal(size=N)]
+    prior = MvNormalMeanCovariance(np.sin(rng.random(10)), np.eye(10))
+    msgs = [U.rule_v(q_outs[i], q_ins[i], q_w, q_theta, meta) for i in range(N)]
+    q = prior
+    for m in msgs:
+        q = U.prod(q, m)
+    Lam = np.linalg.inv(prior.S)
+    xi = Lam @ prior.m
+    for qi, qo in zip(q_ins, q_outs):
+        pts, wts = O.ghcubature_1d(21, qi.m, qi.v)
+        P0, P1, P2 = O.psi_statistics(XU[:, None], pts[:, None], wts, 1.0, np.array([1.0]))
+        Lam = Lam + w * (P2 + 1e-8 * np.eye(10))                 # gt_cov_v_1 = inv(mean(q_w) (Psi2 + 1e-8 I))
+        xi = xi + w * qo.m * P1
+    S_ref = np.linalg.inv(Lam)
+    np.testing.assert_allclose(q.cov(), S_ref, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(q.mean(), S_ref @ xi, rtol=1e-8, atol=1e-11)
+    # :out with an uncertain input (GPtest.jl:156-161)
+    nu = U.rule_out(q_ins[0], q, q_w, q_theta, meta)
+    pts, wts = O.ghcubature_1d(21, q_ins[0].m, q_ins[0].v)
+    _, P1, _ = O.psi_statistics(XU[:, None], pts[:, None], wts, 1.0, np.array([1.0]))
+    assert math.isclose(nu.mean(), float(P1 @ q.mean()), rel_tol=1e-10) and math.isclose(nu.var(), 1.0)
