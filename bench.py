@@ -104,6 +104,7 @@ def main():
     for _ in range(args.warmup):
         sweep.sweep()
     barrier()
+    dev.phase_totals(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sweep.sweep()
@@ -115,14 +116,22 @@ def main():
         elapsed = float(t.item())
 
     # ---- live per-kernel numbers (this rank's shard) ------------------------------------------------
-    stamps = dev.timestamps()                                   # 100 MHz ticks of the last timed sweep
-    tick_us = lambda i: (stamps[i, 1] - stamps[i, 0]) / 100.0
+    # (1) averages over the K timed sweeps, from in-kernel first-block-in / last-block-out stamps (100 MHz clock)
+    #     accumulated on the device inside the timed graph replays -- no host interaction in the timed region;
+    # (2) HIP events around eager launches of the same kernel on the same stream, right after the timed region (the
+    #     kernel alone on the chip: in the sweep it shares the chip with the K_uu chain on the side stream).
+    phase_us, n_counted = dev.phase_totals()
+    tick_us = lambda i: float(phase_us[i])
     stream = torch.cuda.current_stream().cuda_stream
-    syrk_us = dev.time_kernel(_lib.SGP_T_SYRK, 50, stream)      # HIP events, eager launches, same stream
-    gram_us = dev.time_kernel(_lib.SGP_T_GRAM, 50, stream)
+    syrk_us_alone = dev.time_kernel(_lib.SGP_T_SYRK, 10, stream)
+    gram_us_alone = dev.time_kernel(_lib.SGP_T_GRAM, 10, stream)
+    syrk_us = tick_us(_lib.SGP_T_SYRK)
     n_loc = hi - lo
     syrk_flops = float(n_loc) * M * (M + 1)                     # SYRK lower half n M (M+1)
     achieved = syrk_flops / (syrk_us * 1e-6) / 1e12
+    # HBM traffic of the same kernel: separate rocprofv3 --pmc passes (profiles/r01_pmc_*_T.txt), FETCH_SIZE doubled as
+    # MI355X_MICROARCH.md prescribes for 16-B-per-lane streaming reads; only valid for the workload it was measured on
+    PMC_TRAFFIC = {("T", 1): 2 * 22.970e6 + 37.772e6}
 
     out = {
         "metric": "VMP iterations/sec (sparse-GP node sweep, kin40k-shaped synthetic)",
@@ -142,11 +151,14 @@ def main():
                    "points_per_gpu": n_loc, "parallelism": f"data-sharded x{world}, 1 all-reduce of {eng.stats.numel()} f64"},
         "roofline": {"kernel": "k_syrk_stream (Psi2 = K_uf K_uf^T, v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                     "launch_us_hip_events": syrk_us, "launch_us_in_graph": tick_us(_lib.SGP_T_SYRK),
-                     "algorithmic_flops_per_launch": syrk_flops},
-        "phases_us": {"sweep_device": tick_us(_lib.SGP_T_SWEEP), "gram_uf_in_graph": tick_us(_lib.SGP_T_GRAM),
-                      "gram_uf_hip_events": gram_us, "syrk_in_graph": tick_us(_lib.SGP_T_SYRK)},
+                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": PMC_TRAFFIC.get((args.workload, world)),
+                     "launch_us_in_timed_region": syrk_us, "launches_averaged": int(n_counted),
+                     "launch_us_alone_hip_events": syrk_us_alone,
+                     "achieved_alone": syrk_flops / (syrk_us_alone * 1e-6) / 1e12,
+                     "algorithmic_flops_per_launch": syrk_flops,
+                     "peak_note": "78.6 = MI355X FP64 matrix spec; tools/mfma_f64_probe.hip sustains 47.5 (MFMA) / 63.7 (VALU FMA)"},
+        "phases_us": {"sweep_device": tick_us(_lib.SGP_T_SWEEP), "gram_uf": tick_us(_lib.SGP_T_GRAM),
+                      "gram_uf_alone_hip_events": gram_us_alone, "syrk": syrk_us},
     }
 
     if rank == 0:

@@ -25,7 +25,7 @@ EXPORTS = [
     "sgp_set_kernel", "sgp_set_output_cov_sum", "sgp_set_prior", "sgp_set_noise", "sgp_sweep_local", "sgp_sweep_finish", "sgp_sweep",
     "sgp_stats_layout", "sgp_bind_stats", "sgp_get_posterior", "sgp_get_scalars", "sgp_get_stats",
     "sgp_get_kuu_chol", "sgp_get_wishart_invscale", "sgp_w_stats", "sgp_predict", "sgp_theta_objective",
-    "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_time_kernel",
+    "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_get_phase_totals", "sgp_time_kernel",
 ]
 
 
@@ -101,6 +101,7 @@ def load(build_if_missing: bool = True):
     lib.sgp_potrf.argtypes = [C.c_int32, dp, C.c_int32, dp]
     lib.sgp_potri.argtypes = [C.c_int32, dp, C.c_int32, dp]
     lib.sgp_get_timestamps.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.sgp_get_phase_totals.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]
     lib.sgp_time_kernel.argtypes = [vp, C.c_int32, C.c_int32, vp, dp]
     for name in EXPORTS:
         fn = getattr(lib, name)

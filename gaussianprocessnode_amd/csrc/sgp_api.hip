@@ -57,6 +57,7 @@ struct sgp_handle {
     double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr, *dOut2 = nullptr;
     int* dInfo = nullptr;
     int64_t* dStamps = nullptr;
+    int64_t* dStampTotals = nullptr;
     Params* hParams = nullptr;     // pinned
     Params* dParams = nullptr;
     Params* dParamsK = nullptr;    // the K_uu chain's own copy (it runs on the side stream)
@@ -206,6 +207,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dTrace, (size_t)TRACE_BLOCKS * TRACE_SLOTS);
     ALLOC(h->dInfo, 4);
     ALLOC(h->dStamps, 2 * SGP_T_COUNT);
+    ALLOC(h->dStampTotals, SGP_T_COUNT + 1);
     ALLOC(h->dParams, 1);
     ALLOC(h->dParamsK, 1);
     ALLOC(h->dXusK, Mp * h->D);
@@ -236,6 +238,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     hipMemset(h->dInfo, 0, 4 * sizeof(int));
     hipMemset(h->dOut, 0, SGP_R_COUNT * sizeof(double));
     hipMemset(h->dStamps, 0, 2 * SGP_T_COUNT * sizeof(int64_t));
+    hipMemset(h->dStampTotals, 0, (SGP_T_COUNT + 1) * sizeof(int64_t));
     hipMemset(h->dMu, 0, Qp * sizeof(double));
     hipMemset(h->dXi0, 0, Qp * sizeof(double));
     *out = h;
@@ -253,7 +256,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
     void* bufs[] = {h->dXu, h->dXus, h->dX, h->dYw, h->dY, h->dYv, h->dOmega, h->dKuf, h->dBpart, h->dSlabs, h->dStatsOwn,
                     h->dDataScal, h->dKuu, h->dWk, h->dKinv, h->dLam, h->dWl, h->dSigma, h->dR, h->dTmp, h->dLambda0,
                     h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
-                    h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2};
+                    h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evFork) hipEventDestroy(h->evFork);
@@ -501,7 +504,8 @@ static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
                        h->dout, Qp);
     hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, h->dTrace, h->dMu, h->dKuu, h->dLam, h->dInfo,
                        h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS, Qp - Q);
-    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, s, h->dStamps + 2 * SGP_T_SWEEP + 1);
+    hipLaunchKernelGGL(k_stamp_accumulate, dim3(1), dim3(64), 0, s, h->dStamps, h->dStampTotals, (int)SGP_T_SWEEP,
+                       (int)SGP_T_COUNT);
 }
 
 typedef void (*enqueue_fn)(sgp_handle*, hipStream_t);
@@ -538,14 +542,15 @@ extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) {
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
-    // fork: the K_uu chain starts on the side stream once everything earlier on `s` (the previous sweep) is done
+    rc = run_sequence(h, h->gLocal, enqueue_local, s);
+    if (rc) return rc;
+    // fork: the K_uu chain starts on the side stream AFTER the data-sized kernels (they want the whole chip; the chain
+    // is a few-CU latency-bound sequence that then runs beside the all-reduce and the Lambda chain of sgp_sweep_finish)
     HIPCHK(h, hipEventRecord(h->evFork, s));
     HIPCHK(h, hipStreamWaitEvent(h->side, h->evFork, 0));
     rc = run_sequence(h, h->gKuu, enqueue_kuu, h->side);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->evSide, h->side));
-    rc = run_sequence(h, h->gLocal, enqueue_local, s);
-    if (rc) return rc;
     h->swept_local = true;
     return 0;
 }
@@ -668,6 +673,18 @@ extern "C" int sgp_get_timestamps(sgp_handle* h, int64_t* out) {
     int rc = sync_all(h);
     if (rc) return rc;
     HIPCHK(h, hipMemcpy(out, h->dStamps, 2 * SGP_T_COUNT * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int sgp_get_phase_totals(sgp_handle* h, int64_t* totals, int64_t* count, int32_t reset) {
+    if (!h || !totals || !count) return SGP_ERR_ARG;
+    int rc = sync_all(h);
+    if (rc) return rc;
+    int64_t buf[SGP_T_COUNT + 1];
+    HIPCHK(h, hipMemcpy(buf, h->dStampTotals, sizeof buf, hipMemcpyDeviceToHost));
+    for (int i = 0; i < SGP_T_COUNT; ++i) totals[i] = buf[i];
+    *count = buf[SGP_T_COUNT];
+    if (reset) HIPCHK(h, hipMemset(h->dStampTotals, 0, sizeof buf));
     return 0;
 }
 

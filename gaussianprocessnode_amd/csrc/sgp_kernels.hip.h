@@ -57,6 +57,17 @@ __device__ __forceinline__ void stamp_enter(int64_t* stamps) {
 __device__ __forceinline__ void stamp_exit(int64_t* stamps) {
     if (stamps && threadIdx.x == 0) atomicMax(reinterpret_cast<long long*>(stamps + 1), (long long)realtime_ticks());
 }
+// end-of-sweep stamp + running totals over sweeps: totals[i] += end_i - begin_i, totals[nslots] += 1
+__global__ void k_stamp_accumulate(int64_t* stamps, int64_t* totals, int sweep_slot, int nslots) {
+    if (threadIdx.x == 0) {
+        stamps[2 * sweep_slot + 1] = realtime_ticks();
+        for (int i = 0; i < nslots; ++i) {
+            int64_t b = stamps[2 * i], e = stamps[2 * i + 1];
+            if (e > b && b != 0x7fffffffffffffffLL) totals[i] += e - b;
+        }
+        totals[nslots] += 1;
+    }
+}
 __global__ void k_stamp_reset(int64_t* stamps, int nslots) {
     int i = threadIdx.x;
     if (i < nslots) { stamps[2 * i] = 0x7fffffffffffffffLL; stamps[2 * i + 1] = 0; }

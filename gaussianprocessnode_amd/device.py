@@ -183,6 +183,14 @@ class SGPDevice:
                                         C.cast(C.byref(v), C.POINTER(C.c_double))), self._h, "sgp_time_kernel")
         return v.value
 
+    def phase_totals(self, reset: bool = False):
+        """(average microseconds per sweep for every phase slot, number of sweeps counted) since the last reset."""
+        tot = (C.c_int64 * _lib.SGP_T_COUNT)()
+        cnt = C.c_int64()
+        check(self._lib.sgp_get_phase_totals(self._h, tot, C.byref(cnt), int(reset)), self._h, "sgp_get_phase_totals")
+        n = max(cnt.value, 1)
+        return np.array(tot[:], dtype=np.float64) / 100.0 / n, cnt.value
+
     def timestamps(self):
         out = (C.c_int64 * (2 * _lib.SGP_T_COUNT))()
         check(self._lib.sgp_get_timestamps(self._h, out), self._h, "sgp_get_timestamps")
