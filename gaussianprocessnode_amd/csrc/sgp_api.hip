@@ -455,7 +455,8 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
     hipMemcpyAsync(h->dParamsK, h->hParams, sizeof(Params), hipMemcpyHostToDevice, s);
     hipMemsetAsync(h->dInfo, 0, sizeof(int), s);
-    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->dParamsK, M, Mp, D);
+    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->dParamsK, M, Mp, D,
+                       (int64_t*)nullptr, 0, 0);
     hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
     launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s);
     launch_trtri(h->dKuu, h->dWk, h->dKinv, Mp, T, s);
@@ -465,9 +466,8 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
 static void enqueue_local(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
     hipMemcpyAsync(h->dParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice, s);
-    hipLaunchKernelGGL(k_stamp_reset, dim3(1), dim3(64), 0, s, h->dStamps, (int)SGP_T_COUNT);
-    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, s, h->dStamps + 2 * SGP_T_SWEEP);
-    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->dParams, M, Mp, D);
+    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->dParams, M, Mp, D,
+                       h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP);
     if (h->n > 0) {
         hipLaunchKernelGGL(k_gram_uf, dim3(T, h->nblk), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                            h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + 2 * SGP_T_GRAM);
@@ -492,9 +492,9 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     launch_trtri(h->dLam, h->dWl, h->dSigma, Qp, TQ, s);
     launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1);
     hipLaunchKernelGGL(k_symv, dim3((Qp + 3) / 4), dim3(256), 0, s, h->dSigma, h->dXi, h->dMu, Qp, Qp);
-    hipLaunchKernelGGL(k_form_R, dim3(TQ, TQ), dim3(256), 0, s, h->dSigma, h->dMu, h->dR, Q, Qp);
+    hipLaunchKernelGGL(k_form_R, dim3(TQ, TQ), dim3(256), 0, s, h->dSigma, h->dMu, h->dR, Q, Qp, (const double*)h->dWl,
+                       h->dTmp);
     // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69)
-    hipLaunchKernelGGL(k_transpose, dim3(TQ, TQ), dim3(256), 0, s, h->dWl, h->dTmp, Qp);
     hipLaunchKernelGGL(k_cholupdate, dim3(1), dim3(512), 0, s, h->dTmp, h->dMu, h->dUvT, Qp);
 }
 
@@ -781,7 +781,8 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
         dMu = dMuTmp;
     }
     HIPCHK(h, hipMemcpyAsync(h->dParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->dParams, h->M, h->Mp, h->D);
+    hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->dParams, h->M, h->Mp, h->D,
+                       (int64_t*)nullptr, 0, 0);
     switch (h->D) {
         case 1: launch_predict<1>(h, dXs, dMu, dMean, ns, s); break;
         case 2: launch_predict<2>(h, dXs, dMu, dMean, ns, s); break;

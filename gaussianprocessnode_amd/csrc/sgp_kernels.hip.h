@@ -77,7 +77,12 @@ __global__ void k_stamp_reset(int64_t* stamps, int nslots) {
 // Xu (D x M, AoS) -> Xus (SoA, scaled by 1/ell, padded to Mp with zeros)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_prep_xu(const double* __restrict__ Xu, double* __restrict__ Xus, const Params* __restrict__ P,
-                          int M, int Mp, int D) {
+                          int M, int Mp, int D, int64_t* stamps, int nslots, int sweep_slot) {
+    if (stamps && blockIdx.x == 0 && threadIdx.x < nslots) {        // first kernel of a sweep: reset the phase stamps
+        const int i = threadIdx.x;
+        stamps[2 * i] = (i == sweep_slot) ? realtime_ticks() : 0x7fffffffffffffffLL;
+        stamps[2 * i + 1] = 0;
+    }
     int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= Mp) return;
     for (int d = 0; d < D; ++d) Xus[(size_t)d * Mp + m] = (m < M) ? Xu[(size_t)m * D + d] * P->inv_ell[d] : 0.0;
@@ -492,7 +497,8 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// 1/sqrt(d): v_rsq_f64 seed + two Newton steps (full double precision to a few ulp)
+// 1/sqrt(d): v_rsq_f64 seed (measured ~2^-25 relative on gfx950) + two Newton steps (rounding-limited).  One step
+// (-DSGP_RSQRT_ONE_STEP: ~1e-15 relative) was measured to buy < 0.5 % of the sweep, so the exact form stays.
 __device__ __forceinline__ double rsqrt_nr(double d) {
     double y = __builtin_amdgcn_rsq(d);
     const double h = 0.5 * d;
@@ -975,8 +981,11 @@ __global__ void __launch_bounds__(256) k_symv(const double* __restrict__ S, cons
 }
 
 // R = Sigma + mu mu^T on the first q entries, identity pad kept
+// also transposes W (-> Wt) when given: one launch instead of two on the latency-bound tail
 __global__ void __launch_bounds__(256) k_form_R(const double* __restrict__ Sigma, const double* __restrict__ mu,
-                                                double* __restrict__ R, int Q, int Qp) {
+                                                double* __restrict__ R, int Q, int Qp, const double* __restrict__ W,
+                                                double* __restrict__ Wt) {
+    __shared__ double tile[TB * LT];
     const int gi = blockIdx.x * TB + (threadIdx.x & 63);
     const int jg = threadIdx.x >> 6;
     for (int jj = 0; jj < 16; ++jj) {
@@ -985,17 +994,30 @@ __global__ void __launch_bounds__(256) k_form_R(const double* __restrict__ Sigma
         if (gi < Q && gj < Q) v = fma(mu[gi], mu[gj], v);
         R[(size_t)gj * Qp + gi] = v;
     }
+    if (W) {
+        const int I = blockIdx.x * TB, J = blockIdx.y * TB;
+        for (int e = threadIdx.x; e < TB * TB; e += 256) {
+            int c = e >> 6, r = e & 63;
+            tile[r * LT + c] = W[(size_t)(J + c) * Qp + I + r];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < TB * TB; e += 256) {
+            int c = e >> 6, r = e & 63;
+            Wt[(size_t)(I + c) * Qp + J + r] = tile[c * LT + r];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69) as a rank-1 UPDATE of V = chol(Sigma_v).U.
 //   Vt holds W'^T column-major, W' = L'^-1 the inverse factor of the index-reversed Lambda, so that
 //   V[k][j] = W'[Qp-1-k][Qp-1-j] = Vt[(Qp-1-j) + (Qp-1-k) * Qp]   (a row of V is contiguous, descending).
-//   Row k of the update:  r = sqrt(V_kk^2 + x_k^2);  U_kj = (V_kk V_kj + x_k x_j) / r;  x_j <- (r x_j - x_k U_kj) / V_kk.
+//   Row k of the update (a Givens rotation):  r = sqrt(V_kk^2 + x_k^2), c = V_kk / r, s = x_k / r;
+//   U_kj = c V_kj + s x_j;  x_j <- c x_j - s V_kj.
 //   Output LR = Uv^T (lower, column-major: column k = row k of Uv), the layout potrf(R) would have produced.
 // One workgroup of 8 waves, 64 pivots per iteration:
 //   wave 0    : the 64 x 64 diagonal block sequentially, entirely in registers (v_readlane broadcasts, no barrier),
-//               publishing per pivot the four scalars A = V_kk/r, B = x_k/r, C = r/V_kk, D = x_k/V_kk;
+//               publishing per pivot the rotation c = V_kk/r, s = x_k/r;
 //               after the barrier it applies them to the next block's 64 columns (which it needs next);
 //   wave 1    : applies the PREVIOUS block's rotations to the block after the next one;
 //   waves 2-7 : apply the previous block's rotations to all later columns.
@@ -1009,7 +1031,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// apply the 64 rotations `cs` (4 scalars per pivot) of pivot block bb to column j
+// apply the 64 Givens rotations `cs` (c, s per pivot) of pivot block bb to column j:  u = c v + s x,  x <- c x - s v
 __device__ __forceinline__ void cholupdate_column(const double* __restrict__ Vt, double* __restrict__ LR, double* xs,
                                                   const double* cs, int Qp, int bb, int j) {
     double x = xs[j];
@@ -1022,10 +1044,9 @@ __device__ __forceinline__ void cholupdate_column(const double* __restrict__ Vt,
         for (int u = 0; u < 16; ++u) v[u] = vp[-(ptrdiff_t)(k0 + u) * Qp];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const double4 c = *reinterpret_cast<const double4*>(cs + 4 * (k0 + u));
-            const double uu = fma(c.y, x, c.x * v[u]);
-            x = fma(c.z, x, -c.w * uu);
-            up[(size_t)(k0 + u) * Qp] = uu;
+            const double2 c = *reinterpret_cast<const double2*>(cs + 2 * (k0 + u));
+            up[(size_t)(k0 + u) * Qp] = fma(c.x, v[u], c.y * x);
+            x = fma(c.x, x, -c.y * v[u]);
         }
     }
     xs[j] = x;
@@ -1034,7 +1055,8 @@ __device__ __forceinline__ void cholupdate_column(const double* __restrict__ Vt,
 __global__ void __launch_bounds__(512) k_cholupdate(const double* __restrict__ Vt, const double* __restrict__ mu,
                                                     double* __restrict__ LR, int Qp) {
     __shared__ double xs[CU_MAXQ];
-    __shared__ __attribute__((aligned(32))) double cs[2][64 * 4];
+    __shared__ __attribute__((aligned(16))) double cs[2][64 * 2];
+    __shared__ double Vb[64 * 64];                       // diagonal block of V, Vb[kk][j] (wave 0 only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = Qp / 64;
     for (int e = tid; e < Qp; e += 512) xs[e] = mu[e];
@@ -1042,31 +1064,31 @@ __global__ void __launch_bounds__(512) k_cholupdate(const double* __restrict__ V
 #pragma unroll 1
     for (int i = 0; i < nb; ++i) {
         if (wave == 0) {
-            // ---- diagonal block i: 64 sequential pivots in registers
+            // ---- diagonal block i: 64 sequential pivots.  Per pivot: r = sqrt(v_kk^2 + x_k^2), c = v_kk / r, s = x_k / r;
+            // row k of Uv is c V_k + s x, and x <- c x - s V_k.  The chain through x_k is readlane -> fma -> rsqrt -> fma.
             const int base = 64 * i, j = base + lane;
-            double vr[64];
             const double* vp = Vt + (size_t)(Qp - 1 - base) * Qp + (Qp - 1 - j);
-#pragma unroll
-            for (int kk = 0; kk < 64; ++kk) vr[kk] = vp[-(ptrdiff_t)kk * Qp];      // V[base + kk][j]; zero below the diagonal
+#pragma unroll 16
+            for (int kk = 0; kk < 64; ++kk) Vb[kk * 64 + lane] = vp[-(ptrdiff_t)kk * Qp];   // V[base + kk][j]; zero below the diagonal
+            __builtin_amdgcn_wave_barrier();
             double xa = xs[j];
-            double dg = 0.0;
-            static_for<64>([&](auto kc) { constexpr int kk = decltype(kc)::value; if (lane == kk) dg = vr[kk]; });
-            const double iv = 1.0 / dg;
+            const double dg = Vb[lane * 64 + lane];                                         // this lane's diagonal entry
             double* csw = cs[i & 1];
-            static_for<64>([&](auto kc) {
-                constexpr int kk = decltype(kc)::value;
-                const double vkk = readlane_f64(vr[kk], kk);
+            double vcur = Vb[lane];
+#pragma unroll 4
+            for (int kk = 0; kk < 64; ++kk) {
+                const double vnext = Vb[((kk + 1) & 63) * 64 + lane];                       // prefetch the next row
+                const double vkk = readlane_f64(dg, kk);
                 const double xk = readlane_f64(xa, kk);
-                const double ivk = readlane_f64(iv, kk);
                 const double t = fma(xk, xk, vkk * vkk);
                 const double ir = rsqrt_nr(t);
-                const double r = t * ir;
-                const double A = vkk * ir, B = xk * ir, C = r * ivk, D = xk * ivk;
-                const double uu = fma(B, xa, A * vr[kk]);
-                xa = fma(C, xa, -D * uu);
+                const double c = vkk * ir, sn = xk * ir;
+                const double uu = fma(c, vcur, sn * xa);
+                xa = fma(c, xa, -sn * vcur);
                 LR[(size_t)(base + kk) * Qp + j] = (lane >= kk) ? uu : 0.0;
-                if (lane == 0) *reinterpret_cast<double4*>(csw + 4 * kk) = make_double4(A, B, C, D);
-            });
+                if (lane == 0) *reinterpret_cast<double2*>(csw + 2 * kk) = make_double2(c, sn);
+                vcur = vnext;
+            }
         } else if (i > 0) {
             // ---- rotations of block i-1 on later columns
             const double* csr = cs[(i - 1) & 1];
