@@ -236,8 +236,26 @@ __device__ __forceinline__ int acc_row(int lane, int wr, int ti, int r) { return
 __device__ __forceinline__ int acc_col(int lane, int wc, int tj) { return wc * 32 + tj * 16 + (lane & 15); }
 
 // panel[k][i] = G[(row0 + i) + (col0 + k) * ld]  for i < 64, k < kcount   (contiguous along i in memory)
+// (all global loads are issued before the first LDS store: one memory latency per panel instead of one per pass)
 __device__ __forceinline__ void load_panel_n(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0,
                                              int kcount, int tid) {
+    if (kcount == TB) {
+        double2 v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int t = tid + 256 * u, k = t >> 4, rq = t & 15;
+            const double* src = G + (size_t)(col0 + k) * ld + row0 + rq * 4;
+            v0[u] = *reinterpret_cast<const double2*>(src);
+            v1[u] = *reinterpret_cast<const double2*>(src + 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int t = tid + 256 * u, k = t >> 4, rq = t & 15;
+            double* dst = panel + k * PS + rq * 4;
+            dst[0] = v0[u].x; dst[1] = v0[u].y; dst[2] = v1[u].x; dst[3] = v1[u].y;
+        }
+        return;
+    }
     for (int t = tid; t < kcount * 16; t += 256) {
         int k = t >> 4, rq = t & 15;
         const double* src = G + (size_t)(col0 + k) * ld + row0 + rq * 4;
@@ -662,11 +680,25 @@ __device__ __forceinline__ void trsm_tile(double* X, const double* S, const doub
 }
 
 // coalesced copies between a column-major global tile and an LDS tile S[r][c]
-__device__ __forceinline__ void tile_g2s(double* S, const double* __restrict__ A, size_t ld, int row0, int col0) {
-    for (int e = threadIdx.x; e < TB * TB; e += 256) {
-        int c = e >> 6, r = e & 63;
-        S[r * LT + c] = A[(size_t)(col0 + c) * ld + row0 + r];
+struct TileRegs { double v[16]; };
+__device__ __forceinline__ void tile_g2r(TileRegs& t, const double* __restrict__ A, size_t ld, int row0, int col0) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        int e = threadIdx.x + 256 * u, c = e >> 6, r = e & 63;
+        t.v[u] = A[(size_t)(col0 + c) * ld + row0 + r];
     }
+}
+__device__ __forceinline__ void tile_r2s(double* S, const TileRegs& t) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        int e = threadIdx.x + 256 * u, c = e >> 6, r = e & 63;
+        S[r * LT + c] = t.v[u];
+    }
+}
+__device__ __forceinline__ void tile_g2s(double* S, const double* __restrict__ A, size_t ld, int row0, int col0) {
+    TileRegs t;
+    tile_g2r(t, A, ld, row0, col0);
+    tile_r2s(S, t);
 }
 __device__ __forceinline__ void tile_s2g(const double* S, double* __restrict__ A, size_t ld, int row0, int col0) {
     for (int e = threadIdx.x; e < TB * TB; e += 256) {
@@ -709,33 +741,56 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
         const int q0 = (j - 1) * TB;
         for (int e = tid; e < TB * TB; e += 256) A[(size_t)(q0 + (e >> 6)) * ld + q0 + (e & 63)] = scratch[e];
     }
+    // the tiles this block updates are fetched into registers now, so that their latency hides behind the MFMA phase
+    TileRegs rX, rS;
+    if (!panel) tile_g2r(rX, A, ld, i0, k0);
+    else {
+        tile_g2r(rS, A, ld, j0, j0);
+        if (a != 0) tile_g2r(rX, A, ld, i0, j0);
+    }
     if (j > 0) {
         const int p0 = (j - 1) * TB;
         load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
         if (a != b) load_panel_n(P1, A, ld, k0, p0, TB, tid);   // L_{k, j-1}
         __syncthreads();
-        const double* Pb = (a != b) ? P1 : P0;
-        tile_mma(accX, P0, Pb, TB, lane, wr, wc);
-        if (panel && a != 0) tile_mma(accD, P1, P1, TB, lane, wr, wc);   // the diagonal tile's update, redundantly
+        if (panel && a != 0) {
+            // own tile (P0 P1^T) and, redundantly, the diagonal tile (P1 P1^T): eight independent accumulators per k-step
+            const int li = lane & 15, lk = lane >> 4;
+            const double* ap = P0 + lk * PS + wr * 32 + li;
+            const double* dp = P1 + lk * PS + wr * 32 + li;
+            const double* bp = P1 + lk * PS + wc * 32 + li;
+#pragma unroll 2
+            for (int k4 = 0; k4 < TB; k4 += 4) {
+                double a0 = ap[0], a1 = ap[16], d0 = dp[0], d1 = dp[16], b0 = bp[0], b1 = bp[16];
+                accX.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, accX.t[0][0], 0, 0, 0);
+                accD.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(d0, b0, accD.t[0][0], 0, 0, 0);
+                accX.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, accX.t[0][1], 0, 0, 0);
+                accD.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(d0, b1, accD.t[0][1], 0, 0, 0);
+                accX.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, accX.t[1][0], 0, 0, 0);
+                accD.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(d1, b0, accD.t[1][0], 0, 0, 0);
+                accX.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accX.t[1][1], 0, 0, 0);
+                accD.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(d1, b1, accD.t[1][1], 0, 0, 0);
+                ap += 4 * PS; dp += 4 * PS; bp += 4 * PS;
+            }
+        } else {
+            tile_mma(accX, P0, (a != b) ? P1 : P0, TB, lane, wr, wc);
+        }
         __syncthreads();
     }
     if (!panel) {
         // plain trailing tile: A_ik -= acc, through LDS for coalesced global access
-        tile_g2s(X, A, ld, i0, k0);
+        tile_r2s(X, rX);
         __syncthreads();
         tile_sub_acc(X, accX, lane, wr, wc);
         __syncthreads();
         tile_s2g(X, A, ld, i0, k0);
         return;
     }
-    if (a == 0) {
-        tile_g2s(S, A, ld, j0, j0);
-        __syncthreads();
-        tile_sub_acc(S, accX, lane, wr, wc);
-    } else {
-        tile_g2s(S, A, ld, j0, j0);
-        tile_g2s(X, A, ld, i0, j0);
-        __syncthreads();
+    tile_r2s(S, rS);
+    if (a != 0) tile_r2s(X, rX);
+    __syncthreads();
+    if (a == 0) tile_sub_acc(S, accX, lane, wr, wc);
+    else {
         tile_sub_acc(S, accD, lane, wr, wc);
         tile_sub_acc(X, accX, lane, wr, wc);
     }
@@ -899,27 +954,39 @@ constexpr int PS32 = 48;        // LDS panel row stride for 32-wide panels: 2 * 
 
 // panel[k][i] = G[(row0 + i) + (col0 + k) * ld], i < 32, k < 64
 __device__ __forceinline__ void load_panel32_n(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0, int tid) {
-    for (int t = tid; t < 64 * 8; t += 256) {
-        int k = t >> 3, rq = t & 7;
+    double2 v0[2], v1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int t = tid + 256 * u, k = t >> 3, rq = t & 7;
         const double* src = G + (size_t)(col0 + k) * ld + row0 + rq * 4;
-        double2 v0 = *reinterpret_cast<const double2*>(src);
-        double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+        v0[u] = *reinterpret_cast<const double2*>(src);
+        v1[u] = *reinterpret_cast<const double2*>(src + 2);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int t = tid + 256 * u, k = t >> 3, rq = t & 7;
         double* dst = panel + k * PS32 + rq * 4;
-        dst[0] = v0.x; dst[1] = v0.y; dst[2] = v1.x; dst[3] = v1.y;
+        dst[0] = v0[u].x; dst[1] = v0[u].y; dst[2] = v1[u].x; dst[3] = v1[u].y;
     }
 }
 // panel[k][i] = G[(row0 + k) + (col0 + i) * ld], i < 32, k < 64  (transposing load: lanes walk the 32 columns so that
 // the four LDS rows written by one instruction land on different banks)
 __device__ __forceinline__ void load_panel32_t(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0, int tid) {
-    for (int t = tid; t < 32 * 16; t += 256) {
-        int i = t & 31, g = t >> 5;
+    double2 v0[2], v1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int t = tid + 256 * u, i = t & 31, g = t >> 5;
         const double* src = G + (size_t)(col0 + i) * ld + row0 + g * 4;
-        double2 v0 = *reinterpret_cast<const double2*>(src);
-        double2 v1 = *reinterpret_cast<const double2*>(src + 2);
-        panel[(g * 4 + 0) * PS32 + i] = v0.x;
-        panel[(g * 4 + 1) * PS32 + i] = v0.y;
-        panel[(g * 4 + 2) * PS32 + i] = v1.x;
-        panel[(g * 4 + 3) * PS32 + i] = v1.y;
+        v0[u] = *reinterpret_cast<const double2*>(src);
+        v1[u] = *reinterpret_cast<const double2*>(src + 2);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int t = tid + 256 * u, i = t & 31, g = t >> 5;
+        panel[(g * 4 + 0) * PS32 + i] = v0[u].x;
+        panel[(g * 4 + 1) * PS32 + i] = v0[u].y;
+        panel[(g * 4 + 2) * PS32 + i] = v1[u].x;
+        panel[(g * 4 + 3) * PS32 + i] = v1[u].y;
     }
 }
 
