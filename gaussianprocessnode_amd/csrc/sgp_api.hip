@@ -495,7 +495,8 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_form_R, dim3(TQ, TQ), dim3(256), 0, s, h->dSigma, h->dMu, h->dR, Q, Qp, (const double*)h->dWl,
                        h->dTmp);
     // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69)
-    hipLaunchKernelGGL(k_cholupdate, dim3(1), dim3(512), 0, s, h->dTmp, h->dMu, h->dUvT, Qp);
+    hipLaunchKernelGGL(k_uv_p, dim3((Qp + 3) / 4), dim3(256), 0, s, h->dLam, h->dMu, h->dXi, Qp);   // dXi is free again: p
+    hipLaunchKernelGGL(k_uv_cols, dim3(Qp / 64), dim3(64), 0, s, h->dTmp, h->dXi, h->dUvT, Qp);
 }
 
 static void enqueue_finish2(sgp_handle* h, hipStream_t s) {

@@ -1076,101 +1076,79 @@ __global__ void __launch_bounds__(256) k_form_R(const double* __restrict__ Sigma
 }
 
 // ------------------------------------------------------------------------------------------------
-// Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69) as a rank-1 UPDATE of V = chol(Sigma_v).U.
-//   Vt holds W'^T column-major, W' = L'^-1 the inverse factor of the index-reversed Lambda, so that
-//   V[k][j] = W'[Qp-1-k][Qp-1-j] = Vt[(Qp-1-j) + (Qp-1-k) * Qp]   (a row of V is contiguous, descending).
-//   Row k of the update (a Givens rotation):  r = sqrt(V_kk^2 + x_k^2), c = V_kk / r, s = x_k / r;
-//   U_kj = c V_kj + s x_j;  x_j <- c x_j - s V_kj.
-//   Output LR = Uv^T (lower, column-major: column k = row k of Uv), the layout potrf(R) would have produced.
-// One workgroup of 8 waves, 64 pivots per iteration:
-//   wave 0    : the 64 x 64 diagonal block sequentially, entirely in registers (v_readlane broadcasts, no barrier),
-//               publishing per pivot the rotation c = V_kk/r, s = x_k/r;
-//               after the barrier it applies them to the next block's 64 columns (which it needs next);
-//   wave 1    : applies the PREVIOUS block's rotations to the block after the next one;
-//   waves 2-7 : apply the previous block's rotations to all later columns.
-// Every column thus receives the rotations in pivot order with one barrier per 64 pivots.
+// Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69) WITHOUT a third factorisation and without a sequential
+// rank-1 update.  Lambda was factored in index-reversed order, P Lambda P = L' L'^T, so with W' = L'^-1
+//     V = P W' P  is upper triangular with V^T V = Sigma_v   (V = chol(Sigma_v).U),   and   V^-1 = P L' P.
+// Write R = Sigma_v + mu mu^T = V^T (I + p p^T) V with p = V^-T mu.  The Cholesky factor of identity-plus-rank-one is
+// known in closed form: with alpha_0 = 1, alpha_{k+1} = alpha_k + p_k^2,
+//     C_kk = sqrt(alpha_{k+1} / alpha_k),   C_kj = p_k p_j / sqrt(alpha_k alpha_{k+1})  (j > k),   C^T C = I + p p^T,
+// hence  Uv = C V,   Uv[k][j] = C_kk V[k][j] + (p_k / sqrt(alpha_k alpha_{k+1})) * sum_{m=k+1..j} p_m V[m][j].
+// Everything is parallel over the columns j; the sum is a running suffix sum down each column (no cancellation:
+// it is accumulated directly, not as x_j minus a prefix).
+//   k_uv_p    : p_i = sum_{j<=i} L'[r(j)][r(i)] mu_j,  r(i) = Qp-1-i   (column r(i) of L' is contiguous)
+//   k_uv_cols : alpha scan (every block, in LDS), then one thread per column.
+// Vt holds W'^T column-major (written by k_form_R), so that V[k][j] = Vt[(Qp-1-j) + (Qp-1-k) * Qp] is coalesced over j.
+// Output LR = Uv^T (lower, column-major: column k = row k of Uv), the layout potrf(R) would have produced.
 // ------------------------------------------------------------------------------------------------
 constexpr int CU_MAXQ = 4096;
 
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
+__global__ void __launch_bounds__(256) k_uv_p(const double* __restrict__ Lrev, const double* __restrict__ mu,
+                                              double* __restrict__ p, int Qp) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= Qp) return;
+    const int ri = Qp - 1 - i;
+    const double* col = Lrev + (size_t)ri * Qp;          // L'[a][ri], a >= ri
+    double s = 0.0;
+    for (int a = ri + lane; a < Qp; a += 64) s = fma(col[a], mu[Qp - 1 - a], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) p[i] = s;
 }
 
-// apply the 64 Givens rotations `cs` (c, s per pivot) of pivot block bb to column j:  u = c v + s x,  x <- c x - s v
-__device__ __forceinline__ void cholupdate_column(const double* __restrict__ Vt, double* __restrict__ LR, double* xs,
-                                                  const double* cs, int Qp, int bb, int j) {
-    double x = xs[j];
-    const double* vp = Vt + (size_t)(Qp - 1 - 64 * bb) * Qp + (Qp - 1 - j);       // V[64 bb + kk][j] = vp[-kk * Qp]
-    double* up = LR + (size_t)(64 * bb) * Qp + j;
-#pragma unroll 1
-    for (int k0 = 0; k0 < 64; k0 += 16) {
-        double v[16];
+__global__ void __launch_bounds__(64) k_uv_cols(const double* __restrict__ Vt, const double* __restrict__ p,
+                                                double* __restrict__ LR, int Qp) {
+    __shared__ double ps[CU_MAXQ];      // p_k
+    __shared__ double ck[CU_MAXQ];      // C_kk
+    __shared__ double ak[CU_MAXQ];      // p_k / sqrt(alpha_k alpha_{k+1})
+    const int lane = threadIdx.x;
+    // alpha scan by one wave: each lane owns a contiguous chunk
+    const int per = (Qp + 63) / 64;
+    double loc = 0.0;
+    for (int e = lane * per; e < min((lane + 1) * per, Qp); ++e) { double v = p[e]; ps[e] = v; loc = fma(v, v, loc); }
+    double inc = loc;                                    // inclusive scan of the chunk sums
+    for (int o = 1; o < 64; o <<= 1) {
+        double t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    double alpha = 1.0 + (inc - loc);                    // alpha at the start of this lane's chunk
+    for (int e = lane * per; e < min((lane + 1) * per, Qp); ++e) {
+        const double pe = ps[e], an = fma(pe, pe, alpha);
+        const double ir = 1.0 / sqrt(alpha * an);
+        ck[e] = an * ir;                                 // sqrt(an / alpha)
+        ak[e] = pe * ir;
+        alpha = an;
+    }
+    __syncthreads();
+    const int j = blockIdx.x * 64 + lane;
+    if (j >= Qp) return;
+    const double* vp = Vt + (size_t)(Qp - 1) * Qp + (Qp - 1 - j);     // V[k][j] = vp[-k * Qp]
+    double T = 0.0;
+    int k = j;
+    // rows k = j, j-1, ..., 0 (8 loads in flight)
+    for (; k >= 7; k -= 8) {
+        double v[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = vp[-(ptrdiff_t)(k0 + u) * Qp];
+        for (int u = 0; u < 8; ++u) v[u] = vp[-(ptrdiff_t)(k - u) * Qp];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const double2 c = *reinterpret_cast<const double2*>(cs + 2 * (k0 + u));
-            up[(size_t)(k0 + u) * Qp] = fma(c.x, v[u], c.y * x);
-            x = fma(c.x, x, -c.y * v[u]);
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k - u;
+            LR[(size_t)kk * Qp + j] = fma(ck[kk], v[u], ak[kk] * T);
+            T = fma(ps[kk], v[u], T);
         }
     }
-    xs[j] = x;
-}
-
-__global__ void __launch_bounds__(512) k_cholupdate(const double* __restrict__ Vt, const double* __restrict__ mu,
-                                                    double* __restrict__ LR, int Qp) {
-    __shared__ double xs[CU_MAXQ];
-    __shared__ __attribute__((aligned(16))) double cs[2][64 * 2];
-    __shared__ double Vb[64 * 64];                       // diagonal block of V, Vb[kk][j] (wave 0 only)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nb = Qp / 64;
-    for (int e = tid; e < Qp; e += 512) xs[e] = mu[e];
-    __syncthreads();
-#pragma unroll 1
-    for (int i = 0; i < nb; ++i) {
-        if (wave == 0) {
-            // ---- diagonal block i: 64 sequential pivots.  Per pivot: r = sqrt(v_kk^2 + x_k^2), c = v_kk / r, s = x_k / r;
-            // row k of Uv is c V_k + s x, and x <- c x - s V_k.  The chain through x_k is readlane -> fma -> rsqrt -> fma.
-            const int base = 64 * i, j = base + lane;
-            const double* vp = Vt + (size_t)(Qp - 1 - base) * Qp + (Qp - 1 - j);
-#pragma unroll 16
-            for (int kk = 0; kk < 64; ++kk) Vb[kk * 64 + lane] = vp[-(ptrdiff_t)kk * Qp];   // V[base + kk][j]; zero below the diagonal
-            __builtin_amdgcn_wave_barrier();
-            double xa = xs[j];
-            const double dg = Vb[lane * 64 + lane];                                         // this lane's diagonal entry
-            double* csw = cs[i & 1];
-            double vcur = Vb[lane];
-#pragma unroll 4
-            for (int kk = 0; kk < 64; ++kk) {
-                const double vnext = Vb[((kk + 1) & 63) * 64 + lane];                       // prefetch the next row
-                const double vkk = readlane_f64(dg, kk);
-                const double xk = readlane_f64(xa, kk);
-                const double t = fma(xk, xk, vkk * vkk);
-                const double ir = rsqrt_nr(t);
-                const double c = vkk * ir, sn = xk * ir;
-                const double uu = fma(c, vcur, sn * xa);
-                xa = fma(c, xa, -sn * vcur);
-                LR[(size_t)(base + kk) * Qp + j] = (lane >= kk) ? uu : 0.0;
-                if (lane == 0) *reinterpret_cast<double2*>(csw + 2 * kk) = make_double2(c, sn);
-                vcur = vnext;
-            }
-        } else if (i > 0) {
-            // ---- rotations of block i-1 on later columns
-            const double* csr = cs[(i - 1) & 1];
-            if (wave == 1) {
-                const int j = 64 * (i + 1) + lane;
-                if (j < Qp) cholupdate_column(Vt, LR, xs, csr, Qp, i - 1, j);
-            } else {
-                for (int j = 64 * (i + 2) + (tid - 128); j < Qp; j += 384) cholupdate_column(Vt, LR, xs, csr, Qp, i - 1, j);
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            const int j = 64 * (i + 1) + lane;
-            if (j < Qp) cholupdate_column(Vt, LR, xs, cs[i & 1], Qp, i, j);
-        }
+    for (; k >= 0; --k) {
+        const double v = vp[-(ptrdiff_t)k * Qp];
+        LR[(size_t)k * Qp + j] = fma(ck[k], v, ak[k] * T);
+        T = fma(ps[k], v, T);
     }
 }
 
