@@ -54,7 +54,7 @@ struct sgp_handle {
     double *dKuu = nullptr, *dWk = nullptr, *dKinv = nullptr;
     double *dLam = nullptr, *dWl = nullptr, *dSigma = nullptr, *dR = nullptr, *dXi = nullptr, *dMu = nullptr;
     double *dLambda0 = nullptr, *dXi0 = nullptr, *dOut = nullptr, *dWishart = nullptr, *dTrace = nullptr, *dTmp = nullptr;
-    double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr, *dOut2 = nullptr;
+    double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr, *dOut2 = nullptr, *dUvWork = nullptr;
     int* dInfo = nullptr;
     int64_t* dStamps = nullptr;
     int64_t* dStampTotals = nullptr;
@@ -198,6 +198,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dUvT, Qp * Qp);
     ALLOC(h->dScratch, 3 * TB * TB);
     ALLOC(h->dOut2, SGP_R_COUNT);
+    ALLOC(h->dUvWork, (2 + (size_t)h->TQ) * Qp);
     ALLOC(h->dLambda0, Qp * Qp);
     ALLOC(h->dXi, Qp);
     ALLOC(h->dMu, Qp);
@@ -256,7 +257,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
     void* bufs[] = {h->dXu, h->dXus, h->dX, h->dYw, h->dY, h->dYv, h->dOmega, h->dKuf, h->dBpart, h->dSlabs, h->dStatsOwn,
                     h->dDataScal, h->dKuu, h->dWk, h->dKinv, h->dLam, h->dWl, h->dSigma, h->dR, h->dTmp, h->dLambda0,
                     h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
-                    h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals};
+                    h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals, h->dUvWork};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evFork) hipEventDestroy(h->evFork);
@@ -485,7 +486,6 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     hipMemsetAsync(h->dInfo + 1, 0, sizeof(int), s);
     // Lambda is factored in index-reversed order (P Lambda P = L' L'^T): its inverse factor W' = L'^-1 then IS the upper
     // Cholesky factor of Sigma_v up to the reversal, and Uv follows by a rank-1 update instead of a third potrf.
-    hipMemsetAsync(h->dUvT, 0, sizeof(double) * Qp * Qp, s);
     hipLaunchKernelGGL(k_form_lambda, dim3(TQ, TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dLam, h->dXi,
                        h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form, 1);
     launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s);
@@ -495,8 +495,14 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_form_R, dim3(TQ, TQ), dim3(256), 0, s, h->dSigma, h->dMu, h->dR, Q, Qp, (const double*)h->dWl,
                        h->dTmp);
     // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69)
-    hipLaunchKernelGGL(k_uv_p, dim3((Qp + 3) / 4), dim3(256), 0, s, h->dLam, h->dMu, h->dXi, Qp);   // dXi is free again: p
-    hipLaunchKernelGGL(k_uv_cols, dim3(Qp / 64), dim3(64), 0, s, h->dTmp, h->dXi, h->dUvT, Qp);
+    double* uvp = h->dXi;                    // xi is consumed: p
+    double* uvck = h->dUvWork;               // C_kk
+    double* uvak = h->dUvWork + Qp;          // p_k / sqrt(alpha_k alpha_{k+1})
+    double* uvpart = h->dUvWork + 2 * (size_t)Qp;   // TQ x Qp tile partial sums
+    hipLaunchKernelGGL(k_uv_p, dim3((Qp + 3) / 4), dim3(256), 0, s, h->dLam, h->dMu, uvp, Qp);
+    hipLaunchKernelGGL(k_uv_scan, dim3(1), dim3(64), 0, s, uvp, uvck, uvak, Qp);
+    hipLaunchKernelGGL(k_uv_partial, dim3(TQ * (TQ + 1) / 2), dim3(64), 0, s, h->dTmp, uvp, uvpart, Qp);
+    hipLaunchKernelGGL(k_uv_cols, dim3(TQ, TQ), dim3(64), 0, s, h->dTmp, uvp, uvck, uvak, uvpart, h->dUvT, Qp);
 }
 
 static void enqueue_finish2(sgp_handle* h, hipStream_t s) {

@@ -1085,8 +1085,10 @@ __global__ void __launch_bounds__(256) k_form_R(const double* __restrict__ Sigma
 // hence  Uv = C V,   Uv[k][j] = C_kk V[k][j] + (p_k / sqrt(alpha_k alpha_{k+1})) * sum_{m=k+1..j} p_m V[m][j].
 // Everything is parallel over the columns j; the sum is a running suffix sum down each column (no cancellation:
 // it is accumulated directly, not as x_j minus a prefix).
-//   k_uv_p    : p_i = sum_{j<=i} L'[r(j)][r(i)] mu_j,  r(i) = Qp-1-i   (column r(i) of L' is contiguous)
-//   k_uv_cols : alpha scan (every block, in LDS), then one thread per column.
+//   k_uv_p       : p_i = sum_{j<=i} L'[r(j)][r(i)] mu_j,  r(i) = Qp-1-i   (column r(i) of L' is contiguous)
+//   k_uv_scan    : alpha scan -> C_kk and p_k / sqrt(alpha_k alpha_{k+1})
+//   k_uv_partial : per 64-row tile and column, sum_m p_m V[m][j]   (so that tiles can start their suffix sums independently)
+//   k_uv_cols    : one wave per 64 x 64 tile, 64 rows in registers, writes the rows of Uv
 // Vt holds W'^T column-major (written by k_form_R), so that V[k][j] = Vt[(Qp-1-j) + (Qp-1-k) * Qp] is coalesced over j.
 // Output LR = Uv^T (lower, column-major: column k = row k of Uv), the layout potrf(R) would have produced.
 // ------------------------------------------------------------------------------------------------
@@ -1104,51 +1106,67 @@ __global__ void __launch_bounds__(256) k_uv_p(const double* __restrict__ Lrev, c
     if (lane == 0) p[i] = s;
 }
 
-__global__ void __launch_bounds__(64) k_uv_cols(const double* __restrict__ Vt, const double* __restrict__ p,
-                                                double* __restrict__ LR, int Qp) {
-    __shared__ double ps[CU_MAXQ];      // p_k
-    __shared__ double ck[CU_MAXQ];      // C_kk
-    __shared__ double ak[CU_MAXQ];      // p_k / sqrt(alpha_k alpha_{k+1})
+// alpha scan (one wave): ck[k] = C_kk, ak[k] = p_k / sqrt(alpha_k alpha_{k+1})
+__global__ void __launch_bounds__(64) k_uv_scan(const double* __restrict__ p, double* __restrict__ ck, double* __restrict__ ak, int Qp) {
     const int lane = threadIdx.x;
-    // alpha scan by one wave: each lane owns a contiguous chunk
     const int per = (Qp + 63) / 64;
+    const int e0 = lane * per, e1 = min((lane + 1) * per, Qp);
     double loc = 0.0;
-    for (int e = lane * per; e < min((lane + 1) * per, Qp); ++e) { double v = p[e]; ps[e] = v; loc = fma(v, v, loc); }
-    double inc = loc;                                    // inclusive scan of the chunk sums
+    for (int e = e0; e < e1; ++e) { double v = p[e]; loc = fma(v, v, loc); }
+    double inc = loc;
     for (int o = 1; o < 64; o <<= 1) {
         double t = __shfl_up(inc, o);
         if (lane >= o) inc += t;
     }
-    double alpha = 1.0 + (inc - loc);                    // alpha at the start of this lane's chunk
-    for (int e = lane * per; e < min((lane + 1) * per, Qp); ++e) {
-        const double pe = ps[e], an = fma(pe, pe, alpha);
+    double alpha = 1.0 + (inc - loc);
+    for (int e = e0; e < e1; ++e) {
+        const double pe = p[e], an = fma(pe, pe, alpha);
         const double ir = 1.0 / sqrt(alpha * an);
-        ck[e] = an * ir;                                 // sqrt(an / alpha)
+        ck[e] = an * ir;
         ak[e] = pe * ir;
         alpha = an;
     }
-    __syncthreads();
-    const int j = blockIdx.x * 64 + lane;
-    if (j >= Qp) return;
-    const double* vp = Vt + (size_t)(Qp - 1) * Qp + (Qp - 1 - j);     // V[k][j] = vp[-k * Qp]
-    double T = 0.0;
-    int k = j;
-    // rows k = j, j-1, ..., 0 (8 loads in flight)
-    for (; k >= 7; k -= 8) {
-        double v[8];
+}
+
+// pass 1, one wave per 64 x 64 tile (kb <= jb) of V: partial[kb][j] = sum_{kk} p_{64 kb + kk} V[64 kb + kk][j]
+__global__ void __launch_bounds__(64) k_uv_partial(const double* __restrict__ Vt, const double* __restrict__ p,
+                                                   double* __restrict__ partial, int Qp) {
+    int jb, kb;
+    tile_from_index(blockIdx.x, jb, kb);                 // jb >= kb
+    const int lane = threadIdx.x, j = 64 * jb + lane;
+    const double* vp = Vt + (size_t)(Qp - 1 - 64 * kb) * Qp + (Qp - 1 - j);
+    double v[64];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = vp[-(ptrdiff_t)(k - u) * Qp];
+    for (int kk = 0; kk < 64; ++kk) v[kk] = vp[-(ptrdiff_t)kk * Qp];
+    double s = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int kk = k - u;
-            LR[(size_t)kk * Qp + j] = fma(ck[kk], v[u], ak[kk] * T);
-            T = fma(ps[kk], v[u], T);
-        }
+    for (int kk = 0; kk < 64; ++kk) s = fma(p[64 * kb + kk], v[kk], s);
+    partial[(size_t)kb * Qp + j] = s;
+}
+
+// pass 2, one wave per tile of the FULL tile grid: rows of tile (kb, jb) of Uv written into LR = Uv^T (zeros for kb > jb)
+__global__ void __launch_bounds__(64) k_uv_cols(const double* __restrict__ Vt, const double* __restrict__ p,
+                                                const double* __restrict__ ck, const double* __restrict__ ak,
+                                                const double* __restrict__ partial, double* __restrict__ LR, int Qp) {
+    const int kb = blockIdx.x, jb = blockIdx.y;
+    const int lane = threadIdx.x, j = 64 * jb + lane;
+    double* out = LR + (size_t)(64 * kb) * Qp + j;
+    if (kb > jb) {
+#pragma unroll 16
+        for (int kk = 0; kk < 64; ++kk) out[(size_t)kk * Qp] = 0.0;
+        return;
     }
-    for (; k >= 0; --k) {
-        const double v = vp[-(ptrdiff_t)k * Qp];
-        LR[(size_t)k * Qp + j] = fma(ck[k], v, ak[k] * T);
-        T = fma(ps[k], v, T);
+    const double* vp = Vt + (size_t)(Qp - 1 - 64 * kb) * Qp + (Qp - 1 - j);
+    double v[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) v[kk] = vp[-(ptrdiff_t)kk * Qp];
+    double T = 0.0;
+    for (int b = jb; b > kb; --b) T += partial[(size_t)b * Qp + j];       // rows below this tile, nearest first... fixed order
+#pragma unroll
+    for (int kk = 63; kk >= 0; --kk) {
+        const int k = 64 * kb + kk;
+        out[(size_t)kk * Qp] = fma(ck[k], v[kk], ak[k] * T);
+        T = fma(p[k], v[kk], T);
     }
 }
 
