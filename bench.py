@@ -122,7 +122,7 @@ def main():
     #     kernel alone on the chip: in the sweep it shares the chip with the K_uu chain on the side stream).
     phase_us, n_counted = dev.phase_totals()
     tick_us = lambda i: float(phase_us[i])
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = eng.stream.cuda_stream
     syrk_us_alone = dev.time_kernel(_lib.SGP_T_SYRK, 10, stream)
     gram_us_alone = dev.time_kernel(_lib.SGP_T_GRAM, 10, stream)
     syrk_us = tick_us(_lib.SGP_T_SYRK)

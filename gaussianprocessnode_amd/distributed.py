@@ -83,15 +83,19 @@ class HipEngine:
         self.dev = SGPDevice(n_max, m, d, d_out, device=device, use_graph=use_graph)
         self.stats = torch.zeros(stats_count(m, d_out), dtype=torch.float64, device=f"cuda:{device}")
         self.dev.bind_stats(self.stats.data_ptr())
+        # One explicit (non-default) torch stream carries the sweep AND the collective: the C ABI treats a NULL stream as
+        # "the library's own stream", which would not be ordered against torch's default stream or RCCL's.
+        self.stream = torch.cuda.Stream(device=device)
+        torch.cuda.synchronize(device)
 
-    def _stream(self) -> int:
-        return self.torch.cuda.current_stream().cuda_stream
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
 
     def sweep_local(self):
-        self.dev.sweep_local(self._stream())
+        self.dev.sweep_local(self.stream.cuda_stream)
 
     def sweep_finish(self):
-        self.dev.sweep_finish(self._stream())
+        self.dev.sweep_finish(self.stream.cuda_stream)
 
     def synchronize(self):
         self.torch.cuda.synchronize()
@@ -110,7 +114,16 @@ class ShardedSweep:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
     def sweep(self):
-        self.engine.sweep_local()
-        if self.world > 1:
-            self.dist.all_reduce(self.engine.stats, op=self.dist.ReduceOp.SUM, group=self.group)
-        self.engine.sweep_finish()
+        ctx = self.engine.stream_context() if hasattr(self.engine, "stream_context") else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            self.engine.sweep_local()
+            if self.world > 1:
+                # issued inside the engine's stream context: the collective is ordered after the local kernels and before
+                # the replicated tail on that stream
+                self.dist.all_reduce(self.engine.stats, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.engine.sweep_finish()
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)

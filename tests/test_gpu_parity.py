@@ -228,14 +228,16 @@ def test_two_phase_with_bound_statistics_buffer(G):
         devs.append(d)
     _, count, _ = devs[0].stats_layout()
     bufs = [torch.zeros(count, dtype=torch.float64, device="cuda") for _ in devs]
-    stream = torch.cuda.current_stream().cuda_stream
-    for d, b in zip(devs, bufs):
-        d.bind_stats(b.data_ptr())
-        d.sweep_local(stream)
-    total = bufs[0] + bufs[1]
-    for d, b in zip(devs, bufs):
-        b.copy_(total)
-        d.sweep_finish(stream)
+    tstream = torch.cuda.Stream()                 # an explicit stream: a NULL stream means "the library's own" to the ABI
+    torch.cuda.synchronize()
+    with torch.cuda.stream(tstream):
+        for d, b in zip(devs, bufs):
+            d.bind_stats(b.data_ptr())
+            d.sweep_local(tstream.cuda_stream)
+        total = bufs[0] + bufs[1]                 # stands in for the all-reduce, ordered on the same stream
+        for d, b in zip(devs, bufs):
+            b.copy_(total)
+            d.sweep_finish(tstream.cuda_stream)
     torch.cuda.synchronize()
     for d in devs:
         mu, Sig, _ = d.posterior(want_uv=False)

@@ -3,10 +3,10 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# find last k_stamp_reset (start of a sweep)
-idx = [i for i, r in enumerate(rows) if "k_stamp_reset" in r["Kernel_Name"]]
-start = idx[-2] if len(idx) > 1 else idx[-1]
-end = idx[-1] if len(idx) > 1 else len(rows)
+# sweeps are delimited by k_stamp_accumulate (the last kernel of a sweep)
+idx = [i for i, r in enumerate(rows) if "k_stamp_accumulate" in r["Kernel_Name"]]
+start = idx[-3] + 1 if len(idx) > 2 else 0
+end = idx[-2] + 1 if len(idx) > 2 else len(rows)
 t0 = int(rows[start]["Start_Timestamp"])
 for r in rows[start:end]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
