@@ -99,17 +99,19 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // ------------------------------------------------------------------------------------------------
 // dense building blocks (launch sequences)
 // ------------------------------------------------------------------------------------------------
-static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, double* scratch, hipStream_t s) {
+// Winv (may be nullptr): receives the inverses of the diagonal tiles of L, computed by the idle diagonal block of each step
+static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, double* scratch, hipStream_t s,
+                         double* Winv = nullptr) {
     for (int j = 0; j < Tn; ++j) {
         int nt = Tn - j;
-        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, A, ld, j, Tn, info, n_valid, scratch);
+        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, A, ld, j, Tn, info, n_valid, scratch, Winv);
     }
 }
 // W = L^-1 by recursive doubling: diagonal tiles first, then for block sizes s = 1, 2, 4, ... tiles
 //   W21 = -W22 (L21 W11)   for every pair of adjacent diagonal blocks -- two tile-GEMM launches per level,
 // log2(Tn) levels instead of a Tn-long chain of dependent block rows.  `scratch` (ld x ld) holds L21 W11.
-static void launch_trtri(const double* L, double* W, double* scratch, int ld, int Tn, hipStream_t s) {
-    hipLaunchKernelGGL(k_trtri_diag, dim3(Tn), dim3(256), 0, s, L, W, ld);
+static void launch_trtri(const double* L, double* W, double* scratch, int ld, int Tn, hipStream_t s, bool diag_done = false) {
+    if (!diag_done) hipLaunchKernelGGL(k_trtri_diag, dim3(Tn), dim3(256), 0, s, L, W, ld);
     for (int sz = 1; sz < Tn; sz *= 2) {
         int npairs = (Tn + 2 * sz - 1) / (2 * sz);
         hipLaunchKernelGGL(k_gemm32, dim3(sz * sz * 4, npairs), dim3(256), 0, s, L, (const double*)W, scratch, ld, Tn, 1, sz, 0);
@@ -459,8 +461,8 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->dParamsK, M, Mp, D,
                        (int64_t*)nullptr, 0, 0);
     hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
-    launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s);
-    launch_trtri(h->dKuu, h->dWk, h->dKinv, Mp, T, s);
+    launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk);
+    launch_trtri(h->dKuu, h->dWk, h->dKinv, Mp, T, s, true);
     launch_ata(h->dWk, h->dKinv, Mp, T, s);
 }
 
@@ -488,8 +490,8 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     // Cholesky factor of Sigma_v up to the reversal, and Uv follows by a rank-1 update instead of a third potrf.
     hipLaunchKernelGGL(k_form_lambda, dim3(TQ, TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dLam, h->dXi,
                        h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form, 1);
-    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s);
-    launch_trtri(h->dLam, h->dWl, h->dSigma, Qp, TQ, s);
+    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl);
+    launch_trtri(h->dLam, h->dWl, h->dSigma, Qp, TQ, s, true);
     launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1);
     hipLaunchKernelGGL(k_symv, dim3((Qp + 3) / 4), dim3(256), 0, s, h->dSigma, h->dXi, h->dMu, Qp, Qp);
     hipLaunchKernelGGL(k_form_R, dim3(TQ, TQ), dim3(256), 0, s, h->dSigma, h->dMu, h->dR, Q, Qp, (const double*)h->dWl,

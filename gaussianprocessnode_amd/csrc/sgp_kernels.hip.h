@@ -679,6 +679,80 @@ __device__ __forceinline__ void trsm_tile(double* X, const double* S, const doub
     });
 }
 
+// Invert the 64 x 64 lower-triangular tile S (LDS, S[r][c], stride LT; rinv[c] = 1 / L_cc) into Wt (LDS, same layout,
+// strict upper part zero).  Recursive doubling at 16-column granularity, like the matrix-level launch_trtri:
+//   (1) wave w inverts its own diagonal 16 x 16 block (4 lanes per row, right-to-left pivots, in registers, wave-local);
+//   (2) 16-blocks:  W21 = -W22 (L21 W11) for the pairs (0,1) and (2,3)      -- waves 1 and 3, two MFMA products each;
+//   (3) 32-blocks:  W21 = -W22 (L21 W11), a 2 x 2 grid of 16 x 16 MFMA tiles -- one per wave, K = 32.
+// T (>= 32 * 33 doubles of LDS) holds the intermediate L21 W11.
+__device__ __forceinline__ void trtri_tile(const double* S, const double* rinv, double* Wt, double* T) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int rr = lane >> 2, q = lane & 3;
+    for (int e = tid; e < TB * LT; e += 256) Wt[e] = 0.0;
+    __syncthreads();
+    {   // (1) diagonal 16 x 16 blocks
+        const int b0 = 16 * wave;
+        double w[4], wo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { w[i] = (4 * i + q == rr) ? 1.0 : 0.0; wo[i] = 0.0; }
+        static_for<16>([&](auto kc) {
+            constexpr int k = 15 - decltype(kc)::value;
+            constexpr int kq = k & 3, ki = k >> 2;
+            const double v = quad_bcast<kq>(w[ki]) * rinv[b0 + k];               // W_rk (zero for k > r)
+            if (q == kq) wo[ki] = v;
+#pragma unroll
+            for (int i = 0; i <= ki; ++i) {
+                const int c = 4 * i + q;
+                double t = (c < k) ? S[(b0 + k) * LT + b0 + c] : 0.0;            // L_kc
+                w[i] = fma(-v, t, w[i]);
+            }
+        });
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Wt[(b0 + rr) * LT + b0 + 4 * i + q] = wo[i];
+    }
+    __syncthreads();
+    if (wave & 1) {   // (2) pairs of 16-blocks: rows of block `wave`, columns of block `wave - 1`
+        const int rb = 16 * wave, cb = 16 * (wave - 1);
+        double* Tw = T + (wave >> 1) * (16 * 17);
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)                                           // T = L21 W11
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(rb + li) * LT + cb + 4 * s4 + lk],
+                                                       Wt[(cb + 4 * s4 + lk) * LT + cb + li], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tw[(lk + 4 * r) * 17 + li] = acc[r];
+        __builtin_amdgcn_wave_barrier();
+        acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)                                           // W21 = -W22 T
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[(rb + li) * LT + rb + 4 * s4 + lk], Tw[(4 * s4 + lk) * 17 + li],
+                                                       acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Wt[(rb + lk + 4 * r) * LT + cb + li] = -acc[r];
+    }
+    __syncthreads();
+    {   // (3) the 32-blocks: tile (ti, tj) of W21, rows 32 + 16 ti, columns 16 tj
+        const int ti = wave >> 1, tj = wave & 1;
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4)                                           // T = L21 W11, K = 32
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(32 + 16 * ti + li) * LT + 4 * s4 + lk],
+                                                       Wt[(4 * s4 + lk) * LT + 16 * tj + li], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(16 * ti + lk + 4 * r) * 33 + 16 * tj + li] = acc[r];
+        __syncthreads();
+        acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4)                                           // W21 = -W22 T
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[(32 + 16 * ti + li) * LT + 32 + 4 * s4 + lk],
+                                                       T[(4 * s4 + lk) * 33 + 16 * tj + li], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Wt[(32 + 16 * ti + lk + 4 * r) * LT + 16 * tj + li] = -acc[r];
+    }
+    __syncthreads();
+}
+
 // coalesced copies between a column-major global tile and an LDS tile S[r][c]
 struct TileRegs { double v[16]; };
 __device__ __forceinline__ void tile_g2r(TileRegs& t, const double* __restrict__ A, size_t ld, int row0, int col0) {
@@ -719,8 +793,10 @@ __device__ __forceinline__ void tile_sub_acc(double* S, const Acc4& acc, int lan
 // Hazard handled here: every block of the panel column reads the UNFACTORED diagonal tile A_jj from global memory, so
 // the diagonal block must not overwrite it in place during the same launch.  It parks L_jj in `scratch` (one tile) and
 // the next step's block (0, 0) moves it into place (kernel boundary = all readers done).  The last step has no readers.
+// While the panel blocks solve their tiles, the otherwise idle diagonal block also inverts L_jj (Winv != nullptr): the
+// diagonal tiles of L^-1 that the recursive triangular inverse starts from, without a launch of their own.
 __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
-                                                    int n_valid, double* __restrict__ scratch) {
+                                                    int n_valid, double* __restrict__ scratch, double* __restrict__ Winv) {
     // LDS: two MFMA operand panels (2 x 64 x PS) during the update, re-used afterwards as two 64 x 64 tiles
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
     __shared__ double colw[16];
@@ -800,6 +876,10 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
         if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);       // no other block reads A_jj in the last step
         else
             for (int e = tid; e < TB * TB; e += 256) scratch[e] = S[(e & 63) * LT + (e >> 6)];   // column-major tile
+        if (Winv) {
+            trtri_tile(S, rinv, X, lds + 2 * TB * LT);
+            tile_s2g(X, Winv, ld, j0, j0);
+        }
         return;
     }
     trsm_tile(X, S, rinv);
@@ -815,48 +895,15 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
 //       W_ic = - W_ii * sum_{c<=k<i} L_ik W_kc          (two MFMA products per block row)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_trtri_diag(const double* __restrict__ L, double* __restrict__ W, int ld) {
-    // Lq[k][q][16 + i] = L[k][4 i + q]: slots 0..15 of every quarter are a zero dead zone (the window runs downwards)
-    __shared__ __attribute__((aligned(16))) double Lq[TB * PR];
-    __shared__ double Wt[TB * LT];
-    __shared__ double invd[TB];
+    __shared__ double lds[2 * TB * LT + 32 * 33];
+    __shared__ double rinv[TB];
     const int tid = threadIdx.x, j0 = blockIdx.x * TB;
-    for (int e = tid; e < TB * PR; e += 256) Lq[e] = 0.0;
+    tile_g2s(lds, L, ld, j0, j0);
     __syncthreads();
-    for (int e = tid; e < TB * TB; e += 256) {
-        int c = e >> 6, k = e & 63;                      // coalesced along k (rows of the column-major tile)
-        double v = L[(size_t)(j0 + c) * ld + j0 + k];
-        Lq[k * PR + (c & 3) * QS + 16 + (c >> 2)] = (c <= k) ? v : 0.0;
-        if (c == k) invd[k] = 1.0 / v;
-    }
+    if (tid < TB) rinv[tid] = 1.0 / lds[tid * LT + tid];
     __syncthreads();
-    const int r = tid >> 2, q = tid & 3;
-    // right-hand side e_r, eliminated from the last column to the first; w[j] = entry of column 4 (g - j) + q
-    double w[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) w[j] = (4 * (15 - j) + q == r) ? 1.0 : 0.0;
-#pragma unroll 1
-    for (int g = 15; g >= 0; g -= 2) {
-        static_for<8>([&](auto pc) {
-            constexpr int p = decltype(pc)::value;
-            constexpr int kq = 3 - (p & 3), wh = p >> 2;              // pivot k = 4 (g - wh) + kq, held in w[wh]
-            const int k = 4 * (g - wh) + kq;
-            double t[16];                                             // t[u] = L[k][4 (g - 15 + u) + q]
-            load16(t, Lq + k * PR + q * QS + g + 1);
-            const double v = quad_bcast<kq>(w[wh]) * invd[k];         // W_rk (zero for k > r)
-            if (q == kq) Wt[r * LT + k] = v;
-#pragma unroll
-            for (int j = wh; j < 16; ++j) {
-                if (j == wh) w[j] = fma(-v, (q < kq) ? t[15 - j] : 0.0, w[j]);
-                else w[j] = fma(-v, t[15 - j], w[j]);
-            }
-        });
-#pragma unroll
-        for (int j = 0; j < 14; ++j) w[j] = w[j + 2];
-        w[14] = 0.0;
-        w[15] = 0.0;
-    }
-    __syncthreads();
-    tile_s2g(Wt, W, ld, j0, j0);
+    trtri_tile(lds, rinv, lds + TB * LT, lds + 2 * TB * LT);
+    tile_s2g(lds + TB * LT, W, ld, j0, j0);
 }
 
 // One wave computes a 16 x 16 output tile over K = 64: rows wave*16.., operands in LDS panels.
