@@ -472,7 +472,7 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->dParams, M, Mp, D,
                        h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP);
     if (h->n > 0) {
-        hipLaunchKernelGGL(k_gram_uf, dim3(T, h->nblk), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
+        hipLaunchKernelGGL(k_gram_uf, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                            h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + 2 * SGP_T_GRAM);
         hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                            h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, h->ntiles, h->nchunks,
@@ -711,7 +711,7 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
     HIPCHK(h, hipEventCreate(&e1));
     auto launch = [&]() {
         if (which == SGP_T_GRAM)
-            hipLaunchKernelGGL(k_gram_uf, dim3(h->T, h->nblk), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
+            hipLaunchKernelGGL(k_gram_uf, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr);
         else
             hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
@@ -749,8 +749,8 @@ extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) 
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dI2), sizeof(double) * n));
     HIPCHK(h, hipDeviceSynchronize());
     // |L^-1 k_n|^2 with the explicit inverse factor W_k, |Uv k_n|^2 = |L_R^T k_n|^2
-    hipLaunchKernelGGL(k_quadform_cols, dim3(h->T, h->nblk), dim3(256), 0, s, h->dWk, h->dKuf, h->dPa, h->Mp, h->T, n, 0);
-    hipLaunchKernelGGL(k_quadform_cols, dim3(h->T, h->nblk), dim3(256), 0, s, h->dUvT, h->dKuf, h->dPb, h->Mp, h->T, n, 1);
+    hipLaunchKernelGGL(k_quadform_cols, dim3(h->nblk, h->T), dim3(256), 0, s, h->dWk, h->dKuf, h->dPa, h->Mp, h->T, n, 0);
+    hipLaunchKernelGGL(k_quadform_cols, dim3(h->nblk, h->T), dim3(256), 0, s, h->dUvT, h->dKuf, h->dPb, h->Mp, h->T, n, 1);
     hipLaunchKernelGGL(k_w_point_finish, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, h->dPa, h->dPb, h->dKuf, h->dMu,
                        h->dY, h->has_yv ? h->dYv : nullptr, dI1, dI2, h->dParams, h->M, h->Mp, h->T, n);
     HIPCHK(h, hipStreamSynchronize(s));

@@ -132,8 +132,8 @@ __global__ void __launch_bounds__(256) k_gram_uf(const double* __restrict__ Xus,
     __shared__ double xs[MAXD * TB];
     __shared__ double ys[MAXO * TB];
     __shared__ double red[16 * TB];
-    const int I = blockIdx.x * TB;
-    const int64_t n0 = (int64_t)blockIdx.y * TB;
+    const int I = blockIdx.y * TB;                           // m tile on grid.y, point block on grid.x (no 65535 limit)
+    const int64_t n0 = (int64_t)blockIdx.x * TB;
     for (int t = threadIdx.x; t < D * TB; t += 256) {
         int d = t / TB, r = t % TB;
         us[t] = Xus[(size_t)d * Mp + I + r];
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) k_gram_uf(const double* __restrict__ Xus,
             double s = 0.0;
 #pragma unroll
             for (int g = 0; g < 16; ++g) s += red[g * TB + threadIdx.x];
-            bpart[((size_t)blockIdx.y * d_out + o) * Mp + I + threadIdx.x] = s;
+            bpart[((size_t)blockIdx.x * d_out + o) * Mp + I + threadIdx.x] = s;
         }
     }
     stamp_exit(stamps);
@@ -1403,8 +1403,8 @@ __global__ void __launch_bounds__(256) k_quadform_cols(const double* __restrict_
     __shared__ double lds[2 * TB * PS];
     __shared__ double colsum[4][TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    const int I = blockIdx.x;
-    const int64_t n0 = (int64_t)blockIdx.y * TB;
+    const int I = blockIdx.y;
+    const int64_t n0 = (int64_t)blockIdx.x * TB;
     double* As = lds;
     double* Bs = lds + TB * PS;
     Acc4 acc;

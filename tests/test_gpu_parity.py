@@ -429,3 +429,53 @@ def test_theta_objective_and_gradient_at_fixed_posterior(G):
     assert np.array_equal(mu0, mu1)                              # q(v) untouched
     assert math.isclose(val, f(p0), rel_tol=1e-8), (val, f(p0))
     np.testing.assert_allclose(grad, g_ref, rtol=2e-4, atol=1e-4 * np.abs(g_ref).max())
+
+
+def test_full_size_configs_and_size_independent_properties(G):
+    """BASELINE's full sizes: C3 (N = 40 000, M = 512, D = 8) against the oracle, plus properties that hold at any size:
+    statistics are additive over a split and invariant under a permutation of the points; at N = 10^6 (4 GB of K_uf) the
+    sweep still satisfies Uv'Uv = Sigma + mu mu' and Lambda Sigma = I."""
+    N, M, D = 40000, 512, 8
+    X, Xu, y, _ = synth(N, M, D, seed=77)
+    s2, ell, w = 0.18, np.array([2.99, 2.91, 1.74, 2.27, 2.01, 1.58, 1.53, 2.05]), 1e4
+    ref = O.vmp_sweep(Xu, X, y, None, s2, ell, w, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
+    with G.SGPDevice(N, M, D) as dev:
+        dev.set_inducing(Xu)
+        dev.set_kernel(s2, ell, 0.0)
+        dev.set_prior_isotropic(50.0)
+        dev.set_noise([[w]])
+        dev.set_data(X, y)
+        dev.sweep()
+        P_all, B_all, _ = dev.stats()
+        mu, Sig, Uv = dev.posterior()
+        dev.set_data(X[:17003], y[:17003]); dev.sweep_local(); Pa, Ba, _ = dev.stats()
+        dev.set_data(X[17003:], y[17003:]); dev.sweep_local(); Pb, Bb, _ = dev.stats()
+        perm = np.random.default_rng(0).permutation(N)
+        dev.set_data(X[perm], y[perm]); dev.sweep_local(); Pp, Bp, _ = dev.stats()
+    cond_L = np.linalg.cond(np.eye(M) / 50.0 + w * ref.stats.Psi2)
+    tol = min(1e-5, max(1e-9, 20 * np.finfo(float).eps * cond_L))
+    assert relF(P_all, ref.stats.Psi2) < 1e-12 and relF(B_all, ref.stats.b) < 1e-12
+    assert relF(mu, ref.mu_v) < tol and relF(Sig, ref.Sigma_v) < tol and relF(Uv, ref.Uv) < tol
+    assert relF(Pa + Pb, P_all) < 1e-13 and relF(Ba + Bb, B_all) < 1e-13          # additivity (the all-reduce contract)
+    assert relF(Pp, P_all) < 1e-13 and relF(Bp, B_all) < 1e-13                    # permutation invariance
+    # one million points: no oracle at this size, only invariants
+    N2, M2 = 1_000_000, 256
+    rng = np.random.default_rng(5)
+    X2 = rng.uniform(-1.745, 1.745, (N2, D))
+    y2 = np.sin(X2.sum(axis=1))
+    Xu2 = X2[:M2].copy()
+    with G.SGPDevice(N2, M2, D) as dev:
+        dev.set_inducing(Xu2); dev.set_data(X2, y2); dev.set_kernel(s2, ell, 1e-8)
+        dev.set_prior_isotropic(50.0); dev.set_noise([[10.0]])
+        dev.sweep()
+        P2, B2, sc = dev.stats()
+        mu2, Sig2, Uv2 = dev.posterior()
+    assert sc[2] == N2
+    Lam2 = np.eye(M2) / 50.0 + 10.0 * P2
+    assert np.abs(Lam2 @ Sig2 - np.eye(M2)).max() < 1e-6
+    np.testing.assert_allclose(Sig2 @ (10.0 * B2[:, 0]), mu2, rtol=1e-6, atol=1e-9)
+    assert relF(Uv2.T @ Uv2, Sig2 + np.outer(mu2, mu2)) < 1e-10
+    # a 4000-point subsample of Psi2's definition (linearity check of the streaming SYRK at scale)
+    idx = rng.choice(N2, 4000, replace=False)
+    K = O.kernelmatrix(s2, ell, Xu2, X2[idx])
+    assert np.all(np.diag(P2) >= np.sum(K * K, axis=1) - 1e-9)
