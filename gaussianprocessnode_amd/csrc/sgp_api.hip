@@ -46,7 +46,7 @@ struct sgp_handle {
     double n_nodes = 0;
     bool has_omega = false, has_yv = false, have_data = false, have_kernel = false, have_inducing = false;
     int prior_form = 2;            // 1 dense precision, 2 isotropic
-    bool swept_local = false, swept = false;
+    bool swept_local = false, swept = false, stats_dirty = false;
     int n_ell = 1;
     // device buffers
     double *dXu = nullptr, *dXus = nullptr, *dX = nullptr, *dYw = nullptr, *dY = nullptr, *dYv = nullptr, *dOmega = nullptr;
@@ -55,6 +55,7 @@ struct sgp_handle {
     double *dLam = nullptr, *dWl = nullptr, *dSigma = nullptr, *dR = nullptr, *dXi = nullptr, *dMu = nullptr;
     double *dLambda0 = nullptr, *dXi0 = nullptr, *dOut = nullptr, *dWishart = nullptr, *dTrace = nullptr, *dTmp = nullptr;
     double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr, *dOut2 = nullptr, *dUvWork = nullptr;
+    double *dGradM = nullptr, *dGradPart = nullptr, *dGrad = nullptr;   // theta-gradient scratch (allocated on first use)
     int* dInfo = nullptr;
     int64_t* dStamps = nullptr;
     int64_t* dStampTotals = nullptr;
@@ -259,7 +260,8 @@ extern "C" int sgp_destroy(sgp_handle* h) {
     void* bufs[] = {h->dXu, h->dXus, h->dX, h->dYw, h->dY, h->dYv, h->dOmega, h->dKuf, h->dBpart, h->dSlabs, h->dStatsOwn,
                     h->dDataScal, h->dKuu, h->dWk, h->dKinv, h->dLam, h->dWl, h->dSigma, h->dR, h->dTmp, h->dLambda0,
                     h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
-                    h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals, h->dUvWork};
+                    h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals, h->dUvWork,
+                    h->dGradM, h->dGradPart, h->dGrad};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evFork) hipEventDestroy(h->evFork);
@@ -427,6 +429,25 @@ extern "C" int sgp_set_prior(sgp_handle* h, const double* vec, const double* mat
     return 0;
 }
 
+// prior <- posterior in natural form: Lambda0 += W (x) Psi2, xi0 += vec(B W).  The minibatch carry of
+// experiments/regression_kin40k.ipynb:205-212 without the round trip through (mu, Sigma) on the host -- and without
+// inverting Sigma_v again on the next sweep.
+extern "C" int sgp_carry_posterior(sgp_handle* h, void* stream) {
+    if (!h) return SGP_ERR_ARG;
+    if (!h->swept || h->stats_dirty)
+        return fail(h, SGP_ERR_ARG, "sgp_carry_posterior: call it right after a finished sweep (before sgp_theta_objective)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
+    const size_t Qp = h->Qp;
+    hipLaunchKernelGGL(k_form_lambda, dim3(h->TQ, h->TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dTmp, h->dXi,
+                       h->dParams, h->M, h->Mp, h->dout, h->Q, h->Qp, h->prior_form, 0);
+    HIPCHK(h, hipMemcpyAsync(h->dLambda0, h->dTmp, sizeof(double) * Qp * Qp, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->dXi0, h->dXi, sizeof(double) * Qp, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipGetLastError());
+    h->prior_form = 1;
+    return 0;
+}
+
 extern "C" int sgp_stats_layout(const sgp_handle* h, void** stats_dev, int64_t* count, int32_t* mp) {
     if (!h) return SGP_ERR_ARG;
     if (stats_dev) *stats_dev = h->dStats;
@@ -553,6 +574,7 @@ extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) {
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
     rc = run_sequence(h, h->gLocal, enqueue_local, s);
     if (rc) return rc;
+    h->stats_dirty = false;
     // fork: the K_uu chain starts on the side stream AFTER the data-sized kernels (they want the whole chip; the chain
     // is a few-CU latency-bound sequence that then runs beside the all-reduce and the Lambda chain of sgp_sweep_finish)
     HIPCHK(h, hipEventRecord(h->evFork, s));
@@ -839,32 +861,43 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipDeviceSynchronize());
     hipStream_t s = h->own;
+    h->stats_dirty = true;                       // the statistics now belong to the NEW theta, not to q(v)'s sweep
     int rc = theta_objective_eval(h, s, value);
     if (rc || !grad) { h->swept_local = true; return rc; }
-    // gradient w.r.t. (sigma2, ell_1 .. ell_n_ell) by central differences on the device objective (2 (1 + n_ell) more
-    // evaluations, ~0.3 ms each at kin40k size).  The analytic kernel-derivative contraction is the planned replacement.
-    Params saved = *h->hParams;
-    const int np = 1 + h->n_ell;
-    for (int p = 0; p < np; ++p) {
-        double base = (p == 0) ? saved.sigma2 : 1.0 / saved.inv_ell[p - 1];
-        double step = 1e-5 * std::max(std::fabs(base), 1e-3);
-        double f[2];
-        for (int sgn = 0; sgn < 2; ++sgn) {
-            *h->hParams = saved;
-            double v = base + (sgn ? -step : step);
-            if (p == 0) h->hParams->sigma2 = v;
-            else if (h->n_ell == 1) for (int d = 0; d < h->D; ++d) h->hParams->inv_ell[d] = 1.0 / v;
-            else h->hParams->inv_ell[p - 1] = 1.0 / v;
-            rc = theta_objective_eval(h, s, &f[sgn]);
-            if (rc) { *h->hParams = saved; return rc; }
-        }
-        grad[p] = (f[0] - f[1]) / (2.0 * step);
+    // analytic gradient w.r.t. (sigma2, ell_1 .. ell_n_ell): one G K_uf GEMM contracted with the kernel derivatives in its
+    // epilogue, plus the K_uu term through H = Kinv Psi2 Kinv (see k_theta_grad_* in sgp_kernels.hip.h)
+    const int Mp = h->Mp, T = h->T;
+    const int nblk_max = (int)((h->n_max + TB - 1) / TB);
+    if (!h->dGradM) {
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGradM), sizeof(double) * 3 * (size_t)Mp * Mp));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGradPart),
+                            sizeof(double) * ((size_t)std::max(nblk_max, 1) * T + GRAD_UU_BLOCKS) * GRAD_SLOTS));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGrad), sizeof(double) * GRAD_SLOTS));
     }
-    *h->hParams = saved;
-    double dummy;
-    rc = theta_objective_eval(h, s, &dummy);      // leave the device statistics at the unperturbed theta
+    double* dG = h->dGradM;
+    double* dT1 = dG + (size_t)Mp * Mp;
+    double* dH = dT1 + (size_t)Mp * Mp;
+    double* part_uu = h->dGradPart;
+    double* part_uf = h->dGradPart + (size_t)GRAD_UU_BLOCKS * GRAD_SLOTS;
+    const size_t cnt = (size_t)Mp * Mp;
+    const int n_uf = h->n > 0 ? h->nblk * T : 0;
+    hipLaunchKernelGGL(k_form_G, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->dR, h->dKinv, dG, cnt);
+    hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)h->dKinv, (const double*)h->dStats, dT1,
+                       Mp, T, 3, 0, 0);
+    hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)dT1, (const double*)h->dKinv, dH, Mp, T,
+                       3, 0, 0);
+    if (h->n > 0)
+        hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
+                           h->has_omega ? h->dOmega : nullptr, h->dMu, h->dParams, part_uf, Mp, T, h->D, h->n);
+    hipLaunchKernelGGL(k_theta_grad_uu, dim3(GRAD_UU_BLOCKS), dim3(256), 0, s, dH, h->dXus, h->dParams, part_uu, h->M, Mp,
+                       h->D);
+    hipLaunchKernelGGL(k_theta_grad_finish, dim3(1), dim3(64), 0, s, part_uf, n_uf, part_uu, (int)GRAD_UU_BLOCKS,
+                       h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, h->dParams, h->dGrad, h->D, h->n_ell);
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpy(grad, h->dGrad, sizeof(double) * (1 + h->n_ell), hipMemcpyDeviceToHost));
     h->swept_local = true;
-    return rc;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

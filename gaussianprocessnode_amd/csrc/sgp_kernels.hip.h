@@ -1047,6 +1047,9 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
     if (mode == 0) {
         tile_from_index(blockIdx.x >> 2, I, J);
         kbeg = I; kend = Tn;
+    } else if (mode == 3) {                                              // general C = A B, every tile
+        const int t = blockIdx.x >> 2;
+        I = t / Tn; J = t % Tn; kbeg = 0; kend = Tn;
     } else {
         const int t = blockIdx.x >> 2, lo = 2 * s * blockIdx.y;
         I = lo + s + t / s; J = lo + t % s;
@@ -1510,6 +1513,175 @@ __global__ void __launch_bounds__(256) k_transpose(const double* __restrict__ A,
     for (int e = threadIdx.x; e < TB * TB; e += 256) {
         int c = e >> 6, r = e & 63;
         At[(size_t)(I + c) * ld + J + r] = tile[c * (TB + 1) + r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Analytic gradient of the hyper-parameter objective (helper_functions/derivative_helper.jl:23-39; the reference
+// differentiates it with ForwardDiff, :55-63).  With q(v) fixed (mu, R = Sigma_v + mu mu^T), G = R - K_uu^-1 and
+// H = K_uu^-1 Psi2 K_uu^-1:
+//   f      = w/2 [ s_w sigma2 + tr(G Psi2) - 2 b^T mu ]
+//   df     = w/2 [ s_w dsigma2 + sum_mn Z_mn dKuf_mn / Kuf_mn + sum_mm' H_mm' dKuu_mm' ],
+//   Z_mn   = 2 (omega_n (G k_n)_m - omega_n y_n mu_m) Kuf_mn,
+//   dk/dsigma2 = k / sigma2 ,  dk/dell_d = k (x_d - u_d)^2 / ell_d^3  (jitter does not depend on theta).
+// k_theta_grad_uf: one 64 x 64 tile of G K_uf per block on the matrix cores, the contraction with the kernel
+//   derivatives in the epilogue, block partial sums [slot 0: sum Z ; slot 1 + d: sum Z ((x_d - u_d) / ell_d)^2].
+// k_theta_grad_uu: the same contraction of H with the K_uu derivatives.
+// k_theta_grad_finish: fixed-order sum of the partials (bitwise reproducible) and the chain-rule factors.
+// ------------------------------------------------------------------------------------------------
+constexpr int GRAD_SLOTS = MAXD + 1;
+constexpr int GRAD_UU_BLOCKS = 64;
+
+__global__ void __launch_bounds__(256) k_form_G(const double* __restrict__ R, const double* __restrict__ Kinv,
+                                                double* __restrict__ G, size_t count) {
+    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < count) G[e] = R[e] - Kinv[e];
+}
+
+__global__ void __launch_bounds__(256) k_theta_grad_uf(const double* __restrict__ G, const double* __restrict__ Kuf,
+                                                       const double* __restrict__ X, const double* __restrict__ Xus,
+                                                       const double* __restrict__ Yw, const double* __restrict__ omega,
+                                                       const double* __restrict__ mu, const Params* __restrict__ P,
+                                                       double* __restrict__ partial, int Mp, int T, int D, int64_t N) {
+    __shared__ double lds[2 * TB * PS];
+    __shared__ double ys[TB], om[TB], mus[TB];
+    __shared__ double wsum[4][GRAD_SLOTS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int I = blockIdx.y;
+    const int64_t n0 = (int64_t)blockIdx.x * TB;
+    double* As = lds;
+    double* Bs = lds + TB * PS;
+    Acc4 acc;
+    acc_zero(acc);
+    for (int k = 0; k < T; ++k) {
+        __syncthreads();
+        load_panel_n(As, G, Mp, I * TB, k * TB, TB, tid);          // As[kk][i] = G[I*64 + i, k*64 + kk]  (G symmetric)
+        for (int t = tid; t < TB * 16; t += 256) {                 // Bs[kk][j] = Kuf[k*64 + kk, n0 + j]
+            int j = t >> 4, g = t & 15;
+            int64_t n = n0 + j;
+            double v[4] = {0.0, 0.0, 0.0, 0.0};
+            if (n < N) {
+                const double* src = Kuf + (size_t)n * Mp + k * TB + g * 4;
+                double2 v0 = *reinterpret_cast<const double2*>(src);
+                double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+                v[0] = v0.x; v[1] = v0.y; v[2] = v1.x; v[3] = v1.y;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Bs[(g * 4 + q) * PS + j] = v[q];
+        }
+        __syncthreads();
+        tile_mma(acc, As, Bs, TB, lane, wr, wc);
+    }
+    __syncthreads();
+    // the panels are done: their LDS now holds the scaled coordinates of this block's 64 inducing rows / 64 points
+    double* us = lds;
+    double* xs = lds + MAXD * TB;
+    for (int t = tid; t < D * TB; t += 256) {
+        int d = t / TB, r = t % TB;
+        us[t] = Xus[(size_t)d * Mp + I * TB + r];
+    }
+    for (int t = tid; t < D * TB; t += 256) {
+        int p = t / D, d = t % D;
+        int64_t n = n0 + p;
+        xs[d * TB + p] = (n < N) ? X[(size_t)n * D + d] * P->inv_ell[d] : 0.0;
+    }
+    if (tid < TB) {
+        int64_t n = n0 + tid;
+        ys[tid] = (n < N) ? Yw[n] : 0.0;
+        om[tid] = (n < N) ? (omega ? omega[n] : 1.0) : 0.0;
+        mus[tid] = mu[I * TB + tid];
+    }
+    __syncthreads();
+    double z[2][2][4];
+    double e0 = 0.0;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int col = acc_col(lane, wc, tj);
+            const int64_t n = n0 + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = acc_row(lane, wr, ti, r);
+                const double kv = (n < N) ? Kuf[(size_t)n * Mp + I * TB + row] : 0.0;
+                const double v = 2.0 * (om[col] * acc.t[ti][tj][r] - ys[col] * mus[row]) * kv;
+                z[ti][tj][r] = v;
+                e0 += v;
+            }
+        }
+    for (int o = 32; o > 0; o >>= 1) e0 += __shfl_xor(e0, o);
+    if (lane == 0) wsum[wave][0] = e0;
+    for (int d = 0; d < D; ++d) {
+        double e = 0.0;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const double xv = xs[d * TB + acc_col(lane, wc, tj)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double t = xv - us[d * TB + acc_row(lane, wr, ti, r)];
+                    e = fma(z[ti][tj][r], t * t, e);
+                }
+            }
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+        if (lane == 0) wsum[wave][1 + d] = e;
+    }
+    __syncthreads();
+    if (tid <= D)
+        partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GRAD_SLOTS + tid] =
+            (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
+}
+
+__global__ void __launch_bounds__(256) k_theta_grad_uu(const double* __restrict__ H, const double* __restrict__ Xus,
+                                                       const Params* __restrict__ P, double* __restrict__ partial,
+                                                       int M, int Mp, int D) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const double s2 = P->sigma2;
+    // slot -1 (sum H o K) and one slot per dimension; the kernel value is recomputed per pass (M^2 (D + 1) exps: noise)
+    for (int slot = 0; slot <= D; ++slot) {
+        double e = 0.0;
+        for (int j = blockIdx.x; j < M; j += gridDim.x)
+            for (int i = tid; i < M; i += 256) {
+                double d2 = 0.0, td = 1.0;
+                for (int d = 0; d < D; ++d) {
+                    double t = Xus[(size_t)d * Mp + i] - Xus[(size_t)d * Mp + j];
+                    d2 = fma(t, t, d2);
+                    if (d + 1 == slot) td = t * t;
+                }
+                e = fma(H[(size_t)j * Mp + i] * (s2 * exp(-0.5 * d2)), td, e);
+            }
+        e = block_sum(e, red);
+        if (tid == 0) partial[(size_t)blockIdx.x * GRAD_SLOTS + slot] = e;
+    }
+}
+
+// grad[0] = df/dsigma2, grad[1 ..] = df/dell (n_ell = 1: one shared lengthscale, else one per dimension)
+__global__ void __launch_bounds__(64) k_theta_grad_finish(const double* __restrict__ part_uf, int n_uf,
+                                                          const double* __restrict__ part_uu, int n_uu,
+                                                          const double* __restrict__ stats_scal, const Params* __restrict__ P,
+                                                          double* __restrict__ grad, int D, int n_ell) {
+    __shared__ double tot[GRAD_SLOTS];
+    const int lane = threadIdx.x;
+    for (int slot = 0; slot <= D; ++slot) {
+        double v = 0.0;
+        for (int b = lane; b < n_uf; b += 64) v += part_uf[(size_t)b * GRAD_SLOTS + slot];
+        for (int b = lane; b < n_uu; b += 64) v += part_uu[(size_t)b * GRAD_SLOTS + slot];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) tot[slot] = v;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        const double hw = 0.5 * P->W[0];
+        grad[0] = hw * (stats_scal[1] + tot[0] / P->sigma2);
+        if (n_ell == 1) {
+            double g = 0.0;
+            for (int d = 0; d < D; ++d) g += tot[1 + d];
+            grad[1] = hw * g * P->inv_ell[0];
+        } else {
+            for (int d = 0; d < D; ++d) grad[1 + d] = hw * tot[1 + d] * P->inv_ell[d];
+        }
     }
 }
 

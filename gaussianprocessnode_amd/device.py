@@ -167,6 +167,10 @@ class SGPDevice:
         check(self._lib.sgp_predict(self._h, ptr(Xs), ns, ptr(mu), ptr(out)), self._h, "sgp_predict")
         return out[0] if self.d_out == 1 else out.T.copy()
 
+    def carry_posterior(self, stream: int = 0):
+        """prior <- posterior of the last sweep, on the device (the minibatch carry, regression_kin40k.ipynb:205-212)."""
+        check(self._lib.sgp_carry_posterior(self._h, C.c_void_p(stream)), self._h, "sgp_carry_posterior")
+
     def theta_objective(self, want_grad: bool = False, n_ell: Optional[int] = None):
         """neg_log_backwardmess_fast at the current kernel with q(v) fixed at the last sweep; optionally its gradient
         w.r.t. (sigma2, ell...)."""

@@ -48,17 +48,27 @@ def perform_inference(theta, xtrain, ytrain, Xu, engine, *, batch_size=500, epoc
     xb, yb = split2batch((xtrain, np.asarray(ytrain, dtype=np.float64)), batch_size)
     engine.set_inducing(Xu)
     engine.set_noise([[w_val]])
+    device_carry = hasattr(engine, "carry_posterior")
     mu, Sigma = np.zeros(M), prior_var * np.eye(M)
+    zero, Lam_prior = np.zeros(M), np.eye(M) / prior_var
     for _ in range(epochs):
         mu, Sigma = np.zeros(M), prior_var * np.eye(M)                     # :203-204
+        if device_carry:
+            engine.set_prior_precision(zero, Lam_prior)                    # dense form: the captured graphs stay valid
         for xi, yi in zip(xb, yb):
             p = softplus(theta)
-            engine.set_prior_meancov(mu, Sigma)
+            if not device_carry:
+                engine.set_prior_meancov(mu, Sigma)
             engine.set_data(xi, yi)
             engine.set_kernel(float(p[0]), p[1:], jitter)                  # :183-184 (no jitter in training)
             engine.sweep()                                                 # :185-192  infer(iterations = 1)
-            mu, Sigma, _ = engine.posterior(want_uv=False)                 # :212
+            if device_carry:
+                engine.carry_posterior()                                   # :212 without leaving the device
+            else:
+                mu, Sigma, _ = engine.posterior(want_uv=False)
             if learn_theta:
                 _, g = engine.theta_objective(want_grad=True, n_ell=len(p) - 1)    # :214-221
                 optimizer.update(theta, g * sigmoid(theta))                # chain rule through softplus; :222
+    if device_carry:
+        mu, Sigma, _ = engine.posterior(want_uv=False)
     return MvNormalMeanCovariance(mu, Sigma), theta

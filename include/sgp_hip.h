@@ -131,6 +131,12 @@ int sgp_get_kuu_chol(sgp_handle* h, double* KuuL);
 /* MultiSGP: inverse scale sum_t (I1_t + I2_t) of the Wishart messages (GPnode/MultiSGPnode.jl:391-404), d_out^2 */
 int sgp_get_wishart_invscale(sgp_handle* h, double* S);
 
+/* sgp_carry_posterior: prior <- posterior of the last finished sweep, on the device and in natural form
+ * (Lambda0 += W (x) Psi2, xi0 += vec(B W)): the minibatch carry of experiments/regression_kin40k.ipynb:205-212
+ * (`mu_v, Sigma_v = mean_cov(q_v)` fed back as the next prior).  Call after sgp_sweep and before sgp_theta_objective
+ * (which re-evaluates the statistics at the new theta). */
+int sgp_carry_posterior(sgp_handle* h, void* stream);
+
 /* sgp_w_stats: per-point :w rule quantities (GPnode/UniSGPnode.jl:196-238):
  * I1_n = k_nn - |L^-1 k_n|^2 (the Q_ff diagonal term) and I2_n.  Needs SGP_FLAG_KEEP_KUF and a finished sweep.
  * Either output may be NULL. */
@@ -144,7 +150,7 @@ int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const double* mu
 /* sgp_theta_objective: neg_log_backwardmess_fast (helper_functions/derivative_helper.jl:23-39) evaluated at the CURRENT
  * kernel parameters (sgp_set_kernel) with q(v) -- mu_v and Uv'Uv -- held at the last finished sweep, as the notebooks use
  * it (experiments/regression_kin40k.ipynb:212-221).  grad (may be NULL): d/d(sigma2, ell_1..ell_n_ell), 1 + n_ell
- * entries (grad_llh_new!, derivative_helper.jl:59-63; here by central differences of the device objective). */
+ * entries (grad_llh_new!, derivative_helper.jl:59-63 uses ForwardDiff; here the analytic kernel-derivative contraction). */
 int sgp_theta_objective(sgp_handle* h, double* value, double* grad);
 
 /* ---- building blocks exposed for tests / other callers (host pointers, blocking) ------------
