@@ -186,9 +186,12 @@ def test_minibatch_carry_matches_full_batch(G):
             dev.sweep()
             dev.carry_posterior()
         mu_d, Sig_d, _ = dev.posterior(want_uv=False)
-        dev.theta_objective()
+        dev.theta_objective()                          # same theta as the sweep: nothing recomputed, carry still valid
+        dev.carry_posterior()
+        dev.set_kernel(s2 * 1.1, ell, 0.0)
+        dev.theta_objective()                          # new theta: statistics re-evaluated ...
         with pytest.raises(G.SGPError):
-            dev.carry_posterior()                      # the statistics no longer belong to q(v)'s sweep
+            dev.carry_posterior()                      # ... and no longer belong to q(v)'s sweep
     assert relF(mu, full.mu_v) < 1e-7
     assert relF(Sig, full.Sigma_v) < 1e-7
     assert relF(mu_d, full.mu_v) < 1e-7                  # conditioning-limited like the host carry above
