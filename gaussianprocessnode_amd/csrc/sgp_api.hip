@@ -872,8 +872,9 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     // K_uu^-1 and the traces are still on the device, nothing is recomputed.  (Not with externally reduced statistics:
     // the objective is additive over shards only with each rank's LOCAL Psi2.)
     bool fresh = !h->stats_dirty && h->swept_data_gen == h->data_gen && h->dStats == h->dStatsOwn &&
-                 h->swept_params.sigma2 == h->hParams->sigma2 && h->swept_params.jitter == h->hParams->jitter &&
-                 h->swept_params.W[0] == h->hParams->W[0];
+                 h->swept_params.sigma2 == h->hParams->sigma2 && h->swept_params.jitter == h->hParams->jitter;
+    // the objective is linear in w: a new mean(q_w) (classification_banana.ipynb passes the UPDATED q(w)) only rescales it
+    const double wscale = fresh ? h->hParams->W[0] / h->swept_params.W[0] : 1.0;
     for (int d = 0; d < h->D && fresh; ++d) fresh = h->swept_params.inv_ell[d] == h->hParams->inv_ell[d];
     int rc = 0;
     if (fresh) {
@@ -920,6 +921,7 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpy(grad, h->dGrad, sizeof(double) * (1 + h->n_ell), hipMemcpyDeviceToHost));
+    for (int i = 0; i <= h->n_ell; ++i) grad[i] *= wscale;
     if (!fresh) h->swept_local = true;
     return 0;
 }

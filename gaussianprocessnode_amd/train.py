@@ -72,3 +72,61 @@ def perform_inference(theta, xtrain, ytrain, Xu, engine, *, batch_size=500, epoc
     if device_carry:
         mu, Sigma, _ = engine.posterior(want_uv=False)
     return MvNormalMeanCovariance(mu, Sigma), theta
+
+
+def probit_marginal(y, mz, vz):
+    """q(f) for `y ~ Probit(f)` with the forward message N(f; mz, vz): the moment-matched product of the UniSGP :out
+    message with ReactiveMP's Probit(:in) message for a PointMass output (y in {0, 1}).  Returns (mean, variance)."""
+    from scipy.special import log_ndtr
+    y = np.asarray(y, dtype=np.float64)
+    mz = np.asarray(mz, dtype=np.float64)
+    s = 2.0 * y - 1.0
+    g = s * mz / np.sqrt(1.0 + vz)
+    r = np.exp(-0.5 * g * g - 0.5 * np.log(2.0 * np.pi) - log_ndtr(g))        # phi(g) / Phi(g)
+    return mz + s * vz * r / np.sqrt(1.0 + vz), vz - vz * vz / (1.0 + vz) * r * (g + r)
+
+
+def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch_size=200, epochs=1, prior_var=50.0,
+                                     shape=0.01, rate=0.01, jitter=1e-8, optimizer=None):
+    """`PerformInference` of experiments/classification_banana.ipynb (model `f[i] ~ UniSGP(x[i], v, w, theta);
+    y[i] ~ Probit(f[i])`, mean-field q(f) q(v) q(w), one VMP iteration per minibatch, q(v) and q(w) carried over every
+    minibatch and never reset).  Per minibatch:
+      q(f_i)  from the :out message N(k_i mu_v, 1 / mean(q_w)) (GPnode/UniSGPnode.jl:96-104) and the Probit likelihood;
+      q(v)    one sweep with q_out = q(f_i) (the classification :v rule, :161-173);
+      q(w)    Gamma(a + n/2, b + (sum I1 + sum I2)/2) with the NEW q(v) and the `meta.Uv` its product hook just stored
+              (:56-73, :219-238);
+      theta   one optimiser step on neg_log_backwardmess_fast with y_data = mean(q_f), w = mean(new q_w).
+    Returns (q_v, (shape, rate), theta).  The reference's own trajectory is not reproducible bit for bit: its gradient
+    factors K_uu WITHOUT jitter (derivative_helper.jl:24-25), which for the banana inducing inputs is numerically
+    indefinite; here the gradient uses the same jittered K_uu as the sweep."""
+    theta = np.array(theta, dtype=np.float64)
+    xtrain = np.asarray(xtrain, dtype=np.float64).reshape(len(ytrain), -1)
+    ytrain = np.asarray(ytrain, dtype=np.float64)
+    Xu = np.asarray(Xu, dtype=np.float64).reshape(-1, xtrain.shape[1])
+    M = Xu.shape[0]
+    optimizer = optimizer or AdaMax()
+    xb, yb = split2batch((xtrain, ytrain), batch_size)
+    a, b = float(shape), float(rate)
+    engine.set_inducing(Xu)
+    engine.set_prior_precision(np.zeros(M), np.eye(M) / prior_var)
+    mu = np.zeros(M)
+    first = True
+    for _ in range(epochs):
+        for xi, yi in zip(xb, yb):
+            p = softplus(theta)
+            w0 = a / b
+            engine.set_kernel(float(p[0]), p[1:], jitter)
+            mz = engine.predict(xi, mu if first else None)             # k_i' mu_v with the carried posterior mean
+            mf, vf = probit_marginal(yi, mz, 1.0 / w0)
+            engine.set_data(xi, mf, vf)
+            engine.set_noise([[w0]])
+            engine.sweep()
+            sc = engine.scalars()
+            a, b = a + 0.5 * len(yi), b + 0.5 * (sc.sum_I1 + sc.sum_I2)
+            engine.carry_posterior()
+            engine.set_noise([[a / b]])                                # grad_llh_new!(...; w = mean(qw))
+            _, g = engine.theta_objective(want_grad=True, n_ell=len(p) - 1)
+            optimizer.update(theta, g * sigmoid(theta))
+            first = False
+    mu, Sigma, _ = engine.posterior(want_uv=False)
+    return MvNormalMeanCovariance(mu, Sigma), (a, b), theta

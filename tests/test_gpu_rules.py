@@ -262,3 +262,19 @@ def test_kin40k_training_run_reproduces_the_reference_end_to_end():
     assert abs(SMSE(data["ytest"], pred) - 0.08343114079545057) < 1e-8
     assert np.linalg.norm(qv.m - fix["mu_v"]) / np.linalg.norm(fix["mu_v"]) < 1e-5
     np.testing.assert_allclose(np.diag(qv.S), fix["Sigma_diag"], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_banana_classification_driver():
+    """experiments/classification_banana.ipynb's PerformInference (Probit likelihood, q(w) Gamma updates, carried q(v))
+    on the reference's banana data and inducing inputs.  The reference ends at 125 / 1300 test errors after 500 epochs;
+    its exact trajectory is not reproducible (un-jittered, numerically indefinite K_uu in its gradient), so this pins the
+    driver at a short horizon: 30 epochs must already classify within 12 % error, and q(w) must have accumulated
+    exactly shape 0.01 + 30 * 20 * 100."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import train_banana
+    res = train_banana.run(epochs=30)
+    assert res["error_rate"] < 0.12, res
+    assert math.isclose(res["qw"][0], 0.01 + 30 * 20 * 100.0, rel_tol=1e-12)
+    assert 0.2 < res["qw"][0] / res["qw"][1] < 5.0                       # mean(q_w) stays O(1)
