@@ -158,7 +158,9 @@ def main():
                      "algorithmic_flops_per_launch": syrk_flops,
                      "peak_note": "78.6 = MI355X FP64 matrix spec; tools/mfma_f64_probe.hip sustains 47.5 (MFMA) / 63.7 (VALU FMA)"},
         "phases_us": {"sweep_device": tick_us(_lib.SGP_T_SWEEP), "gram_uf": tick_us(_lib.SGP_T_GRAM),
-                      "gram_uf_alone_hip_events": gram_us_alone, "syrk": syrk_us},
+                      "gram_uf_alone_hip_events": gram_us_alone, "syrk": syrk_us,
+                      "local": tick_us(_lib.SGP_T_LOCAL), "gap_local_to_finish": tick_us(_lib.SGP_T_GAP_LOCAL_FINISH),
+                      "finish1_lambda_chain": tick_us(_lib.SGP_T_FINISH1), "finish2_traces": tick_us(_lib.SGP_T_FINISH2)},
     }
 
     if rank == 0:

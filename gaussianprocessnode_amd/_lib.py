@@ -17,7 +17,7 @@ SGP_FLAG_KEEP_KUF = 2
 SGP_S_YY, SGP_S_W, SGP_S_N, SGP_S_COUNT = 0, 1, 2, 8
 (SGP_R_SUM_I1, SGP_R_SUM_I2, SGP_R_ENERGY, SGP_R_INFO_KUU, SGP_R_INFO_LAMBDA, SGP_R_INFO_PRIOR,
  SGP_R_LOGDET_KUU, SGP_R_LOGDET_LAMBDA, SGP_R_COUNT) = range(9)
-SGP_T_SWEEP, SGP_T_GRAM, SGP_T_SYRK = 0, 1, 2
+SGP_T_SWEEP, SGP_T_GRAM, SGP_T_SYRK, SGP_T_FINISH1, SGP_T_FINISH2, SGP_T_GAP_LOCAL_FINISH, SGP_T_KUU, SGP_T_LOCAL = range(8)
 SGP_T_COUNT = 8
 
 EXPORTS = [

@@ -47,6 +47,7 @@ struct sgp_handle {
     bool has_omega = false, has_yv = false, have_data = false, have_kernel = false, have_inducing = false;
     int prior_form = 2;            // 1 dense precision, 2 isotropic
     bool swept_local = false, swept = false, stats_dirty = false;
+    bool in_flight = false;        // a sweep may still be executing (its streams are non-blocking)
     uint64_t data_gen = 0, swept_data_gen = ~0ull;   // bumped by set_data / set_inducing; recorded by the sweep
     Params swept_params{};                            // kernel / noise parameters the last sweep ran with
     int n_ell = 1;
@@ -92,6 +93,18 @@ static int fail(sgp_handle* h, int code, const char* msg) {
 }
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Setters change state that an enqueued sweep reads WHEN IT EXECUTES (the pinned parameter block, the data buffers, the
+// prior): they first wait for any sweep still in flight.  The library's streams are non-blocking, so the implicit
+// synchronisation of hipMemcpy with the legacy default stream does not cover them.
+static int quiesce(sgp_handle* h) {
+    if (h->in_flight) {
+        HIPCHK(h, hipSetDevice(h->cfg.device));
+        HIPCHK(h, hipDeviceSynchronize());
+        h->in_flight = false;
+    }
+    return 0;
+}
 
 // streaming-SYRK grid: tiles x point-chunks.  ~4.5 blocks per CU (3 resident, the rest dispatched as CUs free up) evens
 // out the 2-vs-3 blocks-per-CU imbalance a 2-blocks-per-CU grid leaves; the price is more partial slabs to sum.
@@ -276,6 +289,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
 
 extern "C" int sgp_set_inducing(sgp_handle* h, const double* Xu) {
     if (!h || !Xu) return fail(h, SGP_ERR_ARG, "sgp_set_inducing: null argument");
+    if (int qrc = quiesce(h)) return qrc;
     h->data_gen++;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpy(h->dXu, Xu, sizeof(double) * h->M * h->D, hipMemcpyHostToDevice));
@@ -287,6 +301,7 @@ extern "C" int sgp_set_inducing(sgp_handle* h, const double* Xu) {
 extern "C" int sgp_set_data(sgp_handle* h, const double* X, const double* y_mean, const double* y_var,
                             const double* pt_weight, int64_t n, double n_nodes) {
     if (!h || !X || !y_mean) return fail(h, SGP_ERR_ARG, "sgp_set_data: null argument");
+    if (int qrc = quiesce(h)) return qrc;
     h->data_gen++;
     if (n < 0 || n > h->n_max) return fail(h, SGP_ERR_ARG, "sgp_set_data: n outside [0, n_max]");
     if (y_var && h->dout != 1) return fail(h, SGP_ERR_ARG, "sgp_set_data: y_var is only defined for d_out = 1");
@@ -343,6 +358,7 @@ extern "C" int sgp_set_data(sgp_handle* h, const double* X, const double* y_mean
 
 extern "C" int sgp_set_output_cov_sum(sgp_handle* h, const double* S) {
     if (!h || !S) return fail(h, SGP_ERR_ARG, "sgp_set_output_cov_sum: null argument");
+    if (int qrc = quiesce(h)) return qrc;
     if (!h->have_data) return fail(h, SGP_ERR_ARG, "sgp_set_output_cov_sum: call sgp_set_data first");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int dd = h->dout * h->dout;
@@ -359,6 +375,7 @@ extern "C" int sgp_set_output_cov_sum(sgp_handle* h, const double* S) {
 
 extern "C" int sgp_set_kernel(sgp_handle* h, double sigma2, const double* ell, int32_t n_ell, double jitter) {
     if (!h || !ell) return fail(h, SGP_ERR_ARG, "sgp_set_kernel: null argument");
+    if (int qrc = quiesce(h)) return qrc;
     if (n_ell != 1 && n_ell != h->D) return fail(h, SGP_ERR_ARG, "sgp_set_kernel: n_ell must be 1 or D");
     if (!(sigma2 > 0.0) || !(jitter >= 0.0)) return fail(h, SGP_ERR_ARG, "sgp_set_kernel: sigma2 must be > 0, jitter >= 0");
     for (int d = 0; d < h->D; ++d) {
@@ -375,6 +392,7 @@ extern "C" int sgp_set_kernel(sgp_handle* h, double sigma2, const double* ell, i
 
 extern "C" int sgp_set_noise(sgp_handle* h, const double* W, double E_log_w) {
     if (!h || !W) return fail(h, SGP_ERR_ARG, "sgp_set_noise: null argument");
+    if (int qrc = quiesce(h)) return qrc;
     for (int i = 0; i < h->dout * h->dout; ++i) h->hParams->W[i] = W[i];
     h->hParams->E_logw = E_log_w;
     return 0;
@@ -394,6 +412,7 @@ static int upload_padded(sgp_handle* h, const double* src, double* dst) {
 
 extern "C" int sgp_set_prior(sgp_handle* h, const double* vec, const double* mat, int32_t form) {
     if (!h || !mat) return fail(h, SGP_ERR_ARG, "sgp_set_prior: null argument");
+    if (int qrc = quiesce(h)) return qrc;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t Q = h->Q, Qp = h->Qp;
     if (form == 2) {
@@ -444,7 +463,7 @@ extern "C" int sgp_carry_posterior(sgp_handle* h, void* stream) {
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
     const size_t Qp = h->Qp;
     hipLaunchKernelGGL(k_form_lambda, dim3(h->TQ, h->TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dTmp, h->dXi,
-                       h->dParams, h->M, h->Mp, h->dout, h->Q, h->Qp, h->prior_form, 0);
+                       h->dParams, h->M, h->Mp, h->dout, h->Q, h->Qp, h->prior_form, 0, (int64_t*)nullptr, (int*)nullptr);
     HIPCHK(h, hipMemcpyAsync(h->dLambda0, h->dTmp, sizeof(double) * Qp * Qp, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipMemcpyAsync(h->dXi0, h->dXi, sizeof(double) * Qp, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipGetLastError());
@@ -462,6 +481,7 @@ extern "C" int sgp_stats_layout(const sgp_handle* h, void** stats_dev, int64_t* 
 
 extern "C" int sgp_bind_stats(sgp_handle* h, void* stats_dev) {
     if (!h) return SGP_ERR_ARG;
+    if (int qrc = quiesce(h)) return qrc;
     h->dStats = stats_dev ? static_cast<double*>(stats_dev) : h->dStatsOwn;
     h->gLocal.valid = false;
     h->gFinish.valid = false;
@@ -481,10 +501,8 @@ extern "C" int sgp_bind_stats(sgp_handle* h, void* stats_dev) {
 // different streams (parallel branches inside ONE captured graph were observed to execute back to back).
 static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
-    hipMemcpyAsync(h->dParamsK, h->hParams, sizeof(Params), hipMemcpyHostToDevice, s);
-    hipMemsetAsync(h->dInfo, 0, sizeof(int), s);
-    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->dParamsK, M, Mp, D,
-                       (int64_t*)nullptr, 0, 0);
+    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, (const Params*)h->hParams,
+                       h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0);
     hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
     launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk);
     launch_trtri(h->dKuu, h->dWk, h->dKinv, Mp, T, s, true);
@@ -493,9 +511,8 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
 
 static void enqueue_local(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
-    hipMemcpyAsync(h->dParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice, s);
-    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->dParams, M, Mp, D,
-                       h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP);
+    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, (const Params*)h->hParams,
+                       h->dParams, (int*)nullptr, M, Mp, D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP);
     if (h->n > 0) {
         hipLaunchKernelGGL(k_gram_uf, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                            h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + 2 * SGP_T_GRAM);
@@ -505,16 +522,15 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     }
     hipLaunchKernelGGL(k_assemble, dim3(T, T, 4), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
                        h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
-                       SGP_S_COUNT + h->dout * h->dout);
+                       SGP_S_COUNT + h->dout * h->dout, h->dStamps + 2 * SGP_T_LOCAL);
 }
 
 static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp, TQ = h->TQ;
-    hipMemsetAsync(h->dInfo + 1, 0, sizeof(int), s);
     // Lambda is factored in index-reversed order (P Lambda P = L' L'^T): its inverse factor W' = L'^-1 then IS the upper
     // Cholesky factor of Sigma_v up to the reversal, and Uv follows by a rank-1 update instead of a third potrf.
     hipLaunchKernelGGL(k_form_lambda, dim3(TQ, TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dLam, h->dXi,
-                       h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form, 1);
+                       h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form, 1, h->dStamps + 2 * SGP_T_FINISH1, h->dInfo + 1);
     launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl);
     launch_trtri(h->dLam, h->dWl, h->dSigma, Qp, TQ, s, true);
     launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1);
@@ -529,17 +545,17 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_uv_p, dim3((Qp + 3) / 4), dim3(256), 0, s, h->dLam, h->dMu, uvp, Qp);
     hipLaunchKernelGGL(k_uv_scan, dim3(1), dim3(64), 0, s, uvp, uvck, uvak, Qp);
     hipLaunchKernelGGL(k_uv_partial, dim3(TQ * (TQ + 1) / 2), dim3(64), 0, s, h->dTmp, uvp, uvpart, Qp);
-    hipLaunchKernelGGL(k_uv_cols, dim3(TQ, TQ), dim3(64), 0, s, h->dTmp, uvp, uvck, uvak, uvpart, h->dUvT, Qp);
+    hipLaunchKernelGGL(k_uv_cols, dim3(TQ, TQ), dim3(64), 0, s, h->dTmp, uvp, uvck, uvak, uvpart, h->dUvT, Qp,
+                       h->dStamps + 2 * SGP_T_FINISH1);
 }
 
 static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
     hipLaunchKernelGGL(k_trace_partial, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dR, h->dTrace, M, Mp,
-                       h->dout, Qp);
+                       h->dout, Qp, h->dStamps + 2 * SGP_T_FINISH2);
     hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, h->dTrace, h->dMu, h->dKuu, h->dLam, h->dInfo,
-                       h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS, Qp - Q);
-    hipLaunchKernelGGL(k_stamp_accumulate, dim3(1), dim3(64), 0, s, h->dStamps, h->dStampTotals, (int)SGP_T_SWEEP,
-                       (int)SGP_T_COUNT);
+                       h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS, Qp - Q,
+                       h->dStamps + 2 * SGP_T_FINISH2, h->dStamps, h->dStampTotals);
 }
 
 typedef void (*enqueue_fn)(sgp_handle*, hipStream_t);
@@ -576,6 +592,7 @@ extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) {
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
+    h->in_flight = true;
     rc = run_sequence(h, h->gLocal, enqueue_local, s);
     if (rc) return rc;
     h->stats_dirty = false;
@@ -597,6 +614,7 @@ extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
     if (!h->swept_local) return fail(h, SGP_ERR_ARG, "sgp_sweep_finish: call sgp_sweep_local first");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
+    h->in_flight = true;
     int rc = run_sequence(h, h->gFinish, enqueue_finish1, s);
     if (rc) return rc;
     HIPCHK(h, hipStreamWaitEvent(s, h->evSide, 0));          // join with the K_uu chain
@@ -618,6 +636,7 @@ extern "C" int sgp_sweep(sgp_handle* h, void* stream) {
 static int sync_all(sgp_handle* h) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipDeviceSynchronize());
+    h->in_flight = false;
     return 0;
 }
 
@@ -806,6 +825,7 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
     if (ns == 0) return 0;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipDeviceSynchronize());
+    h->in_flight = false;
     hipStream_t s = h->own;
     double *dXs = nullptr, *dMean = nullptr, *dMuTmp = nullptr;
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dXs), sizeof(double) * ns * h->D));
@@ -817,9 +837,8 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
         HIPCHK(h, hipMemcpy(dMuTmp, mu_v, sizeof(double) * h->Q, hipMemcpyHostToDevice));
         dMu = dMuTmp;
     }
-    HIPCHK(h, hipMemcpyAsync(h->dParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->dParams, h->M, h->Mp, h->D,
-                       (int64_t*)nullptr, 0, 0);
+    hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, (const Params*)h->hParams,
+                       h->dParams, (int*)nullptr, h->M, h->Mp, h->D, (int64_t*)nullptr, 0, 0);
     switch (h->D) {
         case 1: launch_predict<1>(h, dXs, dMu, dMean, ns, s); break;
         case 2: launch_predict<2>(h, dXs, dMu, dMean, ns, s); break;
@@ -847,9 +866,10 @@ static int theta_objective_eval(sgp_handle* h, hipStream_t s, double* value) {
     enqueue_local(h, s);
     const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
     hipLaunchKernelGGL(k_trace_partial, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dR, h->dTrace, M, Mp,
-                       h->dout, Qp);
+                       h->dout, Qp, (int64_t*)nullptr);
     hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, h->dTrace, h->dMu, h->dKuu, h->dLam, h->dInfo,
-                       h->dParams, h->dOut2, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS, Qp - Q);
+                       h->dParams, h->dOut2, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS, Qp - Q, (int64_t*)nullptr,
+                       (int64_t*)nullptr, (int64_t*)nullptr);
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     double out[SGP_R_COUNT], sc[SGP_S_COUNT];
@@ -866,6 +886,7 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     if (!h->have_data || !h->have_kernel) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: data and kernel must be set");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipDeviceSynchronize());
+    h->in_flight = false;
     hipStream_t s = h->own;
     // Same theta, data and noise as the sweep that produced q(v) -- the notebooks' call pattern
     // (experiments/regression_kin40k.ipynb:205-221 evaluates the gradient at the theta the sweep just used): K_uf, Psi2, b,

@@ -58,15 +58,19 @@ __device__ __forceinline__ void stamp_exit(int64_t* stamps) {
     if (stamps && threadIdx.x == 0) atomicMax(reinterpret_cast<long long*>(stamps + 1), (long long)realtime_ticks());
 }
 // end-of-sweep stamp + running totals over sweeps: totals[i] += end_i - begin_i, totals[nslots] += 1
-__global__ void k_stamp_accumulate(int64_t* stamps, int64_t* totals, int sweep_slot, int nslots) {
-    if (threadIdx.x == 0) {
-        stamps[2 * sweep_slot + 1] = realtime_ticks();
-        for (int i = 0; i < nslots; ++i) {
-            int64_t b = stamps[2 * i], e = stamps[2 * i + 1];
-            if (e > b && b != 0x7fffffffffffffffLL) totals[i] += e - b;
-        }
-        totals[nslots] += 1;
+// end of a sweep: totals[i] += end_i - begin_i, totals[count] += 1.  Slot 5 is derived: the idle time between the end of
+// slot 7 (LOCAL) and the begin of slot 3 (FINISH1).  Slot numbers are include/sgp_hip.h's SGP_T_*.
+__device__ __forceinline__ void stamp_accumulate(int64_t* stamps, int64_t* totals) {
+    constexpr int NSLOTS = 8, SWEEP = 0, FINISH1 = 3, GAP = 5, LOCAL = 7;
+    stamps[2 * SWEEP + 1] = realtime_ticks();
+    const int64_t gb = stamps[2 * LOCAL + 1], ge = stamps[2 * FINISH1];
+    stamps[2 * GAP] = gb;
+    stamps[2 * GAP + 1] = (ge != 0x7fffffffffffffffLL) ? ge : gb;
+    for (int i = 0; i < NSLOTS; ++i) {
+        int64_t b = stamps[2 * i], e = stamps[2 * i + 1];
+        if (e > b && b != 0x7fffffffffffffffLL) totals[i] += e - b;
     }
+    totals[NSLOTS] += 1;
 }
 __global__ void k_stamp_reset(int64_t* stamps, int nslots) {
     int i = threadIdx.x;
@@ -76,16 +80,26 @@ __global__ void k_stamp_reset(int64_t* stamps, int nslots) {
 // ------------------------------------------------------------------------------------------------
 // Xu (D x M, AoS) -> Xus (SoA, scaled by 1/ell, padded to Mp with zeros)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_prep_xu(const double* __restrict__ Xu, double* __restrict__ Xus, const Params* __restrict__ P,
-                          int M, int Mp, int D, int64_t* stamps, int nslots, int sweep_slot) {
-    if (stamps && blockIdx.x == 0 && threadIdx.x < nslots) {        // first kernel of a sweep: reset the phase stamps
-        const int i = threadIdx.x;
-        stamps[2 * i] = (i == sweep_slot) ? realtime_ticks() : 0x7fffffffffffffffLL;
-        stamps[2 * i + 1] = 0;
+// `hP` is the handle's PINNED host copy of the parameters, read over the bus by this first kernel of a launch sequence
+// and mirrored into device memory (`dP`) for every later kernel -- one node less than a separate H2D copy in front of it.
+// Also resets the Cholesky status word of the sequence (`info_reset`) and, on the main stream, the phase stamps.
+__global__ void k_prep_xu(const double* __restrict__ Xu, double* __restrict__ Xus, const Params* __restrict__ hP,
+                          Params* __restrict__ dP, int* __restrict__ info_reset, int M, int Mp, int D, int64_t* stamps,
+                          int nslots, int sweep_slot) {
+    if (blockIdx.x == 0) {
+        if (stamps && threadIdx.x < nslots) {                       // first kernel of a sweep: reset the phase stamps
+            const int i = threadIdx.x;
+            stamps[2 * i] = (i == sweep_slot || i == nslots - 1) ? realtime_ticks() : 0x7fffffffffffffffLL;   // sweep and LOCAL begin here
+            stamps[2 * i + 1] = 0;
+        }
+        const double* src = reinterpret_cast<const double*>(hP);
+        double* dst = reinterpret_cast<double*>(dP);
+        for (int e = threadIdx.x; e < (int)(sizeof(Params) / sizeof(double)); e += blockDim.x) dst[e] = src[e];
+        if (info_reset && threadIdx.x == 0) *info_reset = 0;
     }
     int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= Mp) return;
-    for (int d = 0; d < D; ++d) Xus[(size_t)d * Mp + m] = (m < M) ? Xu[(size_t)m * D + d] * P->inv_ell[d] : 0.0;
+    for (int d = 0; d < D; ++d) Xus[(size_t)d * Mp + m] = (m < M) ? Xu[(size_t)m * D + d] * hP->inv_ell[d] : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -381,7 +395,7 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ slabs, const double* __restrict__ bpart,
                                                   const double* __restrict__ data_scalars, double* __restrict__ stats,
-                                                  int Mp, int ntiles, int nchunks, int nblk, int d_out, int nscal) {
+                                                  int Mp, int ntiles, int nchunks, int nblk, int d_out, int nscal, int64_t* stamps) {
     // grid (T, T, 4): block z sums rows [16 z, 16 z + 16) of the slab tile (I, J), I >= J, and writes both mirror images
     __shared__ double tile[16 * LT];
     const int I = blockIdx.x, J = blockIdx.y, z = blockIdx.z;
@@ -444,6 +458,7 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
         if (I == 0 && z == 0)
             for (int e = tid; e < nscal; e += 256) B[(size_t)Mp * d_out + e] = data_scalars[e];
     }
+    stamp_exit(stamps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -454,7 +469,10 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
 __global__ void __launch_bounds__(256) k_form_lambda(const double* __restrict__ stats, const double* __restrict__ Lambda0,
                                                      const double* __restrict__ xi0, double* __restrict__ Lam,
                                                      double* __restrict__ xi, const Params* __restrict__ P,
-                                                     int M, int Mp, int d_out, int Q, int Qp, int prior_form, int rev) {
+                                                     int M, int Mp, int d_out, int Q, int Qp, int prior_form, int rev, int64_t* stamps,
+                                                     int* __restrict__ info_reset) {
+    stamp_enter(stamps);
+    if (info_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *info_reset = 0;
     const int gi = blockIdx.x * TB + (threadIdx.x & 63);
     const int jg = threadIdx.x >> 6;
     const double* Psi2 = stats;
@@ -1197,13 +1215,14 @@ __global__ void __launch_bounds__(64) k_uv_partial(const double* __restrict__ Vt
 // pass 2, one wave per tile of the FULL tile grid: rows of tile (kb, jb) of Uv written into LR = Uv^T (zeros for kb > jb)
 __global__ void __launch_bounds__(64) k_uv_cols(const double* __restrict__ Vt, const double* __restrict__ p,
                                                 const double* __restrict__ ck, const double* __restrict__ ak,
-                                                const double* __restrict__ partial, double* __restrict__ LR, int Qp) {
+                                                const double* __restrict__ partial, double* __restrict__ LR, int Qp, int64_t* stamps) {
     const int kb = blockIdx.x, jb = blockIdx.y;
     const int lane = threadIdx.x, j = 64 * jb + lane;
     double* out = LR + (size_t)(64 * kb) * Qp + j;
     if (kb > jb) {
 #pragma unroll 16
         for (int kk = 0; kk < 64; ++kk) out[(size_t)kk * Qp] = 0.0;
+        stamp_exit(stamps);
         return;
     }
     const double* vp = Vt + (size_t)(Qp - 1 - 64 * kb) * Qp + (Qp - 1 - j);
@@ -1218,6 +1237,7 @@ __global__ void __launch_bounds__(64) k_uv_cols(const double* __restrict__ Vt, c
         out[(size_t)kk * Qp] = fma(ck[k], v[kk], ak[k] * T);
         T = fma(p[k], v[kk], T);
     }
+    stamp_exit(stamps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1244,8 +1264,9 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 
 __global__ void __launch_bounds__(256) k_trace_partial(const double* __restrict__ stats, const double* __restrict__ Kinv,
                                                        const double* __restrict__ R, double* __restrict__ partial,
-                                                       int M, int Mp, int d_out, int Qp) {
+                                                       int M, int Mp, int d_out, int Qp, int64_t* stamps) {
     __shared__ double red[4];
+    stamp_enter(stamps);
     const double* Psi2 = stats;
     const int tid = threadIdx.x;
     double t1 = 0.0;
@@ -1269,7 +1290,8 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
                                                  const double* __restrict__ Llam, const int* __restrict__ info,
                                                  const Params* __restrict__ P, double* __restrict__ out,
                                                  double* __restrict__ wishart, int M, int Mp, int d_out, int Q, int Qp,
-                                                 int nblocks, int lam_off) {
+                                                 int nblocks, int lam_off, int64_t* stamps, int64_t* all_stamps,
+                                                 int64_t* totals) {
     __shared__ double red[4];
     __shared__ double tr[TRACE_SLOTS];
     const double* B = stats + (size_t)Mp * Mp;
@@ -1333,6 +1355,9 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
         out[6] = ld_k;
         out[7] = ld_l;
     }
+    stamp_exit(stamps);
+    // last kernel of a sweep: close the sweep stamp and add this sweep's phase durations to the running totals
+    if (all_stamps && tid == 0) stamp_accumulate(all_stamps, totals);
 }
 
 // ------------------------------------------------------------------------------------------------

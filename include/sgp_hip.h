@@ -165,9 +165,11 @@ int sgp_potri(int32_t device, const double* A, int32_t n, double* Ainv);
 
 /* timing hooks for bench.py: device-side timestamps (100 MHz s_memrealtime) of the last sweep:
  * out[2*i], out[2*i+1] = begin/end ticks of phase i (SGP_T_SWEEP: whole sweep; SGP_T_GRAM / SGP_T_SYRK:
- * first-block-in / last-block-out of the K_uf and streaming-SYRK kernels). */
-enum { SGP_T_SWEEP = 0, SGP_T_GRAM = 1, SGP_T_SYRK = 2, SGP_T_CHOL_LAMBDA = 3, SGP_T_INVERSE = 4,
-       SGP_T_UV = 5, SGP_T_KUU = 6, SGP_T_COUNT = 8 };
+ * first-block-in / last-block-out of the K_uf and streaming-SYRK kernels; SGP_T_LOCAL: sweep begin .. statistics
+ * assembled; SGP_T_FINISH1: Lambda formed .. Uv written; SGP_T_FINISH2: traces .. scalars; SGP_T_GAP_LOCAL_FINISH:
+ * idle time on the main stream between LOCAL and FINISH1 -- launch latency plus, multi-GPU, the all-reduce). */
+enum { SGP_T_SWEEP = 0, SGP_T_GRAM = 1, SGP_T_SYRK = 2, SGP_T_FINISH1 = 3, SGP_T_FINISH2 = 4,
+       SGP_T_GAP_LOCAL_FINISH = 5, SGP_T_KUU = 6, SGP_T_LOCAL = 7, SGP_T_COUNT = 8 };
 int sgp_get_timestamps(sgp_handle* h, int64_t* out /* 2*SGP_T_COUNT */);
 /* Running totals of the per-sweep phase durations (same slots, 100 MHz ticks) over all sweeps since the last reset, and
  * the number of sweeps counted: the per-launch averages of the kernels INSIDE the timed graph replays. */

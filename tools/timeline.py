@@ -3,8 +3,8 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# sweeps are delimited by k_stamp_accumulate (the last kernel of a sweep)
-idx = [i for i, r in enumerate(rows) if "k_stamp_accumulate" in r["Kernel_Name"]]
+# sweeps are delimited by k_scalars (the last kernel of a sweep)
+idx = [i for i, r in enumerate(rows) if "k_scalars" in r["Kernel_Name"]]
 start = idx[-3] + 1 if len(idx) > 2 else 0
 end = idx[-2] + 1 if len(idx) > 2 else len(rows)
 t0 = int(rows[start]["Start_Timestamp"])
