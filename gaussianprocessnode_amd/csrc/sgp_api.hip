@@ -67,7 +67,7 @@ struct sgp_handle {
     Params* dParamsK = nullptr;    // the K_uu chain's own copy (it runs on the side stream)
     double* dXusK = nullptr;
     hipStream_t own = nullptr, side = nullptr;
-    hipEvent_t evFork = nullptr, evSide = nullptr;
+    hipEvent_t evFork = nullptr, evSide = nullptr, evStats = nullptr;
     int nchunks = 1, chunk = 0, nblk = 0, ntiles = 0;
     int64_t stats_count = 0;
     size_t slab_capacity = 0;
@@ -130,13 +130,17 @@ static void launch_trtri(const double* L, double* W, double* scratch, int ld, in
     if (!diag_done) hipLaunchKernelGGL(k_trtri_diag, dim3(Tn), dim3(256), 0, s, L, W, ld);
     for (int sz = 1; sz < Tn; sz *= 2) {
         int npairs = (Tn + 2 * sz - 1) / (2 * sz);
-        hipLaunchKernelGGL(k_gemm32, dim3(sz * sz * 4, npairs), dim3(256), 0, s, L, (const double*)W, scratch, ld, Tn, 1, sz, 0);
+        hipLaunchKernelGGL(k_gemm32, dim3(sz * sz * 4, npairs), dim3(256), 0, s, L, (const double*)W, scratch, ld, Tn, 1, sz, 0
+                           , (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
         hipLaunchKernelGGL(k_gemm32, dim3(sz * sz * 4, npairs), dim3(256), 0, s, (const double*)W, (const double*)scratch, W,
-                           ld, Tn, 2, sz, 0);
+                           ld, Tn, 2, sz, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
     }
 }
-static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s, int rev = 0) {
-    hipLaunchKernelGGL(k_gemm32, dim3(Tn * (Tn + 1) / 2 * 4), dim3(256), 0, s, W, W, C, ld, Tn, 0, 0, rev);
+// C = W^T W (rev: written index-reversed).  With mu: also R = C + mu mu^T, and with Psi2 the per-block shares of tr(R Psi2).
+static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s, int rev = 0, const double* mu = nullptr,
+                       double* R = nullptr, const double* Psi2 = nullptr, double* trace_part = nullptr) {
+    hipLaunchKernelGGL(k_gemm32, dim3(Tn * (Tn + 1) / 2 * 4), dim3(256), 0, s, W, W, C, ld, Tn, 0, 0, rev, mu, R, Psi2,
+                       trace_part);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -216,14 +220,14 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dUvT, Qp * Qp);
     ALLOC(h->dScratch, 3 * TB * TB);
     ALLOC(h->dOut2, SGP_R_COUNT);
-    ALLOC(h->dUvWork, (2 + (size_t)h->TQ) * Qp);
+    ALLOC(h->dUvWork, (3 + (size_t)h->TQ) * Qp);
     ALLOC(h->dLambda0, Qp * Qp);
     ALLOC(h->dXi, Qp);
     ALLOC(h->dMu, Qp);
     ALLOC(h->dXi0, Qp);
     ALLOC(h->dOut, SGP_R_COUNT);
     ALLOC(h->dWishart, MAXO * MAXO);
-    ALLOC(h->dTrace, (size_t)TRACE_BLOCKS * TRACE_SLOTS);
+    ALLOC(h->dTrace, (size_t)TRACE_BLOCKS + std::max((size_t)TRACE_BLOCKS * MAXO * MAXO, (size_t)h->TQ * (h->TQ + 1) * 2));
     ALLOC(h->dInfo, 4);
     ALLOC(h->dStamps, 2 * SGP_T_COUNT);
     ALLOC(h->dStampTotals, SGP_T_COUNT + 1);
@@ -249,7 +253,8 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     if (hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->evSide, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->evSide, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evStats, hipEventDisableTiming) != hipSuccess) {
         g_create_error = "stream/event creation failed";
         sgp_destroy(h);
         return SGP_ERR_HIP;
@@ -281,6 +286,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evFork) hipEventDestroy(h->evFork);
     if (h->evSide) hipEventDestroy(h->evSide);
+    if (h->evStats) hipEventDestroy(h->evStats);
     if (h->own) hipStreamDestroy(h->own);
     if (h->side) hipStreamDestroy(h->side);
     delete h;
@@ -533,29 +539,39 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
                        h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form, 1, h->dStamps + 2 * SGP_T_FINISH1, h->dInfo + 1);
     launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl);
     launch_trtri(h->dLam, h->dWl, h->dSigma, Qp, TQ, s, true);
-    launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1);
-    hipLaunchKernelGGL(k_symv, dim3((Qp + 3) / 4), dim3(256), 0, s, h->dSigma, h->dXi, h->dMu, Qp, Qp);
-    hipLaunchKernelGGL(k_form_R, dim3(TQ, TQ), dim3(256), 0, s, h->dSigma, h->dMu, h->dR, Q, Qp, (const double*)h->dWl,
-                       h->dTmp);
-    // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69)
-    double* uvp = h->dXi;                    // xi is consumed: p
+    // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
+    // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
+    double* uvp = h->dXi;                    // xi is consumed by k_trmv_t; p lands in the same vector afterwards
     double* uvck = h->dUvWork;               // C_kk
     double* uvak = h->dUvWork + Qp;          // p_k / sqrt(alpha_k alpha_{k+1})
-    double* uvpart = h->dUvWork + 2 * (size_t)Qp;   // TQ x Qp tile partial sums
-    hipLaunchKernelGGL(k_uv_p, dim3((Qp + 3) / 4), dim3(256), 0, s, h->dLam, h->dMu, uvp, Qp);
-    hipLaunchKernelGGL(k_uv_scan, dim3(1), dim3(64), 0, s, uvp, uvck, uvak, Qp);
-    hipLaunchKernelGGL(k_uv_partial, dim3(TQ * (TQ + 1) / 2), dim3(64), 0, s, h->dTmp, uvp, uvpart, Qp);
-    hipLaunchKernelGGL(k_uv_cols, dim3(TQ, TQ), dim3(64), 0, s, h->dTmp, uvp, uvck, uvak, uvpart, h->dUvT, Qp,
+    double* uvt = h->dUvWork + 2 * (size_t)Qp;      // t = W' P xi
+    double* uvpart = h->dUvWork + 3 * (size_t)Qp;   // TQ x Qp tile partial sums
+    hipLaunchKernelGGL(k_trmv_t, dim3(TQ), dim3(256), 0, s, (const double*)h->dWl, (const double*)h->dXi, uvt, Qp);
+    hipLaunchKernelGGL(k_trmv_mu_scan, dim3(Qp / 4 + 1), dim3(256), 0, s, (const double*)h->dWl, (const double*)uvt, h->dMu,
+                       uvp, uvck, uvak, Qp);
+    // Sigma = W'^T W' (index-reversed back), R = Sigma + mu mu^T and -- UniSGP -- the tr(R Psi2) shares, one launch
+    double* traceR = h->dTrace + TRACE_BLOCKS;
+    if (h->dout == 1) {
+        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, h->dStats, traceR);
+    } else {
+        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR);
+        hipLaunchKernelGGL(k_trace_R, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dR, traceR, M, Mp, h->dout, Qp,
+                           (int64_t*)nullptr);
+    }
+    // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69)
+    hipLaunchKernelGGL(k_uv_partial, dim3(TQ * (TQ + 1) / 2), dim3(64), 0, s, (const double*)h->dWl, uvp, uvpart, Qp);
+    hipLaunchKernelGGL(k_uv_cols, dim3(TQ, TQ), dim3(64), 0, s, (const double*)h->dWl, uvp, uvck, uvak, uvpart, h->dUvT, Qp,
                        h->dStamps + 2 * SGP_T_FINISH1);
 }
 
+// after the join with the side stream (K_uu chain + tr(Kuu^-1 Psi2)): the scalars, one single-workgroup kernel
 static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
-    hipLaunchKernelGGL(k_trace_partial, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dR, h->dTrace, M, Mp,
-                       h->dout, Qp, h->dStamps + 2 * SGP_T_FINISH2);
-    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, h->dTrace, h->dMu, h->dKuu, h->dLam, h->dInfo,
-                       h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS, Qp - Q,
-                       h->dStamps + 2 * SGP_T_FINISH2, h->dStamps, h->dStampTotals);
+    const int nR = (h->dout == 1) ? h->TQ * (h->TQ + 1) / 2 * 4 : TRACE_BLOCKS;
+    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, (const double*)h->dTrace, (int)TRACE_BLOCKS,
+                       (const double*)(h->dTrace + TRACE_BLOCKS), nR, h->dMu, h->dKuu, h->dLam, h->dInfo, h->dParams, h->dOut,
+                       h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q, h->dStamps + 2 * SGP_T_FINISH2, h->dStamps,
+                       h->dStampTotals);
 }
 
 typedef void (*enqueue_fn)(sgp_handle*, hipStream_t);
@@ -609,25 +625,36 @@ extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) {
     return 0;
 }
 
-extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
+// `stats_final_at_fork`: the statistics were already final when sgp_sweep_local forked the side stream (single-GPU
+// sgp_sweep); otherwise (an all-reduce sits between the two halves) the side stream first waits for the caller's stream.
+static int sweep_finish_impl(sgp_handle* h, void* stream, bool stats_final_at_fork) {
     if (!h) return SGP_ERR_ARG;
     if (!h->swept_local) return fail(h, SGP_ERR_ARG, "sgp_sweep_finish: call sgp_sweep_local first");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
     h->in_flight = true;
+    // side stream, behind the K_uu chain: tr(Kuu^-1 Psi2) of the (by now reduced) statistics -- off the critical path
+    if (!stats_final_at_fork) {
+        HIPCHK(h, hipEventRecord(h->evStats, s));
+        HIPCHK(h, hipStreamWaitEvent(h->side, h->evStats, 0));
+    }
+    hipLaunchKernelGGL(k_trace_kinv, dim3(TRACE_BLOCKS), dim3(256), 0, h->side, h->dStats, h->dKinv, h->dTrace, h->M, h->Mp);
+    HIPCHK(h, hipEventRecord(h->evSide, h->side));
     int rc = run_sequence(h, h->gFinish, enqueue_finish1, s);
     if (rc) return rc;
-    HIPCHK(h, hipStreamWaitEvent(s, h->evSide, 0));          // join with the K_uu chain
+    HIPCHK(h, hipStreamWaitEvent(s, h->evSide, 0));          // join with the side stream
     rc = run_sequence(h, h->gFinish2, enqueue_finish2, s);
     if (rc) return rc;
     h->swept = true;
     return 0;
 }
 
+extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) { return sweep_finish_impl(h, stream, false); }
+
 extern "C" int sgp_sweep(sgp_handle* h, void* stream) {
     int rc = sgp_sweep_local(h, stream);
     if (rc) return rc;
-    return sgp_sweep_finish(h, stream);
+    return sweep_finish_impl(h, stream, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -865,11 +892,13 @@ static int theta_objective_eval(sgp_handle* h, hipStream_t s, double* value) {
     enqueue_kuu(h, s);
     enqueue_local(h, s);
     const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
-    hipLaunchKernelGGL(k_trace_partial, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dR, h->dTrace, M, Mp,
-                       h->dout, Qp, (int64_t*)nullptr);
-    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, h->dTrace, h->dMu, h->dKuu, h->dLam, h->dInfo,
-                       h->dParams, h->dOut2, h->dWishart, M, Mp, h->dout, Q, Qp, TRACE_BLOCKS, Qp - Q, (int64_t*)nullptr,
-                       (int64_t*)nullptr, (int64_t*)nullptr);
+    hipLaunchKernelGGL(k_trace_kinv, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dTrace, M, Mp);
+    hipLaunchKernelGGL(k_trace_R, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dR, h->dTrace + TRACE_BLOCKS, M, Mp, h->dout,
+                       Qp, (int64_t*)nullptr);
+    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, (const double*)h->dTrace, (int)TRACE_BLOCKS,
+                       (const double*)(h->dTrace + TRACE_BLOCKS), (int)TRACE_BLOCKS, h->dMu, h->dKuu, h->dLam, h->dInfo, h->dParams,
+                       h->dOut2, h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q, (int64_t*)nullptr, (int64_t*)nullptr,
+                       (int64_t*)nullptr);
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     double out[SGP_R_COUNT], sc[SGP_S_COUNT];
@@ -929,9 +958,9 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     const int n_uf = h->n > 0 ? h->nblk * T : 0;
     hipLaunchKernelGGL(k_form_G, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->dR, h->dKinv, dG, cnt);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)h->dKinv, (const double*)h->dStats, dT1,
-                       Mp, T, 3, 0, 0);
+                       Mp, T, 3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)dT1, (const double*)h->dKinv, dH, Mp, T,
-                       3, 0, 0);
+                       3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
     if (h->n > 0)
         hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
                            h->has_omega ? h->dOmega : nullptr, h->dMu, h->dParams, part_uf, Mp, T, h->D, h->n);

@@ -44,6 +44,17 @@ struct Params {
 
 __device__ __forceinline__ int64_t realtime_ticks() { return (int64_t)__builtin_amdgcn_s_memrealtime(); }
 
+// deterministic workgroup sum (wave butterflies, then the waves in order); `red` = one double of LDS per wave
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // timestamp marker: one thread writes the 100 MHz constant clock (bench.py's per-phase durations)
 // ------------------------------------------------------------------------------------------------
@@ -1055,10 +1066,15 @@ __device__ __forceinline__ void load_panel32_t(double* panel, const double* __re
     }
 }
 
+// mode 0 extras (all nullable): with `mu` the kernel also writes R = C + mu mu^T (Sigma_v + mu mu^T, GPnode/UniSGPnode.jl:67)
+// and, with `Psi2`, the block's share of tr(R Psi2) into trace_part[blockIdx.x] (the sum I2 trace of :196-238, d_out = 1).
 __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
-                                                int ld, int Tn, int mode, int s, int rev) {
+                                                int ld, int Tn, int mode, int s, int rev, const double* __restrict__ mu,
+                                                double* __restrict__ R, const double* __restrict__ Psi2,
+                                                double* __restrict__ trace_part) {
     __shared__ double As[64 * PS32];
     __shared__ double Bs[64 * PS32];
+    __shared__ double tred[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int quad = blockIdx.x & 3, qi = quad >> 1, qj = quad & 1;
     int I, J, kbeg, kend;
@@ -1088,6 +1104,7 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
 #pragma unroll
         for (int k4 = 0; k4 < 16; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k4 * 4 * PS32], bp[k4 * 4 * PS32], acc, 0, 0, 0);
     }
+    double tsum = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         int row = r0 + wr * 16 + lk + 4 * r, col = c0 + wc * 16 + li;
@@ -1096,9 +1113,21 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
             if (rev) { row = ld - 1 - row; col = ld - 1 - col; }
             C[(size_t)col * ld + row] = v;
             C[(size_t)row * ld + col] = v;       // mirror (on diagonal tiles two quadrants write the same bits twice)
+            if (mu) {
+                const double rv = fma(mu[row], mu[col], v);
+                R[(size_t)col * ld + row] = rv;
+                R[(size_t)row * ld + col] = rv;
+                if (Psi2) tsum = fma(rv, Psi2[(size_t)col * ld + row], tsum);
+            }
         } else {
             C[(size_t)col * ld + row] = (mode == 2) ? -v : v;
         }
+    }
+    if (mode == 0 && trace_part) {
+        // off-diagonal tiles stand for both mirror images; on diagonal tiles all four quadrants are computed
+        if (I != J) tsum *= 2.0;
+        tsum = block_sum(tsum, tred);
+        if (tid == 0) trace_part[blockIdx.x] = tsum;
     }
 }
 
@@ -1115,34 +1144,6 @@ __global__ void __launch_bounds__(256) k_symv(const double* __restrict__ S, cons
     if (lane == 0) y[row] = s;
 }
 
-// R = Sigma + mu mu^T on the first q entries, identity pad kept
-// also transposes W (-> Wt) when given: one launch instead of two on the latency-bound tail
-__global__ void __launch_bounds__(256) k_form_R(const double* __restrict__ Sigma, const double* __restrict__ mu,
-                                                double* __restrict__ R, int Q, int Qp, const double* __restrict__ W,
-                                                double* __restrict__ Wt) {
-    __shared__ double tile[TB * LT];
-    const int gi = blockIdx.x * TB + (threadIdx.x & 63);
-    const int jg = threadIdx.x >> 6;
-    for (int jj = 0; jj < 16; ++jj) {
-        int gj = blockIdx.y * TB + jg * 16 + jj;
-        double v = Sigma[(size_t)gj * Qp + gi];
-        if (gi < Q && gj < Q) v = fma(mu[gi], mu[gj], v);
-        R[(size_t)gj * Qp + gi] = v;
-    }
-    if (W) {
-        const int I = blockIdx.x * TB, J = blockIdx.y * TB;
-        for (int e = threadIdx.x; e < TB * TB; e += 256) {
-            int c = e >> 6, r = e & 63;
-            tile[r * LT + c] = W[(size_t)(J + c) * Qp + I + r];
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < TB * TB; e += 256) {
-            int c = e >> 6, r = e & 63;
-            Wt[(size_t)(I + c) * Qp + J + r] = tile[c * LT + r];
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69) WITHOUT a third factorisation and without a sequential
 // rank-1 update.  Lambda was factored in index-reversed order, P Lambda P = L' L'^T, so with W' = L'^-1
@@ -1153,59 +1154,92 @@ __global__ void __launch_bounds__(256) k_form_R(const double* __restrict__ Sigma
 // hence  Uv = C V,   Uv[k][j] = C_kk V[k][j] + (p_k / sqrt(alpha_k alpha_{k+1})) * sum_{m=k+1..j} p_m V[m][j].
 // Everything is parallel over the columns j; the sum is a running suffix sum down each column (no cancellation:
 // it is accumulated directly, not as x_j minus a prefix).
-//   k_uv_p       : p_i = sum_{j<=i} L'[r(j)][r(i)] mu_j,  r(i) = Qp-1-i   (column r(i) of L' is contiguous)
-//   k_uv_scan    : alpha scan -> C_kk and p_k / sqrt(alpha_k alpha_{k+1})
+// p costs nothing extra: mu = Sigma xi = P W'^T W' P xi, so with t = W' (P xi) one has mu = P W'^T t and
+// p = P L'^T P mu = P L'^T W'^T t = P t.
+//   k_trmv_t       : t = W' (P xi)
+//   k_trmv_mu_scan : mu = P W'^T t, p = P t, alpha scan -> C_kk and p_k / sqrt(alpha_k alpha_{k+1})
 //   k_uv_partial : per 64-row tile and column, sum_m p_m V[m][j]   (so that tiles can start their suffix sums independently)
 //   k_uv_cols    : one wave per 64 x 64 tile, 64 rows in registers, writes the rows of Uv
-// Vt holds W'^T column-major (written by k_form_R), so that V[k][j] = Vt[(Qp-1-j) + (Qp-1-k) * Qp] is coalesced over j.
+// V[k][j] = W'[Qp-1-k][Qp-1-j] is read straight from the inverse factor (load_v_column).
 // Output LR = Uv^T (lower, column-major: column k = row k of Uv), the layout potrf(R) would have produced.
 // ------------------------------------------------------------------------------------------------
 constexpr int CU_MAXQ = 4096;
 
-__global__ void __launch_bounds__(256) k_uv_p(const double* __restrict__ Lrev, const double* __restrict__ mu,
-                                              double* __restrict__ p, int Qp) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= Qp) return;
-    const int ri = Qp - 1 - i;
-    const double* col = Lrev + (size_t)ri * Qp;          // L'[a][ri], a >= ri
-    double s = 0.0;
-    for (int a = ri + lane; a < Qp; a += 64) s = fma(col[a], mu[Qp - 1 - a], s);
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) p[i] = s;
+// t = W' (P xi): lower-triangular mat-vec, one 64-row block per workgroup, the k range split over the four waves.
+// (W' column-major: a fixed column is contiguous over the rows, so the lanes walk rows and the loop walks columns.)
+__global__ void __launch_bounds__(256) k_trmv_t(const double* __restrict__ W, const double* __restrict__ xi,
+                                                double* __restrict__ t, int Qp) {
+    __shared__ double red[4][64];
+    const int I = blockIdx.x, r = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int kend = 64 * (I + 1);                       // the strict upper part of the diagonal tile is stored as zeros
+    const double* base = W + 64 * I + r;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int k = part; k < kend; k += 16) {              // kend is a multiple of 64: the four sub-steps stay in range
+        s0 = fma(base[(size_t)k * Qp], xi[Qp - 1 - k], s0);
+        s1 = fma(base[(size_t)(k + 4) * Qp], xi[Qp - 5 - k], s1);
+        s2 = fma(base[(size_t)(k + 8) * Qp], xi[Qp - 9 - k], s2);
+        s3 = fma(base[(size_t)(k + 12) * Qp], xi[Qp - 13 - k], s3);
+    }
+    red[part][r] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (part == 0) t[64 * I + r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
 }
 
-// alpha scan (one wave): ck[k] = C_kk, ak[k] = p_k / sqrt(alpha_k alpha_{k+1})
-__global__ void __launch_bounds__(64) k_uv_scan(const double* __restrict__ p, double* __restrict__ ck, double* __restrict__ ak, int Qp) {
-    const int lane = threadIdx.x;
-    const int per = (Qp + 63) / 64;
-    const int e0 = lane * per, e1 = min((lane + 1) * per, Qp);
-    double loc = 0.0;
-    for (int e = e0; e < e1; ++e) { double v = p[e]; loc = fma(v, v, loc); }
-    double inc = loc;
-    for (int o = 1; o < 64; o <<= 1) {
-        double t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
+// mu = P W'^T t (one wave per column of W'), p = P t, and -- in the extra last workgroup -- the alpha scan of p:
+// ck[k] = C_kk, ak[k] = p_k / sqrt(alpha_k alpha_{k+1}).
+__global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__ W, const double* __restrict__ t,
+                                                      double* __restrict__ mu, double* __restrict__ p,
+                                                      double* __restrict__ ck, double* __restrict__ ak, int Qp) {
+    const int lane = threadIdx.x & 63;
+    if ((int)blockIdx.x == Qp / 4) {
+        if (threadIdx.x >= 64) return;
+        const int per = (Qp + 63) / 64;
+        const int e0 = lane * per, e1 = min((lane + 1) * per, Qp);
+        double loc = 0.0;
+        for (int e = e0; e < e1; ++e) { double v = t[Qp - 1 - e]; p[e] = v; loc = fma(v, v, loc); }
+        double inc = loc;
+        for (int o = 1; o < 64; o <<= 1) {
+            double u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        double alpha = 1.0 + (inc - loc);
+        for (int e = e0; e < e1; ++e) {
+            const double pe = t[Qp - 1 - e], an = fma(pe, pe, alpha);
+            const double ir = 1.0 / sqrt(alpha * an);
+            ck[e] = an * ir;
+            ak[e] = pe * ir;
+            alpha = an;
+        }
+        return;
     }
-    double alpha = 1.0 + (inc - loc);
-    for (int e = e0; e < e1; ++e) {
-        const double pe = p[e], an = fma(pe, pe, alpha);
-        const double ir = 1.0 / sqrt(alpha * an);
-        ck[e] = an * ir;
-        ak[e] = pe * ir;
-        alpha = an;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const double* col = W + (size_t)k * Qp;
+    double s = 0.0;
+    for (int i = k + lane; i < Qp; i += 64) s = fma(col[i], t[i], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) mu[Qp - 1 - k] = s;
+}
+
+// v[kk] = V[64 kb + kk][j] = W'[Qp-1-64kb-kk][Qp-1-j]: 64 contiguous doubles of column Qp-1-j of W' (descending), read
+// straight from the inverse factor -- every lane its own 512-byte run, fully used, so no transposed copy is needed.
+__device__ __forceinline__ void load_v_column(double (&v)[64], const double* __restrict__ Wp, int Qp, int kb, int j) {
+    const double2* src = reinterpret_cast<const double2*>(Wp + (size_t)(Qp - 1 - j) * Qp + (Qp - 64 * (kb + 1)));
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const double2 w = src[u];
+        v[63 - 2 * u] = w.x;
+        v[62 - 2 * u] = w.y;
     }
 }
 
 // pass 1, one wave per 64 x 64 tile (kb <= jb) of V: partial[kb][j] = sum_{kk} p_{64 kb + kk} V[64 kb + kk][j]
-__global__ void __launch_bounds__(64) k_uv_partial(const double* __restrict__ Vt, const double* __restrict__ p,
+__global__ void __launch_bounds__(64) k_uv_partial(const double* __restrict__ Wp, const double* __restrict__ p,
                                                    double* __restrict__ partial, int Qp) {
     int jb, kb;
     tile_from_index(blockIdx.x, jb, kb);                 // jb >= kb
     const int lane = threadIdx.x, j = 64 * jb + lane;
-    const double* vp = Vt + (size_t)(Qp - 1 - 64 * kb) * Qp + (Qp - 1 - j);
     double v[64];
-#pragma unroll
-    for (int kk = 0; kk < 64; ++kk) v[kk] = vp[-(ptrdiff_t)kk * Qp];
+    load_v_column(v, Wp, Qp, kb, j);
     double s = 0.0;
 #pragma unroll
     for (int kk = 0; kk < 64; ++kk) s = fma(p[64 * kb + kk], v[kk], s);
@@ -1213,7 +1247,7 @@ __global__ void __launch_bounds__(64) k_uv_partial(const double* __restrict__ Vt
 }
 
 // pass 2, one wave per tile of the FULL tile grid: rows of tile (kb, jb) of Uv written into LR = Uv^T (zeros for kb > jb)
-__global__ void __launch_bounds__(64) k_uv_cols(const double* __restrict__ Vt, const double* __restrict__ p,
+__global__ void __launch_bounds__(64) k_uv_cols(const double* __restrict__ Wp, const double* __restrict__ p,
                                                 const double* __restrict__ ck, const double* __restrict__ ak,
                                                 const double* __restrict__ partial, double* __restrict__ LR, int Qp, int64_t* stamps) {
     const int kb = blockIdx.x, jb = blockIdx.y;
@@ -1225,10 +1259,8 @@ __global__ void __launch_bounds__(64) k_uv_cols(const double* __restrict__ Vt, c
         stamp_exit(stamps);
         return;
     }
-    const double* vp = Vt + (size_t)(Qp - 1 - 64 * kb) * Qp + (Qp - 1 - j);
     double v[64];
-#pragma unroll
-    for (int kk = 0; kk < 64; ++kk) v[kk] = vp[-(ptrdiff_t)kk * Qp];
+    load_v_column(v, Wp, Qp, kb, j);
     double T = 0.0;
     for (int b = jb; b > kb; --b) T += partial[(size_t)b * Qp + j];       // rows below this tile, nearest first... fixed order
 #pragma unroll
@@ -1252,28 +1284,29 @@ __global__ void __launch_bounds__(64) k_uv_cols(const double* __restrict__ Vt, c
 constexpr int TRACE_BLOCKS = 64;
 constexpr int TRACE_SLOTS = 1 + MAXO * MAXO;
 
-__device__ __forceinline__ double block_sum(double v, double* red) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double s = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
-    return s;
-}
 
-__global__ void __launch_bounds__(256) k_trace_partial(const double* __restrict__ stats, const double* __restrict__ Kinv,
-                                                       const double* __restrict__ R, double* __restrict__ partial,
-                                                       int M, int Mp, int d_out, int Qp, int64_t* stamps) {
+// partial[g] = block g's share of tr(Kuu^-1 Psi2)
+__global__ void __launch_bounds__(256) k_trace_kinv(const double* __restrict__ stats, const double* __restrict__ Kinv,
+                                                    double* __restrict__ partial, int M, int Mp) {
     __shared__ double red[4];
-    stamp_enter(stamps);
     const double* Psi2 = stats;
     const int tid = threadIdx.x;
     double t1 = 0.0;
     for (int j = blockIdx.x; j < M; j += gridDim.x)
         for (int i = tid; i < M; i += 256) t1 = fma(Kinv[(size_t)j * Mp + i], Psi2[(size_t)j * Mp + i], t1);
     t1 = block_sum(t1, red);
-    if (tid == 0) partial[blockIdx.x * TRACE_SLOTS] = t1;
+    if (tid == 0) partial[blockIdx.x] = t1;
+}
+
+// partial[g * d_out^2 + a + b d_out] = block g's share of tr(Rblk[a][b] Psi2)   (MultiSGP, and the theta objective at a
+// new theta; the UniSGP sweep gets this trace from the epilogue of the Sigma = W^T W product instead)
+__global__ void __launch_bounds__(256) k_trace_R(const double* __restrict__ stats, const double* __restrict__ R,
+                                                 double* __restrict__ partial, int M, int Mp, int d_out, int Qp,
+                                                 int64_t* stamps) {
+    __shared__ double red[4];
+    stamp_enter(stamps);
+    const double* Psi2 = stats;
+    const int tid = threadIdx.x;
     for (int a = 0; a < d_out; ++a)
         for (int b = 0; b < d_out; ++b) {
             double t2 = 0.0;
@@ -1281,26 +1314,31 @@ __global__ void __launch_bounds__(256) k_trace_partial(const double* __restrict_
                 for (int i = tid; i < M; i += 256)
                     t2 = fma(R[(size_t)(b * M + j) * Qp + a * M + i], Psi2[(size_t)j * Mp + i], t2);
             t2 = block_sum(t2, red);
-            if (tid == 0) partial[blockIdx.x * TRACE_SLOTS + 1 + a + b * d_out] = t2;
+            if (tid == 0) partial[(size_t)blockIdx.x * d_out * d_out + a + b * d_out] = t2;
         }
 }
 
-__global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stats, const double* __restrict__ partial,
+__global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stats, const double* __restrict__ partK, int nK,
+                                                 const double* __restrict__ partR, int nR,
                                                  const double* __restrict__ mu, const double* __restrict__ Lkuu,
                                                  const double* __restrict__ Llam, const int* __restrict__ info,
                                                  const Params* __restrict__ P, double* __restrict__ out,
                                                  double* __restrict__ wishart, int M, int Mp, int d_out, int Q, int Qp,
-                                                 int nblocks, int lam_off, int64_t* stamps, int64_t* all_stamps,
+                                                 int lam_off, int64_t* stamps, int64_t* all_stamps,
                                                  int64_t* totals) {
     __shared__ double red[4];
     __shared__ double tr[TRACE_SLOTS];
+    stamp_enter(stamps);
     const double* B = stats + (size_t)Mp * Mp;
     const double* sc = B + (size_t)Mp * d_out;
     const int tid = threadIdx.x;
-    {   // wave w reduces slots w, w + 4, ...: lane l holds block l's partial (nblocks <= 64), butterfly sum
-        const int lane = tid & 63, wave = tid >> 6;
-        for (int slot = wave; slot < 1 + d_out * d_out; slot += 4) {
-            double v = (lane < nblocks) ? partial[lane * TRACE_SLOTS + slot] : 0.0;
+    {   // wave w reduces slots w, w + 4, ... (slot 0: tr(Kuu^-1 Psi2), slot 1 + a + b d_out: tr(Rblk[a][b] Psi2)):
+        // the lanes stride over the block partials in a fixed order, then a butterfly sum
+        const int lane = tid & 63, wave = tid >> 6, nslotR = d_out * d_out;
+        for (int slot = wave; slot < 1 + nslotR; slot += 4) {
+            double v = 0.0;
+            if (slot == 0) { for (int b = lane; b < nK; b += 64) v += partK[b]; }
+            else           { for (int b = lane; b < nR; b += 64) v += partR[(size_t)b * nslotR + slot - 1]; }
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
             if (lane == 0) tr[slot] = v;
         }
