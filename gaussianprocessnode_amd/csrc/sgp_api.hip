@@ -229,7 +229,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dWishart, MAXO * MAXO);
     ALLOC(h->dTrace, (size_t)TRACE_BLOCKS + std::max((size_t)TRACE_BLOCKS * MAXO * MAXO, (size_t)h->TQ * (h->TQ + 1) * 2));
     ALLOC(h->dInfo, 4);
-    ALLOC(h->dStamps, 2 * SGP_T_COUNT);
+    ALLOC(h->dStamps, STAMP_STRIDE * SGP_T_COUNT);
     ALLOC(h->dStampTotals, SGP_T_COUNT + 1);
     ALLOC(h->dParams, 1);
     ALLOC(h->dParamsK, 1);
@@ -261,7 +261,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     }
     hipMemset(h->dInfo, 0, 4 * sizeof(int));
     hipMemset(h->dOut, 0, SGP_R_COUNT * sizeof(double));
-    hipMemset(h->dStamps, 0, 2 * SGP_T_COUNT * sizeof(int64_t));
+    hipMemset(h->dStamps, 0, STAMP_STRIDE * SGP_T_COUNT * sizeof(int64_t));
     hipMemset(h->dStampTotals, 0, (SGP_T_COUNT + 1) * sizeof(int64_t));
     hipMemset(h->dMu, 0, Qp * sizeof(double));
     hipMemset(h->dXi0, 0, Qp * sizeof(double));
@@ -521,14 +521,14 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
                        h->dParams, (int*)nullptr, M, Mp, D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP);
     if (h->n > 0) {
         hipLaunchKernelGGL(k_gram_uf, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
-                           h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + 2 * SGP_T_GRAM);
+                           h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM);
         hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                            h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, h->ntiles, h->nchunks,
-                           h->dStamps + 2 * SGP_T_SYRK);
+                           h->dStamps + STAMP_STRIDE * SGP_T_SYRK);
     }
     hipLaunchKernelGGL(k_assemble, dim3(T, T, 4), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
                        h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
-                       SGP_S_COUNT + h->dout * h->dout, h->dStamps + 2 * SGP_T_LOCAL);
+                       SGP_S_COUNT + h->dout * h->dout, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL);
 }
 
 static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
@@ -536,7 +536,7 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     // Lambda is factored in index-reversed order (P Lambda P = L' L'^T): its inverse factor W' = L'^-1 then IS the upper
     // Cholesky factor of Sigma_v up to the reversal, and Uv follows by a rank-1 update instead of a third potrf.
     hipLaunchKernelGGL(k_form_lambda, dim3(TQ, TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dLam, h->dXi,
-                       h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form, 1, h->dStamps + 2 * SGP_T_FINISH1, h->dInfo + 1);
+                       h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form, 1, h->dStamps + STAMP_STRIDE * SGP_T_FINISH1, h->dInfo + 1);
     launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl);
     launch_trtri(h->dLam, h->dWl, h->dSigma, Qp, TQ, s, true);
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
@@ -561,7 +561,7 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69)
     hipLaunchKernelGGL(k_uv_partial, dim3(TQ * (TQ + 1) / 2), dim3(64), 0, s, (const double*)h->dWl, uvp, uvpart, Qp);
     hipLaunchKernelGGL(k_uv_cols, dim3(TQ, TQ), dim3(64), 0, s, (const double*)h->dWl, uvp, uvck, uvak, uvpart, h->dUvT, Qp,
-                       h->dStamps + 2 * SGP_T_FINISH1);
+                       h->dStamps + STAMP_STRIDE * SGP_T_FINISH1);
 }
 
 // after the join with the side stream (K_uu chain + tr(Kuu^-1 Psi2)): the scalars, one single-workgroup kernel
@@ -570,7 +570,7 @@ static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
     const int nR = (h->dout == 1) ? h->TQ * (h->TQ + 1) / 2 * 4 : TRACE_BLOCKS;
     hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, (const double*)h->dTrace, (int)TRACE_BLOCKS,
                        (const double*)(h->dTrace + TRACE_BLOCKS), nR, h->dMu, h->dKuu, h->dLam, h->dInfo, h->dParams, h->dOut,
-                       h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q, h->dStamps + 2 * SGP_T_FINISH2, h->dStamps,
+                       h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q, h->dStamps + STAMP_STRIDE * SGP_T_FINISH2, h->dStamps,
                        h->dStampTotals);
 }
 
@@ -755,7 +755,8 @@ extern "C" int sgp_get_timestamps(sgp_handle* h, int64_t* out) {
     if (!h || !out) return SGP_ERR_ARG;
     int rc = sync_all(h);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpy(out, h->dStamps, 2 * SGP_T_COUNT * sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy2D(out, 2 * sizeof(int64_t), h->dStamps, STAMP_STRIDE * sizeof(int64_t), 2 * sizeof(int64_t), SGP_T_COUNT,
+                          hipMemcpyDeviceToHost));
     return 0;
 }
 

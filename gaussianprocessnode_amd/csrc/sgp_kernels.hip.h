@@ -58,34 +58,48 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 // ------------------------------------------------------------------------------------------------
 // timestamp marker: one thread writes the 100 MHz constant clock (bench.py's per-phase durations)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_stamp(int64_t* slot) {
-    if (threadIdx.x == 0) *slot = realtime_ticks();
+// Phase stamps.  One record of STAMP_STRIDE int64 per phase slot: [0] begin, [1] end, [2 .. 65] exit ticks spread over
+// 64 addresses.  Every workgroup stamping the SAME address was measured to cost 18 us on the K_uf kernel and 9 us on the
+// streaming SYRK (1256 / 1152 same-address 64-bit atomics serialise at ~14 ns each, and the entry atomic sits in front of
+// the workgroup's first loads): the entry is therefore stamped by workgroup 0 alone (the first dispatched), the exits by
+// every workgroup but onto 64 different addresses, folded into `end` by stamp_accumulate.
+constexpr int STAMP_STRIDE = 2 + 64;
+__device__ __forceinline__ void stamp_enter(int64_t* rec) {
+    if (rec && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        atomicMin(reinterpret_cast<long long*>(rec), (long long)realtime_ticks());
 }
-// first-block-in / last-block-out stamps of a multi-block kernel: stamps[0] = min entry, stamps[1] = max exit
-__device__ __forceinline__ void stamp_enter(int64_t* stamps) {
-    if (stamps && threadIdx.x == 0) atomicMin(reinterpret_cast<long long*>(stamps), (long long)realtime_ticks());
+__device__ __forceinline__ void stamp_exit(int64_t* rec) {
+    if (rec && threadIdx.x == 0)
+        atomicMax(reinterpret_cast<long long*>(rec + 2 + ((blockIdx.x + 7 * blockIdx.y) & 63)), (long long)realtime_ticks());
 }
-__device__ __forceinline__ void stamp_exit(int64_t* stamps) {
-    if (stamps && threadIdx.x == 0) atomicMax(reinterpret_cast<long long*>(stamps + 1), (long long)realtime_ticks());
-}
-// end-of-sweep stamp + running totals over sweeps: totals[i] += end_i - begin_i, totals[nslots] += 1
-// end of a sweep: totals[i] += end_i - begin_i, totals[count] += 1.  Slot 5 is derived: the idle time between the end of
-// slot 7 (LOCAL) and the begin of slot 3 (FINISH1).  Slot numbers are include/sgp_hip.h's SGP_T_*.
-__device__ __forceinline__ void stamp_accumulate(int64_t* stamps, int64_t* totals) {
-    constexpr int NSLOTS = 8, SWEEP = 0, FINISH1 = 3, GAP = 5, LOCAL = 7;
-    stamps[2 * SWEEP + 1] = realtime_ticks();
-    const int64_t gb = stamps[2 * LOCAL + 1], ge = stamps[2 * FINISH1];
-    stamps[2 * GAP] = gb;
-    stamps[2 * GAP + 1] = (ge != 0x7fffffffffffffffLL) ? ge : gb;
+// end of a sweep (one wave): fold the spread exits, close the sweep stamp, totals[i] += end_i - begin_i, totals[count] += 1.
+// Slot 5 is derived: the idle time between the end of slot 7 (LOCAL) and the begin of slot 3 (FINISH1).  Slot numbers are
+// include/sgp_hip.h's SGP_T_*.
+__device__ __forceinline__ void stamp_accumulate(int64_t* stamps, int64_t* totals, int lane) {
+    constexpr int NSLOTS = 8, SWEEP = 0, FINISH1 = 3, FINISH2 = 4, GAP = 5, LOCAL = 7;
+    const int64_t now = realtime_ticks();
     for (int i = 0; i < NSLOTS; ++i) {
-        int64_t b = stamps[2 * i], e = stamps[2 * i + 1];
+        long long e = stamps[i * STAMP_STRIDE + 2 + lane];
+        for (int o = 32; o > 0; o >>= 1) {
+            long long other = __shfl_xor(e, o);
+            e = other > e ? other : e;
+        }
+        if (lane == 0) {
+            int64_t* rec = stamps + i * STAMP_STRIDE;
+            if (e > rec[1]) rec[1] = e;
+        }
+    }
+    if (lane != 0) return;
+    stamps[SWEEP * STAMP_STRIDE + 1] = now;
+    stamps[FINISH2 * STAMP_STRIDE + 1] = now;             // this kernel is the end of FINISH2 (its own exit atomic may be in flight)
+    const int64_t gb = stamps[LOCAL * STAMP_STRIDE + 1], ge = stamps[FINISH1 * STAMP_STRIDE];
+    stamps[GAP * STAMP_STRIDE] = gb;
+    stamps[GAP * STAMP_STRIDE + 1] = (ge != 0x7fffffffffffffffLL) ? ge : gb;
+    for (int i = 0; i < NSLOTS; ++i) {
+        int64_t b = stamps[i * STAMP_STRIDE], e = stamps[i * STAMP_STRIDE + 1];
         if (e > b && b != 0x7fffffffffffffffLL) totals[i] += e - b;
     }
     totals[NSLOTS] += 1;
-}
-__global__ void k_stamp_reset(int64_t* stamps, int nslots) {
-    int i = threadIdx.x;
-    if (i < nslots) { stamps[2 * i] = 0x7fffffffffffffffLL; stamps[2 * i + 1] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -98,10 +112,13 @@ __global__ void k_prep_xu(const double* __restrict__ Xu, double* __restrict__ Xu
                           Params* __restrict__ dP, int* __restrict__ info_reset, int M, int Mp, int D, int64_t* stamps,
                           int nslots, int sweep_slot) {
     if (blockIdx.x == 0) {
-        if (stamps && threadIdx.x < nslots) {                       // first kernel of a sweep: reset the phase stamps
-            const int i = threadIdx.x;
-            stamps[2 * i] = (i == sweep_slot || i == nslots - 1) ? realtime_ticks() : 0x7fffffffffffffffLL;   // sweep and LOCAL begin here
-            stamps[2 * i + 1] = 0;
+        if (stamps) {                                               // first kernel of a sweep: reset the phase stamps
+            for (int e = threadIdx.x; e < nslots * STAMP_STRIDE; e += blockDim.x) {
+                const int i = e / STAMP_STRIDE, f = e % STAMP_STRIDE;
+                int64_t v = 0;
+                if (f == 0) v = (i == sweep_slot || i == nslots - 1) ? realtime_ticks() : 0x7fffffffffffffffLL;   // sweep and LOCAL begin here
+                stamps[e] = v;
+            }
         }
         const double* src = reinterpret_cast<const double*>(hP);
         double* dst = reinterpret_cast<double*>(dP);
@@ -1395,7 +1412,8 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
     }
     stamp_exit(stamps);
     // last kernel of a sweep: close the sweep stamp and add this sweep's phase durations to the running totals
-    if (all_stamps && tid == 0) stamp_accumulate(all_stamps, totals);
+    __syncthreads();                                            // every wave's exit stamp of this kernel is in
+    if (all_stamps && tid < 64) stamp_accumulate(all_stamps, totals, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
