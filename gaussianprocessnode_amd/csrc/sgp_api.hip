@@ -115,26 +115,19 @@ static int quiesce(sgp_handle* h) {
 // ------------------------------------------------------------------------------------------------
 // dense building blocks (launch sequences)
 // ------------------------------------------------------------------------------------------------
-// Winv (may be nullptr): receives the inverses of the diagonal tiles of L, computed by the idle diagonal block of each step
+// Winv (may be nullptr): receives W = L^-1.  The diagonal tile of step j is inverted by that step's otherwise idle
+// diagonal workgroup; block row j - 1 of W is computed by 2 (j - 1) extra workgroups of step j's launch (see
+// winv_row_tile), and the last row by one short launch after the last step.
 static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, double* scratch, hipStream_t s,
                          double* Winv = nullptr) {
     for (int j = 0; j < Tn; ++j) {
-        int nt = Tn - j;
-        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, A, ld, j, Tn, info, n_valid, scratch, Winv);
+        const int nt = Tn - j;
+        const int extra = (Winv && j >= 2) ? 2 * (j - 1) : 0;
+        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + extra), dim3(256), 0, s, A, ld, j, Tn, info, n_valid, scratch,
+                           Winv);
     }
-}
-// W = L^-1 by recursive doubling: diagonal tiles first, then for block sizes s = 1, 2, 4, ... tiles
-//   W21 = -W22 (L21 W11)   for every pair of adjacent diagonal blocks -- two tile-GEMM launches per level,
-// log2(Tn) levels instead of a Tn-long chain of dependent block rows.  `scratch` (ld x ld) holds L21 W11.
-static void launch_trtri(const double* L, double* W, double* scratch, int ld, int Tn, hipStream_t s, bool diag_done = false) {
-    if (!diag_done) hipLaunchKernelGGL(k_trtri_diag, dim3(Tn), dim3(256), 0, s, L, W, ld);
-    for (int sz = 1; sz < Tn; sz *= 2) {
-        int npairs = (Tn + 2 * sz - 1) / (2 * sz);
-        hipLaunchKernelGGL(k_gemm32, dim3(sz * sz * 4, npairs), dim3(256), 0, s, L, (const double*)W, scratch, ld, Tn, 1, sz, 0
-                           , (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
-        hipLaunchKernelGGL(k_gemm32, dim3(sz * sz * 4, npairs), dim3(256), 0, s, (const double*)W, (const double*)scratch, W,
-                           ld, Tn, 2, sz, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
-    }
+    if (Winv && Tn >= 2)
+        hipLaunchKernelGGL(k_potrf_step, dim3(2 * (Tn - 1)), dim3(256), 0, s, A, ld, Tn, Tn, info, n_valid, scratch, Winv);
 }
 // C = W^T W (rev: written index-reversed).  With mu: also R = C + mu mu^T, and with Psi2 the per-block shares of tr(R Psi2).
 static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s, int rev = 0, const double* mu = nullptr,
@@ -444,8 +437,7 @@ extern "C" int sgp_set_prior(sgp_handle* h, const double* vec, const double* mat
     if (rc) return rc;
     hipStream_t s = h->own;
     HIPCHK(h, hipMemsetAsync(h->dInfo + 2, 0, sizeof(int), s));
-    launch_potrf(h->dTmp, h->Qp, h->TQ, h->dInfo + 2, h->Q, h->dScratch + 2 * TB * TB, s);
-    launch_trtri(h->dTmp, h->dWl, h->dLambda0, h->Qp, h->TQ, s);
+    launch_potrf(h->dTmp, h->Qp, h->TQ, h->dInfo + 2, h->Q, h->dScratch + 2 * TB * TB, s, h->dWl);
     launch_ata(h->dWl, h->dLambda0, h->Qp, h->TQ, s);
     HIPCHK(h, hipMemcpyAsync(h->dMu, v.data(), Qp * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_symv, dim3((h->Qp + 3) / 4), dim3(256), 0, s, h->dLambda0, h->dMu, h->dXi0, h->Qp, h->Qp);
@@ -511,7 +503,6 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
                        h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0);
     hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
     launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk);
-    launch_trtri(h->dKuu, h->dWk, h->dKinv, Mp, T, s, true);
     launch_ata(h->dWk, h->dKinv, Mp, T, s);
 }
 
@@ -538,7 +529,6 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_form_lambda, dim3(TQ, TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dLam, h->dXi,
                        h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form, 1, h->dStamps + STAMP_STRIDE * SGP_T_FINISH1, h->dInfo + 1);
     launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl);
-    launch_trtri(h->dLam, h->dWl, h->dSigma, Qp, TQ, s, true);
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
     // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
     double* uvp = h->dXi;                    // xi is consumed by k_trmv_t; p lands in the same vector afterwards
@@ -1036,12 +1026,13 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
     HIPCHK(h, hipMemcpy(dA, tmp.data(), sizeof(double) * np * np, hipMemcpyHostToDevice));
     double* dScr = nullptr;
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dScr), sizeof(double) * TB * TB));
-    launch_potrf(dA, np, Tn, dInfo, n, dScr, 0);
-    const double* result = dA;
     if (inverse) {
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dW), sizeof(double) * np * np));
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dC), sizeof(double) * np * np));
-        launch_trtri(dA, dW, dC, np, Tn, 0);
+    }
+    launch_potrf(dA, np, Tn, dInfo, n, dScr, 0, dW);
+    const double* result = dA;
+    if (inverse) {
         launch_ata(dW, dC, np, Tn, 0);
         result = dC;
     }

@@ -841,6 +841,114 @@ __device__ __forceinline__ void tile_sub_acc(double* S, const Acc4& acc, int lan
 // the next step's block (0, 0) moves it into place (kernel boundary = all readers done).  The last step has no readers.
 // While the panel blocks solve their tiles, the otherwise idle diagonal block also inverts L_jj (Winv != nullptr): the
 // diagonal tiles of L^-1 that the recursive triangular inverse starts from, without a launch of their own.
+constexpr int PS32 = 48;        // LDS panel row stride for 32-wide panels: 2 * PS32 dwords = 32 (mod 64)
+
+// panel[k][i] = G[(row0 + i) + (col0 + k) * ld], i < 32, k < 64
+__device__ __forceinline__ void load_panel32_n(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0, int tid) {
+    double2 v0[2], v1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int t = tid + 256 * u, k = t >> 3, rq = t & 7;
+        const double* src = G + (size_t)(col0 + k) * ld + row0 + rq * 4;
+        v0[u] = *reinterpret_cast<const double2*>(src);
+        v1[u] = *reinterpret_cast<const double2*>(src + 2);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int t = tid + 256 * u, k = t >> 3, rq = t & 7;
+        double* dst = panel + k * PS32 + rq * 4;
+        dst[0] = v0[u].x; dst[1] = v0[u].y; dst[2] = v1[u].x; dst[3] = v1[u].y;
+    }
+}
+// panel[k][i] = G[(row0 + k) + (col0 + i) * ld], i < 32, k < 64  (transposing load: lanes walk the 32 columns so that
+// the four LDS rows written by one instruction land on different banks)
+__device__ __forceinline__ void load_panel32_t(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0, int tid) {
+    double2 v0[2], v1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int t = tid + 256 * u, i = t & 31, g = t >> 5;
+        const double* src = G + (size_t)(col0 + i) * ld + row0 + g * 4;
+        v0[u] = *reinterpret_cast<const double2*>(src);
+        v1[u] = *reinterpret_cast<const double2*>(src + 2);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int t = tid + 256 * u, i = t & 31, g = t >> 5;
+        panel[(g * 4 + 0) * PS32 + i] = v0[u].x;
+        panel[(g * 4 + 1) * PS32 + i] = v0[u].y;
+        panel[(g * 4 + 2) * PS32 + i] = v1[u].x;
+        panel[(g * 4 + 3) * PS32 + i] = v1[u].y;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Inverse factor W = L^-1 row by row, riding along the Cholesky steps: once step i has finished, block row i of W is
+//   W_ic = - W_ii * sum_{k=c}^{i-1} L_ik W_kc ,   c < i      (W_ii: the diagonal tile's inverse, trtri_tile)
+// and needs only finished things -- columns < i of L, rows < i of W.  Its tiles are computed by EXTRA workgroups of the
+// next step's launch (k_potrf_step, blockIdx >= the step's own tile count): the steps are latency-bound on a handful of
+// CUs, so the inverse costs one short extra launch (for the last row) instead of a phase of its own.
+// One workgroup = the 64 x 32 half h of tile (i, c): per k one 64 x 64 x 32 product on the matrix cores (wave w: rows
+// 16 w .., two 16 x 16 tiles, K split over two accumulator sets), then the product with W_ii, then a coalesced store.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void winv_half_mma(d4& c0a, d4& c1a, d4& c0b, d4& c1b, const double* As, const double* Bs, int lane,
+                                              int wave) {
+    const int li = lane & 15, lk = lane >> 4;
+    const double* ap = As + lk * PS + wave * 16 + li;
+    const double* bp = Bs + lk * PS32 + li;
+#pragma unroll
+    for (int k4 = 0; k4 < 16; k4 += 2) {
+        const double a0 = ap[(4 * k4) * PS], b00 = bp[(4 * k4) * PS32], b01 = bp[(4 * k4) * PS32 + 16];
+        const double a1 = ap[(4 * k4 + 4) * PS], b10 = bp[(4 * k4 + 4) * PS32], b11 = bp[(4 * k4 + 4) * PS32 + 16];
+        c0a = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b00, c0a, 0, 0, 0);
+        c1a = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b01, c1a, 0, 0, 0);
+        c0b = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b10, c0b, 0, 0, 0);
+        c1b = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b11, c1b, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void winv_row_tile(const double* __restrict__ L, double* __restrict__ W, int ld, int i, int c, int h,
+                                              double* lds) {
+    double* As = lds;                                     // As[kk][r], 64 x 64, stride PS
+    double* Bs = lds + TB * PS;                           // Bs[kk][jj], 64 x 32, stride PS32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int col0 = c * TB + 32 * h;
+    const d4 Z = (d4){0.0, 0.0, 0.0, 0.0};
+    d4 t0a = Z, t1a = Z, t0b = Z, t1b = Z;
+    for (int k = c; k < i; ++k) {
+        __syncthreads();
+        load_panel_n(As, L, ld, i * TB, k * TB, TB, tid);             // As[kk][r]  = L[i*64 + r, k*64 + kk]
+        load_panel32_t(Bs, W, ld, k * TB, col0, tid);                 // Bs[kk][jj] = W[k*64 + kk, col0 + jj]
+        __syncthreads();
+        winv_half_mma(t0a, t1a, t0b, t1b, As, Bs, lane, wave);
+    }
+    __syncthreads();
+    load_panel_n(As, W, ld, i * TB, i * TB, TB, tid);                 // As[kk][r]  = W_ii[r][kk]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = wave * 16 + lk + 4 * r;
+        Bs[row * PS32 + li] = t0a[r] + t0b[r];
+        Bs[row * PS32 + 16 + li] = t1a[r] + t1b[r];
+    }
+    __syncthreads();
+    d4 o0a = Z, o1a = Z, o0b = Z, o1b = Z;
+    winv_half_mma(o0a, o1a, o0b, o1b, As, Bs, lane, wave);
+    __syncthreads();
+    double* Os = Bs;                                      // Os[jj][r], stride LT: columns contiguous for the store
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = wave * 16 + lk + 4 * r;
+        Os[li * LT + row] = -(o0a[r] + o0b[r]);
+        Os[(16 + li) * LT + row] = -(o1a[r] + o1b[r]);
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * TB; e += 256) {
+        const int jj = e >> 6, r = e & 63;
+        W[(size_t)(col0 + jj) * ld + i * TB + r] = Os[jj * LT + r];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
                                                     int n_valid, double* __restrict__ scratch, double* __restrict__ Winv) {
     // LDS: two MFMA operand panels (2 x 64 x PS) during the update, re-used afterwards as two 64 x 64 tiles
@@ -848,6 +956,14 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     __shared__ double colw[16];
     __shared__ double rinv[TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    {
+        const int npot = (Tn - j) * (Tn - j + 1) / 2;     // this step's own tiles; the workgroups beyond them compute
+        if ((int)blockIdx.x >= npot) {                    // block row j - 1 of the inverse factor (winv_row_tile)
+            const int e = blockIdx.x - npot;
+            winv_row_tile(A, Winv, ld, j - 1, e >> 1, e & 1, lds);
+            return;
+        }
+    }
     int a, b;
     tile_from_index(blockIdx.x, a, b);                    // a >= b, tile (j + a, j + b) of the matrix
     const int i0 = (j + a) * TB, k0 = (j + b) * TB, j0 = j * TB;
@@ -934,155 +1050,12 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Triangular inverse W = L^-1 (lower).
-//   k_trtri_diag: one block per diagonal tile, rows independent (4 lanes per row as above):
-//       W_rc = (delta_rc - sum_{c<k<=r} W_rk L_kc) / L_cc   for c = r .. 0
-//   k_trtri_col: block (c, s) owns the 16-column strip s of block column c and walks down the rows:
-//       W_ic = - W_ii * sum_{c<=k<i} L_ik W_kc          (two MFMA products per block row)
+// Tile GEMM with 32 x 32 output per block (4 waves x one 16 x 16 MFMA tile), for M x M products where a 64 x 64 tiling
+// leaves too few blocks for 256 CUs.
+//   mode 0  C(I,J) = sum_{k >= I} W(k,I)^T W(k,J)   lower tiles, mirrored; optional index reversal   (Sigma = W^T W)
+//   mode 3  C = A B                                 every tile                                     (theta gradient)
+// (I, J, k are 64-tile indices; W lower triangular, so the k range skips the structural zeros.)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_trtri_diag(const double* __restrict__ L, double* __restrict__ W, int ld) {
-    __shared__ double lds[2 * TB * LT + 32 * 33];
-    __shared__ double rinv[TB];
-    const int tid = threadIdx.x, j0 = blockIdx.x * TB;
-    tile_g2s(lds, L, ld, j0, j0);
-    __syncthreads();
-    if (tid < TB) rinv[tid] = 1.0 / lds[tid * LT + tid];
-    __syncthreads();
-    trtri_tile(lds, rinv, lds + TB * LT, lds + 2 * TB * LT);
-    tile_s2g(lds + TB * LT, W, ld, j0, j0);
-}
-
-// One wave computes a 16 x 16 output tile over K = 64: rows wave*16.., operands in LDS panels.
-__device__ __forceinline__ d4 strip_mma(d4 acc, const double* As, const double* Bs, int lane, int wave) {
-    const int li = lane & 15, lk = lane >> 4;
-    const double* ap = As + lk * PS + wave * 16 + li;
-    const double* bp = Bs + lk * PS + li;
-#pragma unroll 4
-    for (int k = 0; k < TB; k += 4) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], bp[0], acc, 0, 0, 0);
-        ap += 4 * PS;
-        bp += 4 * PS;
-    }
-    return acc;
-}
-
-__global__ void __launch_bounds__(256) k_trtri_col(const double* __restrict__ L, double* __restrict__ W, int ld, int T) {
-    __shared__ double As[TB * PS];
-    __shared__ double Bs[TB * PS];                       // only 16 columns used: Bs[k][0..15]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = blockIdx.x, s = blockIdx.y;
-    const int c0 = c * TB + s * 16;                      // first global column of the strip
-    for (int i = c + 1; i < T; ++i) {
-        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int k = c; k < i; ++k) {
-            __syncthreads();
-            // As[kk][r] = L[(i*64 + r), (k*64 + kk)] ; Bs[kk][cc] = W[(k*64 + kk), c0 + cc]
-            load_panel_n(As, L, ld, i * TB, k * TB, TB, tid);
-            for (int t = tid; t < TB * 16; t += 256) {
-                int cc = t >> 6, kk = t & 63;
-                Bs[kk * PS + cc] = W[(size_t)(c0 + cc) * ld + k * TB + kk];
-            }
-            __syncthreads();
-            acc = strip_mma(acc, As, Bs, lane, wave);
-        }
-        __syncthreads();
-        // second product: W_ic = - W_ii * Acc ; As[kk][r] = W_ii[r][kk] (column-major tile -> panel_n), Bs = Acc
-        load_panel_n(As, W, ld, i * TB, i * TB, TB, tid);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Bs[(wave * 16 + (lane >> 4) + 4 * r) * PS + (lane & 15)] = acc[r];
-        __syncthreads();
-        d4 out = strip_mma((d4){0.0, 0.0, 0.0, 0.0}, As, Bs, lane, wave);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int row = i * TB + wave * 16 + (lane >> 4) + 4 * r;
-            W[(size_t)(c0 + (lane & 15)) * ld + row] = -out[r];
-        }
-        __threadfence_block();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// C = W^T W for lower-triangular W (inverse from the Cholesky factor: Sigma = L^-T L^-1), full symmetric out.
-// Tile (I, J), I >= J: sum over block rows k = I .. T-1.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ata_lower(const double* __restrict__ W, double* __restrict__ C, int ld, int T, int rev) {
-    __shared__ double lds[2 * TB * PS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    int I, J;
-    tile_from_index(blockIdx.x, I, J);
-    double* As = lds;
-    double* Bs = lds + TB * PS;
-    Acc4 acc;
-    acc_zero(acc);
-    for (int k = I; k < T; ++k) {
-        __syncthreads();
-        load_panel_t(As, W, ld, k * TB, I * TB, TB, tid);          // As[kk][i] = W[k*64 + kk, I*64 + i]
-        if (I != J) load_panel_t(Bs, W, ld, k * TB, J * TB, TB, tid);
-        __syncthreads();
-        tile_mma(acc, As, (I != J) ? Bs : As, TB, lane, wr, wc);
-    }
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int row = I * TB + acc_row(lane, wr, ti, r), col = J * TB + acc_col(lane, wc, tj);
-                double v = acc.t[ti][tj][r];
-                if (rev) { row = ld - 1 - row; col = ld - 1 - col; }          // undo the index reversal of k_form_lambda
-                C[(size_t)col * ld + row] = v;
-                if (I != J) C[(size_t)row * ld + col] = v;
-            }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Tile GEMM with 32 x 32 output per block (4 waves x one 16 x 16 MFMA tile): the products of the recursive triangular
-// inverse and the inverse-from-factor product, where the 64 x 64 tiling leaves too few blocks for 256 CUs.
-//   mode 0  C(I,J) = sum_{k >= I} W(k,I)^T W(k,J)          lower tiles, mirrored; optional index reversal    (Sigma = W^T W)
-//   mode 1  T(i,j) = sum_{k=j}^{lo+s-1} L(i,k) W(k,j)      i in [lo+s, lo+2s), j in [lo, lo+s), lo = 2 s p   (L21 W11)
-//   mode 2  W(i,j) = - sum_{k=lo+s}^{i} W(i,k) T(k,j)      same tiles                                        (-W22 T)
-// (i, j, k are 64-tile indices; W11 / W22 lower triangular, so the k ranges skip the structural zeros.)
-// ------------------------------------------------------------------------------------------------
-constexpr int PS32 = 48;        // LDS panel row stride for 32-wide panels: 2 * PS32 dwords = 32 (mod 64)
-
-// panel[k][i] = G[(row0 + i) + (col0 + k) * ld], i < 32, k < 64
-__device__ __forceinline__ void load_panel32_n(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0, int tid) {
-    double2 v0[2], v1[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        int t = tid + 256 * u, k = t >> 3, rq = t & 7;
-        const double* src = G + (size_t)(col0 + k) * ld + row0 + rq * 4;
-        v0[u] = *reinterpret_cast<const double2*>(src);
-        v1[u] = *reinterpret_cast<const double2*>(src + 2);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        int t = tid + 256 * u, k = t >> 3, rq = t & 7;
-        double* dst = panel + k * PS32 + rq * 4;
-        dst[0] = v0[u].x; dst[1] = v0[u].y; dst[2] = v1[u].x; dst[3] = v1[u].y;
-    }
-}
-// panel[k][i] = G[(row0 + k) + (col0 + i) * ld], i < 32, k < 64  (transposing load: lanes walk the 32 columns so that
-// the four LDS rows written by one instruction land on different banks)
-__device__ __forceinline__ void load_panel32_t(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0, int tid) {
-    double2 v0[2], v1[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        int t = tid + 256 * u, i = t & 31, g = t >> 5;
-        const double* src = G + (size_t)(col0 + i) * ld + row0 + g * 4;
-        v0[u] = *reinterpret_cast<const double2*>(src);
-        v1[u] = *reinterpret_cast<const double2*>(src + 2);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        int t = tid + 256 * u, i = t & 31, g = t >> 5;
-        panel[(g * 4 + 0) * PS32 + i] = v0[u].x;
-        panel[(g * 4 + 1) * PS32 + i] = v0[u].y;
-        panel[(g * 4 + 2) * PS32 + i] = v1[u].x;
-        panel[(g * 4 + 3) * PS32 + i] = v1[u].y;
-    }
-}
-
 // mode 0 extras (all nullable): with `mu` the kernel also writes R = C + mu mu^T (Sigma_v + mu mu^T, GPnode/UniSGPnode.jl:67)
 // and, with `Psi2`, the block's share of tr(R Psi2) into trace_part[blockIdx.x] (the sum I2 trace of :196-238, d_out = 1).
 __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
@@ -1098,14 +1071,9 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
     if (mode == 0) {
         tile_from_index(blockIdx.x >> 2, I, J);
         kbeg = I; kend = Tn;
-    } else if (mode == 3) {                                              // general C = A B, every tile
+    } else {                                                             // mode 3: general C = A B, every tile
         const int t = blockIdx.x >> 2;
         I = t / Tn; J = t % Tn; kbeg = 0; kend = Tn;
-    } else {
-        const int t = blockIdx.x >> 2, lo = 2 * s * blockIdx.y;
-        I = lo + s + t / s; J = lo + t % s;
-        if (I >= Tn) return;
-        if (mode == 1) { kbeg = J; kend = lo + s; } else { kbeg = lo + s; kend = I + 1; }
     }
     const int r0 = I * TB + qi * 32, c0 = J * TB + qj * 32;
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
@@ -1137,7 +1105,7 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
                 if (Psi2) tsum = fma(rv, Psi2[(size_t)col * ld + row], tsum);
             }
         } else {
-            C[(size_t)col * ld + row] = (mode == 2) ? -v : v;
+            C[(size_t)col * ld + row] = v;
         }
     }
     if (mode == 0 && trace_part) {
