@@ -86,7 +86,7 @@ def main():
     X, Xu, y, Xt, yt = synthetic(N, M, D)
     lo, hi = shard_bounds(N, world, rank)
 
-    eng = HipEngine(hi - lo, M, D, 1, device=local_rank)
+    eng = HipEngine(hi - lo, M, D, 1, device=local_rank, use_graph=os.environ.get("SGP_BENCH_GRAPH") is not None)
     dev = eng.dev
     dev.set_inducing(Xu)
     dev.set_data(X[lo:hi], y[lo:hi])
@@ -117,9 +117,9 @@ def main():
 
     # ---- live per-kernel numbers (this rank's shard) ------------------------------------------------
     # (1) averages over the K timed sweeps, from in-kernel first-block-in / last-block-out stamps (100 MHz clock)
-    #     accumulated on the device inside the timed graph replays -- no host interaction in the timed region;
+    #     accumulated on the device inside the timed sweeps -- no host interaction in the timed region;
     # (2) HIP events around eager launches of the same kernel on the same stream, right after the timed region (the
-    #     kernel alone on the chip: in the sweep it shares the chip with the K_uu chain on the side stream).
+    #     kernel alone on the chip, launch overhead included).
     phase_us, n_counted = dev.phase_totals()
     tick_us = lambda i: float(phase_us[i])
     stream = eng.stream.cuda_stream

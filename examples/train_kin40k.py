@@ -41,7 +41,7 @@ def main():
     w_val = 1e4
 
     t_create = time.perf_counter()
-    with G.SGPDevice(args.batch, M, D) as eng:
+    with G.SGPDevice(args.batch, M, D, use_graph=os.environ.get("SGP_GRAPH") is not None) as eng:
         t0 = time.perf_counter()
         qv, theta = perform_inference(theta_init, xtrain, ytrain, Xu, eng, batch_size=args.batch, epochs=args.epochs,
                                       w_val=w_val, optimizer=AdaMax(eta=args.eta))

@@ -14,6 +14,7 @@ from . import _build
 
 SGP_FLAG_NO_GRAPH = 1
 SGP_FLAG_KEEP_KUF = 2
+SGP_FLAG_GRAPH = 4
 SGP_S_YY, SGP_S_W, SGP_S_N, SGP_S_COUNT = 0, 1, 2, 8
 (SGP_R_SUM_I1, SGP_R_SUM_I2, SGP_R_ENERGY, SGP_R_INFO_KUU, SGP_R_INFO_LAMBDA, SGP_R_INFO_PRIOR,
  SGP_R_LOGDET_KUU, SGP_R_LOGDET_LAMBDA, SGP_R_COUNT) = range(9)

@@ -567,7 +567,7 @@ static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
 typedef void (*enqueue_fn)(sgp_handle*, hipStream_t);
 
 static int run_sequence(sgp_handle* h, Graph& g, enqueue_fn fn, hipStream_t s) {
-    if (h->cfg.flags & SGP_FLAG_NO_GRAPH) {
+    if (!(h->cfg.flags & SGP_FLAG_GRAPH)) {
         fn(h, s);
         HIPCHK(h, hipGetLastError());
         return 0;

@@ -73,7 +73,7 @@ def unpack_stats(buf, m: int, d_out: int = 1):
 class HipEngine:
     """This rank's shard on its MI355X: local statistics and the replicated tail through the C ABI."""
 
-    def __init__(self, n_max: int, m: int, d: int, d_out: int = 1, device: int = 0, use_graph: bool = True):
+    def __init__(self, n_max: int, m: int, d: int, d_out: int = 1, device: int = 0, use_graph: bool = False):
         import torch
         from .device import SGPDevice
         if not torch.cuda.is_available():

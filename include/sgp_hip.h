@@ -34,8 +34,10 @@ extern "C" {
 #define SGP_ERR_NOMEM    (-4)
 
 /* flags for sgp_config.flags */
-#define SGP_FLAG_NO_GRAPH   1   /* launch kernels eagerly instead of replaying a captured hipGraph */
+#define SGP_FLAG_NO_GRAPH   1   /* launch kernels eagerly -- the default since eager launches measured ~20 us per sweep faster
+                                 * than hipGraph replay at every size (tools/graph_vs_eager.py); kept as a no-op */
 #define SGP_FLAG_KEEP_KUF   2   /* keep K_uf resident for the per-point outputs (sgp_w_stats per_point) */
+#define SGP_FLAG_GRAPH      4   /* replay the launch sequences as captured hipGraphs (opt-in; bitwise the same results) */
 
 typedef struct sgp_handle sgp_handle;
 
