@@ -118,16 +118,20 @@ static int quiesce(sgp_handle* h) {
 // Winv (may be nullptr): receives W = L^-1.  The diagonal tile of step j is inverted by that step's otherwise idle
 // diagonal workgroup; block row j - 1 of W is computed by 2 (j - 1) extra workgroups of step j's launch (see
 // winv_row_tile), and the last row by one short launch after the last step.
+// form (may be nullptr): step 0 evaluates the matrix on the fly (Lambda = Lambda0 + W (x) Psi2, see LamForm) instead of
+// reading it from A.
 static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, double* scratch, hipStream_t s,
-                         double* Winv = nullptr) {
+                         double* Winv = nullptr, const LamForm* form = nullptr) {
+    LamForm none;
+    memset(&none, 0, sizeof none);
     for (int j = 0; j < Tn; ++j) {
         const int nt = Tn - j;
         const int extra = (Winv && j >= 2) ? 2 * (j - 1) : 0;
         hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + extra), dim3(256), 0, s, A, ld, j, Tn, info, n_valid, scratch,
-                           Winv);
+                           Winv, (j == 0 && form) ? *form : none);
     }
     if (Winv && Tn >= 2)
-        hipLaunchKernelGGL(k_potrf_step, dim3(2 * (Tn - 1)), dim3(256), 0, s, A, ld, Tn, Tn, info, n_valid, scratch, Winv);
+        hipLaunchKernelGGL(k_potrf_step, dim3(2 * (Tn - 1)), dim3(256), 0, s, A, ld, Tn, Tn, info, n_valid, scratch, Winv, none);
 }
 // C = W^T W (rev: written index-reversed).  With mu: also R = C + mu mu^T, and with Psi2 the per-block shares of tr(R Psi2).
 static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s, int rev = 0, const double* mu = nullptr,
@@ -213,7 +217,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dUvT, Qp * Qp);
     ALLOC(h->dScratch, 3 * TB * TB);
     ALLOC(h->dOut2, SGP_R_COUNT);
-    ALLOC(h->dUvWork, (3 + (size_t)h->TQ) * Qp);
+    ALLOC(h->dUvWork, (2 + 2 * (size_t)h->TQ) * Qp);
     ALLOC(h->dLambda0, Qp * Qp);
     ALLOC(h->dXi, Qp);
     ALLOC(h->dMu, Qp);
@@ -519,24 +523,28 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     }
     hipLaunchKernelGGL(k_assemble, dim3(T, T, 4), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
                        h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
-                       SGP_S_COUNT + h->dout * h->dout, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL);
+                       SGP_S_COUNT + h->dout * h->dout, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL, h->dInfo + 1);
 }
 
 static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp, TQ = h->TQ;
     // Lambda is factored in index-reversed order (P Lambda P = L' L'^T): its inverse factor W' = L'^-1 then IS the upper
     // Cholesky factor of Sigma_v up to the reversal, and Uv follows by a rank-1 update instead of a third potrf.
-    hipLaunchKernelGGL(k_form_lambda, dim3(TQ, TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dLam, h->dXi,
-                       h->dParams, M, Mp, h->dout, Q, Qp, h->prior_form, 1, h->dStamps + STAMP_STRIDE * SGP_T_FINISH1, h->dInfo + 1);
-    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl);
+    // (Lambda = Lambda0 + W (x) Psi2 and xi are formed by step 0 of the factorisation itself; the status word was reset by
+    // k_assemble)
+    LamForm form;
+    form.stats = h->dStats; form.Lambda0 = h->dLambda0; form.xi0 = h->dXi0; form.xi = h->dXi; form.P = h->dParams;
+    form.M = M; form.Mp = Mp; form.d_out = h->dout; form.Q = Q; form.prior_form = h->prior_form;
+    form.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
+    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl, &form);
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
     // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
     double* uvp = h->dXi;                    // xi is consumed by k_trmv_t; p lands in the same vector afterwards
     double* uvck = h->dUvWork;               // C_kk
     double* uvak = h->dUvWork + Qp;          // p_k / sqrt(alpha_k alpha_{k+1})
-    double* uvt = h->dUvWork + 2 * (size_t)Qp;      // t = W' P xi
-    double* uvpart = h->dUvWork + 3 * (size_t)Qp;   // TQ x Qp tile partial sums
-    hipLaunchKernelGGL(k_trmv_t, dim3(TQ), dim3(256), 0, s, (const double*)h->dWl, (const double*)h->dXi, uvt, Qp);
+    double* uvt = h->dUvWork + 2 * (size_t)Qp;      // TQ x Qp tile contributions to t = W' P xi
+    double* uvpart = uvt + (size_t)TQ * Qp;         // TQ x Qp tile partial sums
+    hipLaunchKernelGGL(k_trmv_t, dim3(TQ * (TQ + 1) / 2), dim3(256), 0, s, (const double*)h->dWl, (const double*)h->dXi, uvt, Qp);
     hipLaunchKernelGGL(k_trmv_mu_scan, dim3(Qp / 4 + 1), dim3(256), 0, s, (const double*)h->dWl, (const double*)uvt, h->dMu,
                        uvp, uvck, uvak, Qp);
     // Sigma = W'^T W' (index-reversed back), R = Sigma + mu mu^T and -- UniSGP -- the tr(R Psi2) shares, one launch

@@ -423,7 +423,8 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ slabs, const double* __restrict__ bpart,
                                                   const double* __restrict__ data_scalars, double* __restrict__ stats,
-                                                  int Mp, int ntiles, int nchunks, int nblk, int d_out, int nscal, int64_t* stamps) {
+                                                  int Mp, int ntiles, int nchunks, int nblk, int d_out, int nscal, int64_t* stamps,
+                                                  int* __restrict__ info_reset) {
     // grid (T, T, 4): block z sums rows [16 z, 16 z + 16) of the slab tile (I, J), I >= J, and writes both mirror images
     __shared__ double tile[16 * LT];
     const int I = blockIdx.x, J = blockIdx.y, z = blockIdx.z;
@@ -486,6 +487,7 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
         if (I == 0 && z == 0)
             for (int e = tid; e < nscal; e += 256) B[(size_t)Mp * d_out + e] = data_scalars[e];
     }
+    if (info_reset && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *info_reset = 0;
     stamp_exit(stamps);
 }
 
@@ -808,6 +810,38 @@ __device__ __forceinline__ void tile_g2r(TileRegs& t, const double* __restrict__
         t.v[u] = A[(size_t)(col0 + c) * ld + row0 + r];
     }
 }
+// Lambda = Lambda0 + W (x) Psi2 in index-reversed order, evaluated on the fly: step 0 of the Lambda factorisation reads its
+// tiles through this instead of from memory, so that no separate k_form_lambda launch (and no round trip of Lambda through
+// HBM) sits in front of the chain.  stats == nullptr: the matrix is already in A.
+struct LamForm {
+    const double* stats;
+    const double* Lambda0;
+    const double* xi0;
+    double* xi;
+    const Params* P;
+    int M, Mp, d_out, Q, prior_form;
+    int64_t* stamps;
+};
+// (branch-free on purpose: with the loads under a data-dependent branch the compiler waits for each of a thread's 16 loads
+// in turn -- measured 13 us for step 0 instead of 1)
+__device__ __forceinline__ double lambda_entry(const LamForm& f, int gi, int gj, int Qp) {
+    const bool inside = gi < f.Q && gj < f.Q;
+    const int si = inside ? gi : 0, sj = inside ? gj : 0;              // safe indices for the pad entries
+    int a = 0, i = si, b = 0, j = sj;
+    if (f.d_out > 1) { a = si / f.M; i = si % f.M; b = sj / f.M; j = sj % f.M; }
+    const double psi = f.stats[(size_t)j * f.Mp + i];
+    const double diag = (gi == gj) ? 1.0 : 0.0;
+    const double prior = (f.prior_form == 1) ? f.Lambda0[(size_t)sj * Qp + si] : diag * f.P->prior_iso;
+    return inside ? fma(f.P->W[a + b * f.d_out], psi, prior) : diag;
+}
+// tile (row0.., col0..) of P Lambda P: entry (r, c) is Lambda[Qp-1-r][Qp-1-c]
+__device__ __forceinline__ void tile_form_r(TileRegs& t, const LamForm& f, int Qp, int row0, int col0) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        int e = threadIdx.x + 256 * u, c = e >> 6, r = e & 63;
+        t.v[u] = lambda_entry(f, Qp - 1 - (row0 + r), Qp - 1 - (col0 + c), Qp);
+    }
+}
 __device__ __forceinline__ void tile_r2s(double* S, const TileRegs& t) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -950,7 +984,8 @@ __device__ __forceinline__ void winv_row_tile(const double* __restrict__ L, doub
 }
 
 __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
-                                                    int n_valid, double* __restrict__ scratch, double* __restrict__ Winv) {
+                                                    int n_valid, double* __restrict__ scratch, double* __restrict__ Winv,
+                                                    LamForm form) {
     // LDS: two MFMA operand panels (2 x 64 x PS) during the update, re-used afterwards as two 64 x 64 tiles
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
     __shared__ double colw[16];
@@ -981,7 +1016,27 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     }
     // the tiles this block updates are fetched into registers now, so that their latency hides behind the MFMA phase
     TileRegs rX, rS;
-    if (!panel) tile_g2r(rX, A, ld, i0, k0);
+    if (j == 0 && form.stats) {
+        // step 0 of the Lambda chain forms its tiles instead of loading them; the last workgroup also writes xi
+        stamp_enter(form.stamps);
+        if (!panel) tile_form_r(rX, form, ld, i0, k0);
+        else {
+            tile_form_r(rS, form, ld, j0, j0);
+            if (a != 0) tile_form_r(rX, form, ld, i0, j0);
+        }
+        if (blockIdx.x == gridDim.x - 1) {
+            const double* B = form.stats + (size_t)form.Mp * form.Mp;
+            for (int gi = tid; gi < ld; gi += 256) {
+                double v = 0.0;
+                if (gi < form.Q) {
+                    const int aa = gi / form.M, i = gi % form.M;
+                    v = (form.prior_form == 1) ? form.xi0[gi] : 0.0;
+                    for (int e = 0; e < form.d_out; ++e) v = fma(B[(size_t)e * form.Mp + i], form.P->W[e + aa * form.d_out], v);
+                }
+                form.xi[gi] = v;
+            }
+        }
+    } else if (!panel) tile_g2r(rX, A, ld, i0, k0);
     else {
         tile_g2r(rS, A, ld, j0, j0);
         if (a != 0) tile_g2r(rX, A, ld, i0, j0);
@@ -1150,38 +1205,51 @@ __global__ void __launch_bounds__(256) k_symv(const double* __restrict__ S, cons
 // ------------------------------------------------------------------------------------------------
 constexpr int CU_MAXQ = 4096;
 
-// t = W' (P xi): lower-triangular mat-vec, one 64-row block per workgroup, the k range split over the four waves.
-// (W' column-major: a fixed column is contiguous over the rows, so the lanes walk rows and the loop walks columns.)
+// t = W' (P xi): lower-triangular mat-vec.  One workgroup per 64 x 64 tile (I, kt), kt <= I, of W' -- every thread issues
+// its 16 loads at once (a whole row block per workgroup was latency-bound: 15 us) -- writing the tile's contribution
+// tpart[kt][64 I + r]; k_trmv_mu_scan adds the <= TQ contributions in a fixed order.
+// (W' column-major: a fixed column is contiguous over the rows, so the lanes walk rows and each wave owns 16 columns.)
 __global__ void __launch_bounds__(256) k_trmv_t(const double* __restrict__ W, const double* __restrict__ xi,
-                                                double* __restrict__ t, int Qp) {
+                                                double* __restrict__ tpart, int Qp) {
     __shared__ double red[4][64];
-    const int I = blockIdx.x, r = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int kend = 64 * (I + 1);                       // the strict upper part of the diagonal tile is stored as zeros
-    const double* base = W + 64 * I + r;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int k = part; k < kend; k += 16) {              // kend is a multiple of 64: the four sub-steps stay in range
-        s0 = fma(base[(size_t)k * Qp], xi[Qp - 1 - k], s0);
-        s1 = fma(base[(size_t)(k + 4) * Qp], xi[Qp - 5 - k], s1);
-        s2 = fma(base[(size_t)(k + 8) * Qp], xi[Qp - 9 - k], s2);
-        s3 = fma(base[(size_t)(k + 12) * Qp], xi[Qp - 13 - k], s3);
+    int I, kt;
+    tile_from_index(blockIdx.x, I, kt);                  // I >= kt
+    const int r = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int k0 = 64 * kt + 16 * part;                  // the strict upper part of a diagonal tile is stored as zeros
+    const double* base = W + (size_t)k0 * Qp + 64 * I + r;
+    double w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w[u] = base[(size_t)u * Qp];
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) {
+        s0 = fma(w[u], xi[Qp - 1 - (k0 + u)], s0);
+        s1 = fma(w[u + 1], xi[Qp - 2 - (k0 + u)], s1);
     }
-    red[part][r] = (s0 + s1) + (s2 + s3);
+    red[part][r] = s0 + s1;
     __syncthreads();
-    if (part == 0) t[64 * I + r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+    if (part == 0) tpart[(size_t)kt * Qp + 64 * I + r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
 }
 
 // mu = P W'^T t (one wave per column of W'), p = P t, and -- in the extra last workgroup -- the alpha scan of p:
 // ck[k] = C_kk, ak[k] = p_k / sqrt(alpha_k alpha_{k+1}).
-__global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__ W, const double* __restrict__ t,
+__global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__ W, const double* __restrict__ tpart,
                                                       double* __restrict__ mu, double* __restrict__ p,
                                                       double* __restrict__ ck, double* __restrict__ ak, int Qp) {
+    __shared__ double ts[CU_MAXQ];
     const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < Qp; i += 256) {        // t_i = sum of the tile contributions kt = 0 .. i / 64
+        double v = 0.0;
+        for (int kt = 0; kt <= (i >> 6); ++kt) v += tpart[(size_t)kt * Qp + i];
+        ts[i] = v;
+    }
+    __syncthreads();
     if ((int)blockIdx.x == Qp / 4) {
         if (threadIdx.x >= 64) return;
         const int per = (Qp + 63) / 64;
         const int e0 = lane * per, e1 = min((lane + 1) * per, Qp);
         double loc = 0.0;
-        for (int e = e0; e < e1; ++e) { double v = t[Qp - 1 - e]; p[e] = v; loc = fma(v, v, loc); }
+        for (int e = e0; e < e1; ++e) { double v = ts[Qp - 1 - e]; p[e] = v; loc = fma(v, v, loc); }
         double inc = loc;
         for (int o = 1; o < 64; o <<= 1) {
             double u = __shfl_up(inc, o);
@@ -1189,7 +1257,7 @@ __global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__
         }
         double alpha = 1.0 + (inc - loc);
         for (int e = e0; e < e1; ++e) {
-            const double pe = t[Qp - 1 - e], an = fma(pe, pe, alpha);
+            const double pe = ts[Qp - 1 - e], an = fma(pe, pe, alpha);
             const double ir = 1.0 / sqrt(alpha * an);
             ck[e] = an * ir;
             ak[e] = pe * ir;
@@ -1200,7 +1268,7 @@ __global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     const double* col = W + (size_t)k * Qp;
     double s = 0.0;
-    for (int i = k + lane; i < Qp; i += 64) s = fma(col[i], t[i], s);
+    for (int i = k + lane; i < Qp; i += 64) s = fma(col[i], ts[i], s);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) mu[Qp - 1 - k] = s;
 }
