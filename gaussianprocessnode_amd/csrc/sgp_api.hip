@@ -94,6 +94,13 @@ static int fail(sgp_handle* h, int code, const char* msg) {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// the side stream (K_uu chain) yields to whatever stream carries the critical path
+static hipError_t create_low_priority_stream(hipStream_t* s) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+}
+
 // Setters change state that an enqueued sweep reads WHEN IT EXECUTES (the pinned parameter block, the data buffers, the
 // prior): they first wait for any sweep still in flight.  The library's streams are non-blocking, so the implicit
 // synchronisation of hipMemcpy with the legacy default stream does not cover them.
@@ -116,8 +123,8 @@ static int quiesce(sgp_handle* h) {
 // dense building blocks (launch sequences)
 // ------------------------------------------------------------------------------------------------
 // Winv (may be nullptr): receives W = L^-1.  The diagonal tile of step j is inverted by that step's otherwise idle
-// diagonal workgroup; block row j - 1 of W is computed by 2 (j - 1) extra workgroups of step j's launch (see
-// winv_row_tile), and the last row by one short launch after the last step.
+// diagonal workgroup; extra workgroups of step j's launch finish block row j - 1 of W and pre-accumulate block row j (see
+// winv_row_tile), so that the one short launch after the last step only has two products per tile left for the last row.
 // form (may be nullptr): step 0 evaluates the matrix on the fly (Lambda = Lambda0 + W (x) Psi2, see LamForm) instead of
 // reading it from A.
 static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, double* scratch, hipStream_t s,
@@ -126,7 +133,7 @@ static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, doub
     memset(&none, 0, sizeof none);
     for (int j = 0; j < Tn; ++j) {
         const int nt = Tn - j;
-        const int extra = (Winv && j >= 2) ? 2 * (j - 1) : 0;
+        const int extra = (Winv && j >= 2) ? 2 * (j - 1) * (j <= Tn - 1 ? 2 : 1) : 0;   // finish row j-1 (+ pre-accumulate row j)
         hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + extra), dim3(256), 0, s, A, ld, j, Tn, info, n_valid, scratch,
                            Winv, (j == 0 && form) ? *form : none);
     }
@@ -248,7 +255,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     h->hParams->W[0] = 1.0;
     h->hParams->prior_iso = 1.0;
     if (hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        create_low_priority_stream(&h->side) != hipSuccess ||
         hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evSide, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evStats, hipEventDisableTiming) != hipSuccess) {

@@ -941,16 +941,34 @@ __device__ __forceinline__ void winv_half_mma(d4& c0a, d4& c1a, d4& c0b, d4& c1b
     }
 }
 
+// mode 0: the whole tile half at once.  The two-launch pipeline used by the Cholesky steps splits it:
+// mode 1 (one launch early): T' = sum_{k=c}^{i-2} L_ik W_kc, parked in W's own (i, c) tile;
+// mode 2 (finish):           W_ic = - W_ii (T' + L_{i,i-1} W_{i-1,c})   -- two products instead of up to i - c + 1.
 __device__ __forceinline__ void winv_row_tile(const double* __restrict__ L, double* __restrict__ W, int ld, int i, int c, int h,
-                                              double* lds) {
+                                              double* lds, int mode) {
     double* As = lds;                                     // As[kk][r], 64 x 64, stride PS
     double* Bs = lds + TB * PS;                           // Bs[kk][jj], 64 x 32, stride PS32
+    double* Os = Bs;                                      // Os[jj][r], stride LT: staging for coalesced tile-half I/O
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int col0 = c * TB + 32 * h;
     const d4 Z = (d4){0.0, 0.0, 0.0, 0.0};
     d4 t0a = Z, t1a = Z, t0b = Z, t1b = Z;
-    for (int k = c; k < i; ++k) {
+    const int kbeg = (mode == 2) ? i - 1 : c, kend = (mode == 1) ? i - 1 : i;      // [kbeg, kend)
+    if (mode == 2 && c <= i - 2) {                        // resume from the parked partial sum
+        for (int e = tid; e < 32 * TB; e += 256) {
+            const int jj = e >> 6, r = e & 63;
+            Os[jj * LT + r] = W[(size_t)(col0 + jj) * ld + i * TB + r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + lk + 4 * r;
+            t0a[r] = Os[li * LT + row];
+            t1a[r] = Os[(16 + li) * LT + row];
+        }
+    }
+    for (int k = kbeg; k < kend; ++k) {
         __syncthreads();
         load_panel_n(As, L, ld, i * TB, k * TB, TB, tid);             // As[kk][r]  = L[i*64 + r, k*64 + kk]
         load_panel32_t(Bs, W, ld, k * TB, col0, tid);                 // Bs[kk][jj] = W[k*64 + kk, col0 + jj]
@@ -958,23 +976,30 @@ __device__ __forceinline__ void winv_row_tile(const double* __restrict__ L, doub
         winv_half_mma(t0a, t1a, t0b, t1b, As, Bs, lane, wave);
     }
     __syncthreads();
-    load_panel_n(As, W, ld, i * TB, i * TB, TB, tid);                 // As[kk][r]  = W_ii[r][kk]
+    d4 o0 = Z, o1 = Z;
+    if (mode == 1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = wave * 16 + lk + 4 * r;
-        Bs[row * PS32 + li] = t0a[r] + t0b[r];
-        Bs[row * PS32 + 16 + li] = t1a[r] + t1b[r];
+        for (int r = 0; r < 4; ++r) { o0[r] = t0a[r] + t0b[r]; o1[r] = t1a[r] + t1b[r]; }
+    } else {
+        load_panel_n(As, W, ld, i * TB, i * TB, TB, tid);             // As[kk][r]  = W_ii[r][kk]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + lk + 4 * r;
+            Bs[row * PS32 + li] = t0a[r] + t0b[r];
+            Bs[row * PS32 + 16 + li] = t1a[r] + t1b[r];
+        }
+        __syncthreads();
+        d4 o0a = Z, o1a = Z, o0b = Z, o1b = Z;
+        winv_half_mma(o0a, o1a, o0b, o1b, As, Bs, lane, wave);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o0[r] = -(o0a[r] + o0b[r]); o1[r] = -(o1a[r] + o1b[r]); }
     }
-    __syncthreads();
-    d4 o0a = Z, o1a = Z, o0b = Z, o1b = Z;
-    winv_half_mma(o0a, o1a, o0b, o1b, As, Bs, lane, wave);
-    __syncthreads();
-    double* Os = Bs;                                      // Os[jj][r], stride LT: columns contiguous for the store
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = wave * 16 + lk + 4 * r;
-        Os[li * LT + row] = -(o0a[r] + o0b[r]);
-        Os[(16 + li) * LT + row] = -(o1a[r] + o1b[r]);
+        Os[li * LT + row] = o0[r];
+        Os[(16 + li) * LT + row] = o1[r];
     }
     __syncthreads();
     for (int e = tid; e < 32 * TB; e += 256) {
@@ -992,10 +1017,12 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     __shared__ double rinv[TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     {
-        const int npot = (Tn - j) * (Tn - j + 1) / 2;     // this step's own tiles; the workgroups beyond them compute
-        if ((int)blockIdx.x >= npot) {                    // block row j - 1 of the inverse factor (winv_row_tile)
-            const int e = blockIdx.x - npot;
-            winv_row_tile(A, Winv, ld, j - 1, e >> 1, e & 1, lds);
+        const int npot = (Tn - j) * (Tn - j + 1) / 2;     // this step's own tiles; the workgroups beyond them work on
+        if ((int)blockIdx.x >= npot) {                    // the inverse factor (winv_row_tile): finish block row j - 1,
+            int e = blockIdx.x - npot;                    // then pre-accumulate block row j
+            const int nfin = 2 * (j - 1);
+            if (e < nfin) winv_row_tile(A, Winv, ld, j - 1, e >> 1, e & 1, lds, 2);
+            else { e -= nfin; winv_row_tile(A, Winv, ld, j, e >> 1, e & 1, lds, 1); }
             return;
         }
     }
