@@ -142,9 +142,11 @@ static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, doub
 }
 // C = W^T W (rev: written index-reversed).  With mu: also R = C + mu mu^T, and with Psi2 the per-block shares of tr(R Psi2).
 static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s, int rev = 0, const double* mu = nullptr,
-                       double* R = nullptr, const double* Psi2 = nullptr, double* trace_part = nullptr) {
-    hipLaunchKernelGGL(k_gemm32, dim3(Tn * (Tn + 1) / 2 * 4), dim3(256), 0, s, W, W, C, ld, Tn, 0, 0, rev, mu, R, Psi2,
-                       trace_part);
+                       double* R = nullptr, const double* Psi2 = nullptr, double* trace_part = nullptr,
+                       const UvArgs* uv = nullptr) {
+    const int extra = uv ? Tn * Tn : 0;                  // pass 2 of Uv rides in the same launch (uv_cols_role)
+    hipLaunchKernelGGL(k_gemm32, dim3(Tn * (Tn + 1) / 2 * 4 + extra), dim3(256), 0, s, W, W, C, ld, Tn, 0, 0, rev, mu, R, Psi2,
+                       trace_part, uv ? *uv : UvArgs{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -552,21 +554,22 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     double* uvt = h->dUvWork + 2 * (size_t)Qp;      // TQ x Qp tile contributions to t = W' P xi
     double* uvpart = uvt + (size_t)TQ * Qp;         // TQ x Qp tile partial sums
     hipLaunchKernelGGL(k_trmv_t, dim3(TQ * (TQ + 1) / 2), dim3(256), 0, s, (const double*)h->dWl, (const double*)h->dXi, uvt, Qp);
-    hipLaunchKernelGGL(k_trmv_mu_scan, dim3(Qp / 4 + 1), dim3(256), 0, s, (const double*)h->dWl, (const double*)uvt, h->dMu,
-                       uvp, uvck, uvak, Qp);
-    // Sigma = W'^T W' (index-reversed back), R = Sigma + mu mu^T and -- UniSGP -- the tr(R Psi2) shares, one launch
+    // mu, p, the alpha scan and (extra workgroups) pass 1 of Uv in one launch
+    hipLaunchKernelGGL(k_trmv_mu_scan, dim3(Qp / 4 + 1 + TQ * (TQ + 1) / 2), dim3(256), 0, s, (const double*)h->dWl,
+                       (const double*)uvt, h->dMu, uvp, uvck, uvak, uvpart, Qp);
+    // Sigma = W'^T W' (index-reversed back), R = Sigma + mu mu^T, -- UniSGP -- the tr(R Psi2) shares, and (extra workgroups)
+    // pass 2 of Uv = chol(Sigma_v + mu mu^T).U (GPnode/UniSGPnode.jl:67-69), one launch
     double* traceR = h->dTrace + TRACE_BLOCKS;
+    UvArgs uv;
+    uv.Wp = h->dWl; uv.p = uvp; uv.ck = uvck; uv.ak = uvak; uv.partial = uvpart; uv.LR = h->dUvT;
+    uv.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
     if (h->dout == 1) {
-        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, h->dStats, traceR);
+        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, h->dStats, traceR, &uv);
     } else {
-        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR);
+        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, nullptr, nullptr, &uv);
         hipLaunchKernelGGL(k_trace_R, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dR, traceR, M, Mp, h->dout, Qp,
                            (int64_t*)nullptr);
     }
-    // Uv = chol(Sigma_v + mu mu^T).U  (GPnode/UniSGPnode.jl:67-69)
-    hipLaunchKernelGGL(k_uv_partial, dim3(TQ * (TQ + 1) / 2), dim3(64), 0, s, (const double*)h->dWl, uvp, uvpart, Qp);
-    hipLaunchKernelGGL(k_uv_cols, dim3(TQ, TQ), dim3(64), 0, s, (const double*)h->dWl, uvp, uvck, uvak, uvpart, h->dUvT, Qp,
-                       h->dStamps + STAMP_STRIDE * SGP_T_FINISH1);
 }
 
 // after the join with the side stream (K_uu chain + tr(Kuu^-1 Psi2)): the scalars, one single-workgroup kernel
@@ -964,9 +967,9 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     const int n_uf = h->n > 0 ? h->nblk * T : 0;
     hipLaunchKernelGGL(k_form_G, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->dR, h->dKinv, dG, cnt);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)h->dKinv, (const double*)h->dStats, dT1,
-                       Mp, T, 3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
+                       Mp, T, 3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{});
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)dT1, (const double*)h->dKinv, dH, Mp, T,
-                       3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
+                       3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{});
     if (h->n > 0)
         hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
                            h->has_omega ? h->dOmega : nullptr, h->dMu, h->dParams, part_uf, Mp, T, h->D, h->n);

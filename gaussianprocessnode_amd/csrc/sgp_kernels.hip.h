@@ -1131,6 +1131,51 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     tile_s2g(X, A, ld, i0, j0);
 }
 
+// v[kk] = V[64 kb + kk][j] = W'[Qp-1-64kb-kk][Qp-1-j]: 64 contiguous doubles of column Qp-1-j of W' (descending), read
+// straight from the inverse factor -- every lane its own 512-byte run, fully used, so no transposed copy is needed.
+__device__ __forceinline__ void load_v_column(double (&v)[64], const double* __restrict__ Wp, int Qp, int kb, int j) {
+    const double2* src = reinterpret_cast<const double2*>(Wp + (size_t)(Qp - 1 - j) * Qp + (Qp - 64 * (kb + 1)));
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const double2 w = src[u];
+        v[63 - 2 * u] = w.x;
+        v[62 - 2 * u] = w.y;
+    }
+}
+
+// pass 2 of Uv, one wave per tile of the FULL tile grid: rows of tile (kb, jb) of Uv written into LR = Uv^T (zeros for
+// kb > jb).  Runs as the extra workgroups of the Sigma = W'^T W' launch (k_gemm32 mode 0): neither needs the other.
+struct UvArgs {
+    const double* Wp;        // nullptr: no Uv role in this launch
+    const double* p;
+    const double* ck;
+    const double* ak;
+    const double* partial;
+    double* LR;
+    int64_t* stamps;
+};
+__device__ __forceinline__ void uv_cols_role(const UvArgs& u, int Qp, int kb, int jb) {
+    const int lane = threadIdx.x, j = 64 * jb + lane;
+    double* out = u.LR + (size_t)(64 * kb) * Qp + j;
+    if (kb > jb) {
+#pragma unroll 16
+        for (int kk = 0; kk < 64; ++kk) out[(size_t)kk * Qp] = 0.0;
+        stamp_exit(u.stamps);
+        return;
+    }
+    double v[64];
+    load_v_column(v, u.Wp, Qp, kb, j);
+    double T = 0.0;
+    for (int b = jb; b > kb; --b) T += u.partial[(size_t)b * Qp + j];     // rows below this tile, nearest first: fixed order
+#pragma unroll
+    for (int kk = 63; kk >= 0; --kk) {
+        const int k = 64 * kb + kk;
+        out[(size_t)kk * Qp] = fma(u.ck[k], v[kk], u.ak[k] * T);
+        T = fma(u.p[k], v[kk], T);
+    }
+    stamp_exit(u.stamps);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Tile GEMM with 32 x 32 output per block (4 waves x one 16 x 16 MFMA tile), for M x M products where a 64 x 64 tiling
 // leaves too few blocks for 256 CUs.
@@ -1143,10 +1188,19 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
 __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
                                                 int ld, int Tn, int mode, int s, int rev, const double* __restrict__ mu,
                                                 double* __restrict__ R, const double* __restrict__ Psi2,
-                                                double* __restrict__ trace_part) {
+                                                double* __restrict__ trace_part, UvArgs uv) {
     __shared__ double As[64 * PS32];
     __shared__ double Bs[64 * PS32];
     __shared__ double tred[4];
+    if (mode == 0 && uv.Wp) {                                            // extra workgroups: pass 2 of Uv (uv_cols_role)
+        const int ngemm = Tn * (Tn + 1) / 2 * 4;
+        if ((int)blockIdx.x >= ngemm) {
+            if (threadIdx.x >= 64) return;
+            const int e = blockIdx.x - ngemm;
+            uv_cols_role(uv, ld, e % Tn, e / Tn);
+            return;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int quad = blockIdx.x & 3, qi = quad >> 1, qj = quad & 1;
     int I, J, kbeg, kend;
@@ -1262,7 +1316,8 @@ __global__ void __launch_bounds__(256) k_trmv_t(const double* __restrict__ W, co
 // ck[k] = C_kk, ak[k] = p_k / sqrt(alpha_k alpha_{k+1}).
 __global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__ W, const double* __restrict__ tpart,
                                                       double* __restrict__ mu, double* __restrict__ p,
-                                                      double* __restrict__ ck, double* __restrict__ ak, int Qp) {
+                                                      double* __restrict__ ck, double* __restrict__ ak,
+                                                      double* __restrict__ uvpart, int Qp) {
     __shared__ double ts[CU_MAXQ];
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < Qp; i += 256) {        // t_i = sum of the tile contributions kt = 0 .. i / 64
@@ -1271,6 +1326,21 @@ __global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__
         ts[i] = v;
     }
     __syncthreads();
+    if ((int)blockIdx.x > Qp / 4) {
+        // workgroups beyond the mat-vec and the scan: pass 1 of Uv, one wave per 64 x 64 tile (kb <= jb) of V:
+        //   partial[kb][j] = sum_kk p_{64 kb + kk} V[64 kb + kk][j],  p = P t straight from the LDS copy of t
+        if (threadIdx.x >= 64) return;
+        int jb, kb;
+        tile_from_index(blockIdx.x - Qp / 4 - 1, jb, kb);            // jb >= kb
+        const int j = 64 * jb + lane;
+        double v[64];
+        load_v_column(v, W, Qp, kb, j);
+        double sacc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) sacc = fma(ts[Qp - 1 - (64 * kb + kk)], v[kk], sacc);
+        uvpart[(size_t)kb * Qp + j] = sacc;
+        return;
+    }
     if ((int)blockIdx.x == Qp / 4) {
         if (threadIdx.x >= 64) return;
         const int per = (Qp + 63) / 64;
@@ -1298,58 +1368,6 @@ __global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__
     for (int i = k + lane; i < Qp; i += 64) s = fma(col[i], ts[i], s);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) mu[Qp - 1 - k] = s;
-}
-
-// v[kk] = V[64 kb + kk][j] = W'[Qp-1-64kb-kk][Qp-1-j]: 64 contiguous doubles of column Qp-1-j of W' (descending), read
-// straight from the inverse factor -- every lane its own 512-byte run, fully used, so no transposed copy is needed.
-__device__ __forceinline__ void load_v_column(double (&v)[64], const double* __restrict__ Wp, int Qp, int kb, int j) {
-    const double2* src = reinterpret_cast<const double2*>(Wp + (size_t)(Qp - 1 - j) * Qp + (Qp - 64 * (kb + 1)));
-#pragma unroll
-    for (int u = 0; u < 32; ++u) {
-        const double2 w = src[u];
-        v[63 - 2 * u] = w.x;
-        v[62 - 2 * u] = w.y;
-    }
-}
-
-// pass 1, one wave per 64 x 64 tile (kb <= jb) of V: partial[kb][j] = sum_{kk} p_{64 kb + kk} V[64 kb + kk][j]
-__global__ void __launch_bounds__(64) k_uv_partial(const double* __restrict__ Wp, const double* __restrict__ p,
-                                                   double* __restrict__ partial, int Qp) {
-    int jb, kb;
-    tile_from_index(blockIdx.x, jb, kb);                 // jb >= kb
-    const int lane = threadIdx.x, j = 64 * jb + lane;
-    double v[64];
-    load_v_column(v, Wp, Qp, kb, j);
-    double s = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < 64; ++kk) s = fma(p[64 * kb + kk], v[kk], s);
-    partial[(size_t)kb * Qp + j] = s;
-}
-
-// pass 2, one wave per tile of the FULL tile grid: rows of tile (kb, jb) of Uv written into LR = Uv^T (zeros for kb > jb)
-__global__ void __launch_bounds__(64) k_uv_cols(const double* __restrict__ Wp, const double* __restrict__ p,
-                                                const double* __restrict__ ck, const double* __restrict__ ak,
-                                                const double* __restrict__ partial, double* __restrict__ LR, int Qp, int64_t* stamps) {
-    const int kb = blockIdx.x, jb = blockIdx.y;
-    const int lane = threadIdx.x, j = 64 * jb + lane;
-    double* out = LR + (size_t)(64 * kb) * Qp + j;
-    if (kb > jb) {
-#pragma unroll 16
-        for (int kk = 0; kk < 64; ++kk) out[(size_t)kk * Qp] = 0.0;
-        stamp_exit(stamps);
-        return;
-    }
-    double v[64];
-    load_v_column(v, Wp, Qp, kb, j);
-    double T = 0.0;
-    for (int b = jb; b > kb; --b) T += partial[(size_t)b * Qp + j];       // rows below this tile, nearest first... fixed order
-#pragma unroll
-    for (int kk = 63; kk >= 0; --kk) {
-        const int k = 64 * kb + kk;
-        out[(size_t)kk * Qp] = fma(ck[k], v[kk], ak[k] * T);
-        T = fma(p[k], v[kk], T);
-    }
-    stamp_exit(stamps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1407,11 +1425,52 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
                                                  int lam_off, int64_t* stamps, int64_t* all_stamps,
                                                  int64_t* totals) {
     __shared__ double red[4];
+    __shared__ double redn[4 * 5];
     __shared__ double tr[TRACE_SLOTS];
     stamp_enter(stamps);
     const double* B = stats + (size_t)Mp * Mp;
     const double* sc = B + (size_t)Mp * d_out;
     const int tid = threadIdx.x;
+    if (d_out == 1) {
+        // UniSGP: every thread's share of all five sums first (independent loads, one memory round trip), then ONE
+        // workgroup reduction -- this kernel is the last link of the critical path
+        double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};         // tr(Kuu^-1 Psi2), tr(R Psi2), log|L_K|, log|L_Lambda|, b' mu
+        for (int b = tid; b < nK; b += 256) v[0] += partK[b];
+        for (int b = tid; b < nR; b += 256) v[1] += partR[b];
+        for (int e = tid; e < M; e += 256) {
+            v[2] += log(Lkuu[(size_t)e * Mp + e]);
+            v[4] = fma(B[e], mu[e], v[4]);
+        }
+        for (int e = tid; e < Q; e += 256) v[3] += log(Llam[(size_t)(e + lam_off) * Qp + e + lam_off]);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) redn[(tid >> 6) * 5 + i] = v[i];
+        __syncthreads();
+        if (tid == 0) {
+            double t[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) t[i] = (redn[i] + redn[5 + i]) + (redn[10 + i] + redn[15 + i]);
+            const double LOG2PI = 1.8378770664093454835606594728112;
+            const double n = sc[2], w = P->W[0];
+            const double sum_I1 = P->sigma2 * sc[1] - t[0];
+            const double sum_I2 = sc[0] - 2.0 * t[4] + t[1];
+            out[0] = sum_I1;
+            out[1] = sum_I2;
+            out[2] = 0.5 * (w * (sum_I1 + sum_I2) - n * P->E_logw + n * LOG2PI);
+            out[3] = (double)info[0];
+            out[4] = (double)info[1];
+            out[5] = (double)info[2];
+            out[6] = 2.0 * t[2];
+            out[7] = 2.0 * t[3];
+        }
+        stamp_exit(stamps);
+        __syncthreads();
+        if (all_stamps && tid < 64) stamp_accumulate(all_stamps, totals, tid);
+        return;
+    }
     {   // wave w reduces slots w, w + 4, ... (slot 0: tr(Kuu^-1 Psi2), slot 1 + a + b d_out: tr(Rblk[a][b] Psi2)):
         // the lanes stride over the block partials in a fixed order, then a butterfly sum
         const int lane = tid & 63, wave = tid >> 6, nslotR = d_out * d_out;
