@@ -67,7 +67,7 @@ struct sgp_handle {
     Params* dParamsK = nullptr;    // the K_uu chain's own copy (it runs on the side stream)
     double* dXusK = nullptr;
     hipStream_t own = nullptr, side = nullptr;
-    hipEvent_t evFork = nullptr, evSide = nullptr, evStats = nullptr;
+    hipEvent_t evSide = nullptr, evDone = nullptr;
     int nchunks = 1, chunk = 0, nblk = 0, ntiles = 0;
     int64_t stats_count = 0;
     size_t slab_capacity = 0;
@@ -142,11 +142,11 @@ static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, doub
 }
 // C = W^T W (rev: written index-reversed).  With mu: also R = C + mu mu^T, and with Psi2 the per-block shares of tr(R Psi2).
 static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s, int rev = 0, const double* mu = nullptr,
-                       double* R = nullptr, const double* Psi2 = nullptr, double* trace_part = nullptr,
-                       const UvArgs* uv = nullptr) {
+                       double* R = nullptr, const double* Psi2 = nullptr, const double* Kinv = nullptr,
+                       double* trace_part = nullptr, const UvArgs* uv = nullptr) {
     const int extra = uv ? Tn * Tn : 0;                  // pass 2 of Uv rides in the same launch (uv_cols_role)
     hipLaunchKernelGGL(k_gemm32, dim3(Tn * (Tn + 1) / 2 * 4 + extra), dim3(256), 0, s, W, W, C, ld, Tn, 0, 0, rev, mu, R, Psi2,
-                       trace_part, uv ? *uv : UvArgs{});
+                       Kinv, trace_part, uv ? *uv : UvArgs{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -233,7 +233,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dXi0, Qp);
     ALLOC(h->dOut, SGP_R_COUNT);
     ALLOC(h->dWishart, MAXO * MAXO);
-    ALLOC(h->dTrace, (size_t)TRACE_BLOCKS + std::max((size_t)TRACE_BLOCKS * MAXO * MAXO, (size_t)h->TQ * (h->TQ + 1) * 2));
+    ALLOC(h->dTrace, (size_t)TRACE_BLOCKS + std::max((size_t)TRACE_BLOCKS * MAXO * MAXO, (size_t)h->TQ * (h->TQ + 1) * 4));
     ALLOC(h->dInfo, 4);
     ALLOC(h->dStamps, STAMP_STRIDE * SGP_T_COUNT);
     ALLOC(h->dStampTotals, SGP_T_COUNT + 1);
@@ -258,9 +258,8 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     h->hParams->prior_iso = 1.0;
     if (hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking) != hipSuccess ||
         create_low_priority_stream(&h->side) != hipSuccess ||
-        hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evSide, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->evStats, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->evDone, hipEventDisableTiming) != hipSuccess) {
         g_create_error = "stream/event creation failed";
         sgp_destroy(h);
         return SGP_ERR_HIP;
@@ -290,9 +289,8 @@ extern "C" int sgp_destroy(sgp_handle* h) {
                     h->dGradM, h->dGradPart, h->dGrad};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
-    if (h->evFork) hipEventDestroy(h->evFork);
     if (h->evSide) hipEventDestroy(h->evSide);
-    if (h->evStats) hipEventDestroy(h->evStats);
+    if (h->evDone) hipEventDestroy(h->evDone);
     if (h->own) hipStreamDestroy(h->own);
     if (h->side) hipStreamDestroy(h->side);
     delete h;
@@ -557,29 +555,37 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     // mu, p, the alpha scan and (extra workgroups) pass 1 of Uv in one launch
     hipLaunchKernelGGL(k_trmv_mu_scan, dim3(Qp / 4 + 1 + TQ * (TQ + 1) / 2), dim3(256), 0, s, (const double*)h->dWl,
                        (const double*)uvt, h->dMu, uvp, uvck, uvak, uvpart, Qp);
-    // Sigma = W'^T W' (index-reversed back), R = Sigma + mu mu^T, -- UniSGP -- the tr(R Psi2) shares, and (extra workgroups)
-    // pass 2 of Uv = chol(Sigma_v + mu mu^T).U (GPnode/UniSGPnode.jl:67-69), one launch
-    double* traceR = h->dTrace + TRACE_BLOCKS;
+}
+
+// after the join with the side stream (K_uu chain): Sigma, R, the traces, Uv pass 2 and the scalars
+static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
+    const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp, TQ = h->TQ;
+    double* uvp = h->dXi;
+    double* uvck = h->dUvWork;
+    double* uvak = h->dUvWork + Qp;
+    double* uvpart = h->dUvWork + 2 * (size_t)Qp + (size_t)TQ * Qp;
+    // Sigma = W'^T W' (index-reversed back), R = Sigma + mu mu^T, -- UniSGP -- the shares of tr(R Psi2) and tr(Kuu^-1 Psi2),
+    // and (extra workgroups) pass 2 of Uv = chol(Sigma_v + mu mu^T).U (GPnode/UniSGPnode.jl:67-69): one launch
+    const int nata = TQ * (TQ + 1) / 2 * 4;
+    double* traceR = h->dTrace + TRACE_BLOCKS;           // UniSGP: [nata] R shares, then [nata] K shares
+    const double* partK = h->dTrace;
+    int nK = TRACE_BLOCKS, nR = TRACE_BLOCKS;
     UvArgs uv;
     uv.Wp = h->dWl; uv.p = uvp; uv.ck = uvck; uv.ak = uvak; uv.partial = uvpart; uv.LR = h->dUvT;
     uv.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
     if (h->dout == 1) {
-        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, h->dStats, traceR, &uv);
+        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, h->dStats, h->dKinv, traceR, &uv);
+        partK = traceR + nata;
+        nK = nR = nata;
     } else {
-        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, nullptr, nullptr, &uv);
+        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, nullptr, nullptr, nullptr, &uv);
+        hipLaunchKernelGGL(k_trace_kinv, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dTrace, M, Mp);
         hipLaunchKernelGGL(k_trace_R, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dR, traceR, M, Mp, h->dout, Qp,
                            (int64_t*)nullptr);
     }
-}
-
-// after the join with the side stream (K_uu chain + tr(Kuu^-1 Psi2)): the scalars, one single-workgroup kernel
-static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
-    const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
-    const int nR = (h->dout == 1) ? h->TQ * (h->TQ + 1) / 2 * 4 : TRACE_BLOCKS;
-    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, (const double*)h->dTrace, (int)TRACE_BLOCKS,
-                       (const double*)(h->dTrace + TRACE_BLOCKS), nR, h->dMu, h->dKuu, h->dLam, h->dInfo, h->dParams, h->dOut,
-                       h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q, h->dStamps + STAMP_STRIDE * SGP_T_FINISH2, h->dStamps,
-                       h->dStampTotals);
+    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, partK, nK, (const double*)traceR, nR, h->dMu, h->dKuu,
+                       h->dLam, h->dInfo, h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q,
+                       h->dStamps + STAMP_STRIDE * SGP_T_FINISH2, h->dStamps, h->dStampTotals);
 }
 
 typedef void (*enqueue_fn)(sgp_handle*, hipStream_t);
@@ -617,52 +623,43 @@ extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
     h->in_flight = true;
+    // The K_uu chain depends on theta and Xu only: it starts on the (low-priority) side stream as soon as the previous
+    // sweep has finished with its outputs, runs beside the data-sized kernels, the all-reduce and the Lambda chain, and is
+    // joined just before the Sigma launch.  The main stream itself only ever WAITS on the side stream's event and records
+    // one event at the very end of a sweep: an event record between two of its kernels was measured at ~6 us of idle time.
+    HIPCHK(h, hipStreamWaitEvent(h->side, h->evDone, 0));
+    rc = run_sequence(h, h->gKuu, enqueue_kuu, h->side);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->evSide, h->side));
     rc = run_sequence(h, h->gLocal, enqueue_local, s);
     if (rc) return rc;
     h->stats_dirty = false;
     h->swept_params = *h->hParams;
     h->swept_data_gen = h->data_gen;
-    // fork: the K_uu chain starts on the side stream AFTER the data-sized kernels (they want the whole chip; the chain
-    // is a few-CU latency-bound sequence that then runs beside the all-reduce and the Lambda chain of sgp_sweep_finish)
-    HIPCHK(h, hipEventRecord(h->evFork, s));
-    HIPCHK(h, hipStreamWaitEvent(h->side, h->evFork, 0));
-    rc = run_sequence(h, h->gKuu, enqueue_kuu, h->side);
-    if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->evSide, h->side));
     h->swept_local = true;
     return 0;
 }
 
-// `stats_final_at_fork`: the statistics were already final when sgp_sweep_local forked the side stream (single-GPU
-// sgp_sweep); otherwise (an all-reduce sits between the two halves) the side stream first waits for the caller's stream.
-static int sweep_finish_impl(sgp_handle* h, void* stream, bool stats_final_at_fork) {
+extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
     if (!h) return SGP_ERR_ARG;
     if (!h->swept_local) return fail(h, SGP_ERR_ARG, "sgp_sweep_finish: call sgp_sweep_local first");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
     h->in_flight = true;
-    // side stream, behind the K_uu chain: tr(Kuu^-1 Psi2) of the (by now reduced) statistics -- off the critical path
-    if (!stats_final_at_fork) {
-        HIPCHK(h, hipEventRecord(h->evStats, s));
-        HIPCHK(h, hipStreamWaitEvent(h->side, h->evStats, 0));
-    }
-    hipLaunchKernelGGL(k_trace_kinv, dim3(TRACE_BLOCKS), dim3(256), 0, h->side, h->dStats, h->dKinv, h->dTrace, h->M, h->Mp);
-    HIPCHK(h, hipEventRecord(h->evSide, h->side));
     int rc = run_sequence(h, h->gFinish, enqueue_finish1, s);
     if (rc) return rc;
-    HIPCHK(h, hipStreamWaitEvent(s, h->evSide, 0));          // join with the side stream
+    HIPCHK(h, hipStreamWaitEvent(s, h->evSide, 0));          // join with the K_uu chain
     rc = run_sequence(h, h->gFinish2, enqueue_finish2, s);
     if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->evDone, s));                 // the next sweep's K_uu chain may overwrite K_uu^-1 after this
     h->swept = true;
     return 0;
 }
 
-extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) { return sweep_finish_impl(h, stream, false); }
-
 extern "C" int sgp_sweep(sgp_handle* h, void* stream) {
     int rc = sgp_sweep_local(h, stream);
     if (rc) return rc;
-    return sweep_finish_impl(h, stream, true);
+    return sgp_sweep_finish(h, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -967,9 +964,9 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     const int n_uf = h->n > 0 ? h->nblk * T : 0;
     hipLaunchKernelGGL(k_form_G, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->dR, h->dKinv, dG, cnt);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)h->dKinv, (const double*)h->dStats, dT1,
-                       Mp, T, 3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{});
+                       Mp, T, 3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{});
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)dT1, (const double*)h->dKinv, dH, Mp, T,
-                       3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{});
+                       3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{});
     if (h->n > 0)
         hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
                            h->has_omega ? h->dOmega : nullptr, h->dMu, h->dParams, part_uf, Mp, T, h->D, h->n);

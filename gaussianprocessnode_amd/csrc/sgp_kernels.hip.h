@@ -1184,11 +1184,12 @@ __device__ __forceinline__ void uv_cols_role(const UvArgs& u, int Qp, int kb, in
 // (I, J, k are 64-tile indices; W lower triangular, so the k range skips the structural zeros.)
 // ------------------------------------------------------------------------------------------------
 // mode 0 extras (all nullable): with `mu` the kernel also writes R = C + mu mu^T (Sigma_v + mu mu^T, GPnode/UniSGPnode.jl:67)
-// and, with `Psi2`, the block's share of tr(R Psi2) into trace_part[blockIdx.x] (the sum I2 trace of :196-238, d_out = 1).
+// and, with `Psi2` (d_out = 1), the block's shares of the two traces of the :w rule / average energy (:196-238, :337-359):
+// tr(R Psi2) into trace_part[blockIdx.x] and tr(Kuu^-1 Psi2) into trace_part[n + blockIdx.x], n = the launch's Tn (Tn + 1) / 2 * 4 product workgroups.
 __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
                                                 int ld, int Tn, int mode, int s, int rev, const double* __restrict__ mu,
                                                 double* __restrict__ R, const double* __restrict__ Psi2,
-                                                double* __restrict__ trace_part, UvArgs uv) {
+                                                const double* __restrict__ Kinv, double* __restrict__ trace_part, UvArgs uv) {
     __shared__ double As[64 * PS32];
     __shared__ double Bs[64 * PS32];
     __shared__ double tred[4];
@@ -1225,7 +1226,7 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
 #pragma unroll
         for (int k4 = 0; k4 < 16; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k4 * 4 * PS32], bp[k4 * 4 * PS32], acc, 0, 0, 0);
     }
-    double tsum = 0.0;
+    double tsum = 0.0, tsumK = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         int row = r0 + wr * 16 + lk + 4 * r, col = c0 + wc * 16 + li;
@@ -1238,7 +1239,11 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
                 const double rv = fma(mu[row], mu[col], v);
                 R[(size_t)col * ld + row] = rv;
                 R[(size_t)row * ld + col] = rv;
-                if (Psi2) tsum = fma(rv, Psi2[(size_t)col * ld + row], tsum);
+                if (Psi2) {
+                    const double ps = Psi2[(size_t)col * ld + row];
+                    tsum = fma(rv, ps, tsum);
+                    tsumK = fma(Kinv[(size_t)col * ld + row], ps, tsumK);
+                }
             }
         } else {
             C[(size_t)col * ld + row] = v;
@@ -1246,9 +1251,13 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
     }
     if (mode == 0 && trace_part) {
         // off-diagonal tiles stand for both mirror images; on diagonal tiles all four quadrants are computed
-        if (I != J) tsum *= 2.0;
+        if (I != J) { tsum *= 2.0; tsumK *= 2.0; }
         tsum = block_sum(tsum, tred);
-        if (tid == 0) trace_part[blockIdx.x] = tsum;
+        tsumK = block_sum(tsumK, tred);
+        if (tid == 0) {
+            trace_part[blockIdx.x] = tsum;
+            trace_part[Tn * (Tn + 1) / 2 * 4 + blockIdx.x] = tsumK;
+        }
     }
 }
 
