@@ -822,25 +822,36 @@ struct LamForm {
     int M, Mp, d_out, Q, prior_form;
     int64_t* stamps;
 };
-// (branch-free on purpose: with the loads under a data-dependent branch the compiler waits for each of a thread's 16 loads
-// in turn -- measured 13 us for step 0 instead of 1)
-__device__ __forceinline__ double lambda_entry(const LamForm& f, int gi, int gj, int Qp) {
+// Straight-line on purpose, with the two uniform choices (dense prior? several outputs?) made OUTSIDE the 16-entry loop:
+// any branch inside it splits the loop body into basic blocks, the compiler then waits for each load before the next is
+// issued, and step 0 was measured 13-15 us longer than a step that just loads its tiles.
+template <bool DENSE, bool MULTI>
+__device__ __forceinline__ double lambda_entry(const LamForm& f, int gi, int gj, int Qp, double prior_iso, double w00) {
     const bool inside = gi < f.Q && gj < f.Q;
     const int si = inside ? gi : 0, sj = inside ? gj : 0;              // safe indices for the pad entries
     int a = 0, i = si, b = 0, j = sj;
-    if (f.d_out > 1) { a = si / f.M; i = si % f.M; b = sj / f.M; j = sj % f.M; }
+    if constexpr (MULTI) { a = si / f.M; i = si % f.M; b = sj / f.M; j = sj % f.M; }
     const double psi = f.stats[(size_t)j * f.Mp + i];
     const double diag = (gi == gj) ? 1.0 : 0.0;
-    const double prior = (f.prior_form == 1) ? f.Lambda0[(size_t)sj * Qp + si] : diag * f.P->prior_iso;
-    return inside ? fma(f.P->W[a + b * f.d_out], psi, prior) : diag;
+    double prior, w;
+    if constexpr (DENSE) prior = f.Lambda0[(size_t)sj * Qp + si]; else prior = diag * prior_iso;
+    if constexpr (MULTI) w = f.P->W[a + b * f.d_out]; else w = w00;
+    return inside ? fma(w, psi, prior) : diag;
 }
 // tile (row0.., col0..) of P Lambda P: entry (r, c) is Lambda[Qp-1-r][Qp-1-c]
-__device__ __forceinline__ void tile_form_r(TileRegs& t, const LamForm& f, int Qp, int row0, int col0) {
+template <bool DENSE, bool MULTI>
+__device__ __forceinline__ void tile_form_r_impl(TileRegs& t, const LamForm& f, int Qp, int row0, int col0) {
+    const double prior_iso = f.P->prior_iso, w00 = f.P->W[0];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         int e = threadIdx.x + 256 * u, c = e >> 6, r = e & 63;
-        t.v[u] = lambda_entry(f, Qp - 1 - (row0 + r), Qp - 1 - (col0 + c), Qp);
+        t.v[u] = lambda_entry<DENSE, MULTI>(f, Qp - 1 - (row0 + r), Qp - 1 - (col0 + c), Qp, prior_iso, w00);
     }
+}
+__device__ __forceinline__ void tile_form_r(TileRegs& t, const LamForm& f, int Qp, int row0, int col0) {
+    const bool dense = f.prior_form == 1, multi = f.d_out > 1;
+    if (dense) { if (multi) tile_form_r_impl<true, true>(t, f, Qp, row0, col0); else tile_form_r_impl<true, false>(t, f, Qp, row0, col0); }
+    else       { if (multi) tile_form_r_impl<false, true>(t, f, Qp, row0, col0); else tile_form_r_impl<false, false>(t, f, Qp, row0, col0); }
 }
 __device__ __forceinline__ void tile_r2s(double* S, const TileRegs& t) {
 #pragma unroll
