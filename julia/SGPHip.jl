@@ -122,6 +122,18 @@ function predict(meta, Xstar::Matrix{Float64}, μ_v::Vector{Float64}, θ)
     return out
 end
 
+# ---- hyper-parameter objective and gradient (replace neg_log_backwardmess_fast / grad_llh_new!,
+# helper_functions/derivative_helper.jl:23-39,55-63) at the theta of the last sweep, q(v) fixed --------------------
+# Returns (F, dF/d(sigma2, ell...)); the caller applies the chain rule of its kernel_gp(theta) (softplus in the notebooks).
+function theta_objective(meta, nparams::Int)
+    st = STATE[meta]; f = Ref{Float64}(0.0); g = zeros(nparams)
+    check(ccall((:sgp_theta_objective, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}), st.handle, f, g), st.handle)
+    return f[], g
+end
+
+# ---- minibatch loops (experiments/regression_kin40k.ipynb:205-212): prior <- posterior without leaving the device
+carry_posterior!(meta) = (st = STATE[meta]; check(ccall((:sgp_carry_posterior, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), st.handle, C_NULL), st.handle))
+
 end # module
 
 # ---- dispatch glue: the reference's rules stay for metas that are not attached ------------------------------
