@@ -73,6 +73,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: SGP_BENCH_REHEARSAL=1 puts every rank on device 0 and uses gloo for the collective
+    # (RCCL refuses two ranks on one device); numbers from such a run mean nothing, it only exercises the N > 1 code path
+    rehearsal = os.environ.get("SGP_BENCH_REHEARSAL") is not None
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run")
     if not torch.cuda.is_available():
@@ -80,7 +85,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     N, M, D = WORKLOADS[args.workload]
     X, Xu, y, Xt, yt = synthetic(N, M, D)
