@@ -181,6 +181,14 @@ def main():
         except ImportError:                                      # pragma: no cover
             threadpool_limits = None
         cores = min(16, os.cpu_count() or 1)
+        # Never RAISE the BLAS thread count above what it was initialised with: torch.distributed.run exports
+        # OMP_NUM_THREADS=1, and lifting OpenBLAS from 1 to 16 threads afterwards segfaults inside scipy's Cholesky
+        # (seen in the two-rank rehearsal).  N > 1 runs carry no CPU baseline anyway.
+        for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+            if os.environ.get(var, "").isdigit():
+                cores = min(cores, int(os.environ[var]))
+        if world > 1:
+            threadpool_limits = None
         Lam0, xi0 = np.eye(M) / PRIOR_VAR, np.zeros(M)
 
         def cpu_sweep():
