@@ -952,14 +952,14 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     if (!h->dGradM) {
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGradM), sizeof(double) * 3 * (size_t)Mp * Mp));
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGradPart),
-                            sizeof(double) * ((size_t)std::max(nblk_max, 1) * T + GRAD_UU_BLOCKS) * GRAD_SLOTS));
+                            sizeof(double) * ((size_t)std::max(nblk_max, 1) * T + (size_t)T * T) * GRAD_SLOTS));
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGrad), sizeof(double) * GRAD_SLOTS));
     }
     double* dG = h->dGradM;
     double* dT1 = dG + (size_t)Mp * Mp;
     double* dH = dT1 + (size_t)Mp * Mp;
     double* part_uu = h->dGradPart;
-    double* part_uf = h->dGradPart + (size_t)GRAD_UU_BLOCKS * GRAD_SLOTS;
+    double* part_uf = h->dGradPart + (size_t)T * T * GRAD_SLOTS;
     const size_t cnt = (size_t)Mp * Mp;
     const int n_uf = h->n > 0 ? h->nblk * T : 0;
     hipLaunchKernelGGL(k_form_G, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->dR, h->dKinv, dG, cnt);
@@ -970,9 +970,8 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     if (h->n > 0)
         hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
                            h->has_omega ? h->dOmega : nullptr, h->dMu, h->dParams, part_uf, Mp, T, h->D, h->n);
-    hipLaunchKernelGGL(k_theta_grad_uu, dim3(GRAD_UU_BLOCKS), dim3(256), 0, s, dH, h->dXus, h->dParams, part_uu, h->M, Mp,
-                       h->D);
-    hipLaunchKernelGGL(k_theta_grad_finish, dim3(1), dim3(64), 0, s, part_uf, n_uf, part_uu, (int)GRAD_UU_BLOCKS,
+    hipLaunchKernelGGL(k_theta_grad_uu, dim3(T, T), dim3(256), 0, s, dH, h->dXus, h->dParams, part_uu, h->M, Mp, h->D);
+    hipLaunchKernelGGL(k_theta_grad_finish, dim3(1), dim3(64), 0, s, part_uf, n_uf, part_uu, T * T,
                        h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, h->dParams, h->dGrad, h->D, h->n_ell);
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());

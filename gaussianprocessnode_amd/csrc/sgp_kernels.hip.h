@@ -1753,7 +1753,6 @@ __global__ void __launch_bounds__(256) k_transpose(const double* __restrict__ A,
 // k_theta_grad_finish: fixed-order sum of the partials (bitwise reproducible) and the chain-rule factors.
 // ------------------------------------------------------------------------------------------------
 constexpr int GRAD_SLOTS = MAXD + 1;
-constexpr int GRAD_UU_BLOCKS = 64;
 
 __global__ void __launch_bounds__(256) k_form_G(const double* __restrict__ R, const double* __restrict__ Kinv,
                                                 double* __restrict__ G, size_t count) {
@@ -1856,27 +1855,55 @@ __global__ void __launch_bounds__(256) k_theta_grad_uf(const double* __restrict_
             (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
 }
 
+// one 64 x 64 tile of H o dK_uu per workgroup (grid T x T): the kernel value is computed once per entry, 16 entries per
+// thread stay in registers across the D + 1 contractions.  (A first version re-evaluated the kernel in every pass with
+// 64 workgroups striding over the matrix: 280 us at M = 600 -- a quarter of a training step.)
 __global__ void __launch_bounds__(256) k_theta_grad_uu(const double* __restrict__ H, const double* __restrict__ Xus,
                                                        const Params* __restrict__ P, double* __restrict__ partial,
                                                        int M, int Mp, int D) {
+    __shared__ double ui[MAXD * TB];
+    __shared__ double uj[MAXD * TB];
     __shared__ double red[4];
     const int tid = threadIdx.x;
+    const int I = blockIdx.x * TB, J = blockIdx.y * TB;
+    for (int t = tid; t < D * TB; t += 256) {
+        const int d = t / TB, r = t % TB;
+        ui[t] = Xus[(size_t)d * Mp + I + r];
+        uj[t] = Xus[(size_t)d * Mp + J + r];
+    }
+    __syncthreads();
+    const int r = tid & 63, c0 = (tid >> 6) * 16;
     const double s2 = P->sigma2;
-    // slot -1 (sum H o K) and one slot per dimension; the kernel value is recomputed per pass (M^2 (D + 1) exps: noise)
-    for (int slot = 0; slot <= D; ++slot) {
-        double e = 0.0;
-        for (int j = blockIdx.x; j < M; j += gridDim.x)
-            for (int i = tid; i < M; i += 256) {
-                double d2 = 0.0, td = 1.0;
-                for (int d = 0; d < D; ++d) {
-                    double t = Xus[(size_t)d * Mp + i] - Xus[(size_t)d * Mp + j];
-                    d2 = fma(t, t, d2);
-                    if (d + 1 == slot) td = t * t;
-                }
-                e = fma(H[(size_t)j * Mp + i] * (s2 * exp(-0.5 * d2)), td, e);
-            }
-        e = block_sum(e, red);
-        if (tid == 0) partial[(size_t)blockIdx.x * GRAD_SLOTS + slot] = e;
+    double hk[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double t = ui[d * TB + r] - uj[d * TB + c0 + e];
+            d2 = fma(t, t, d2);
+        }
+        const bool in = (I + r < M) && (J + c0 + e < M);
+        const double h = H[(size_t)(J + c0 + e) * Mp + I + r];
+        hk[e] = in ? h * (s2 * exp(-0.5 * d2)) : 0.0;
+    }
+    double* out = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GRAD_SLOTS;
+    {
+        double v = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v += hk[e];
+        v = block_sum(v, red);
+        if (tid == 0) out[0] = v;
+    }
+    for (int d = 0; d < D; ++d) {
+        const double a = ui[d * TB + r];
+        double v = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const double t = a - uj[d * TB + c0 + e];
+            v = fma(hk[e], t * t, v);
+        }
+        v = block_sum(v, red);
+        if (tid == 0) out[1 + d] = v;
     }
 }
 
