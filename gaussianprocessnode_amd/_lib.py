@@ -25,7 +25,7 @@ EXPORTS = [
     "sgp_abi_version", "sgp_create", "sgp_destroy", "sgp_last_error", "sgp_set_inducing", "sgp_set_data",
     "sgp_set_kernel", "sgp_set_output_cov_sum", "sgp_set_prior", "sgp_set_noise", "sgp_sweep_local", "sgp_sweep_finish", "sgp_sweep",
     "sgp_stats_layout", "sgp_bind_stats", "sgp_get_posterior", "sgp_get_scalars", "sgp_get_stats",
-    "sgp_get_kuu_chol", "sgp_get_wishart_invscale", "sgp_w_stats", "sgp_predict", "sgp_theta_objective", "sgp_carry_posterior",
+    "sgp_get_kuu_chol", "sgp_get_wishart_invscale", "sgp_w_stats", "sgp_predict", "sgp_theta_objective", "sgp_carry_posterior", "sgp_set_posterior",
     "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_get_phase_totals", "sgp_time_kernel",
 ]
 
@@ -97,6 +97,7 @@ def load(build_if_missing: bool = True):
     lib.sgp_get_wishart_invscale.argtypes = [vp, dp]
     lib.sgp_w_stats.argtypes = [vp, dp, dp, vp]
     lib.sgp_carry_posterior.argtypes = [vp, vp]
+    lib.sgp_set_posterior.argtypes = [vp, dp, dp]
     lib.sgp_predict.argtypes = [vp, dp, C.c_int64, dp, dp]
     lib.sgp_theta_objective.argtypes = [vp, dp, dp]
     lib.sgp_kernelmatrix.argtypes = [C.c_int32, dp, C.c_int64, dp, C.c_int64, C.c_int32, C.c_double, dp, C.c_int32, dp]

@@ -677,6 +677,27 @@ static int download_square(sgp_handle* h, const double* dsrc, int ld, int n, dou
     return 0;
 }
 
+// Install an externally given q(v) for the per-point outputs: mu_v and Uv = chol(Sigma_v + mu mu^T).U.  The reference's
+// cold rules are called with an arbitrary q_v / meta.Uv (GPtest.jl:173-181,221-229,257-292): with this, sgp_w_stats
+// evaluates them at that posterior for whatever points sgp_set_data + sgp_sweep_local put on the device.
+extern "C" int sgp_set_posterior(sgp_handle* h, const double* mu_v, const double* Uv) {
+    if (!h || !mu_v || !Uv) return fail(h, SGP_ERR_ARG, "sgp_set_posterior: null argument");
+    if (int qrc = quiesce(h)) return qrc;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t Q = h->Q, Qp = h->Qp;
+    std::vector<double> m(Qp, 0.0), ut(Qp * Qp, 0.0);
+    memcpy(m.data(), mu_v, Q * sizeof(double));
+    for (size_t k = 0; k < Qp; ++k) {
+        if (k >= Q) { ut[k * Qp + k] = 1.0; continue; }
+        for (size_t j = k; j < Q; ++j) ut[k * Qp + j] = Uv[k + j * Q];      // column k of Uv^T = row k of Uv (upper part)
+    }
+    HIPCHK(h, hipMemcpy(h->dMu, m.data(), Qp * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->dUvT, ut.data(), Qp * Qp * sizeof(double), hipMemcpyHostToDevice));
+    h->swept = true;
+    h->stats_dirty = true;                     // q(v) no longer belongs to the statistics on the device
+    return 0;
+}
+
 extern "C" int sgp_get_scalars(sgp_handle* h, double* out) {
     if (!h || !out) return fail(h, SGP_ERR_ARG, "sgp_get_scalars: null argument");
     if (!h->swept) return fail(h, SGP_ERR_ARG, "sgp_get_scalars: no finished sweep");

@@ -167,6 +167,12 @@ class SGPDevice:
         check(self._lib.sgp_predict(self._h, ptr(Xs), ns, ptr(mu), ptr(out)), self._h, "sgp_predict")
         return out[0] if self.d_out == 1 else out.T.copy()
 
+    def set_posterior(self, mu_v, Uv):
+        """Install an external q(v) (mean and Uv = chol(Sigma_v + mu mu').U) for the per-point outputs (`w_stats`)."""
+        mu = as_f64(np.reshape(mu_v, (self.Q,)))
+        U = as_f64(np.asarray(Uv, dtype=np.float64).reshape(self.Q, self.Q).T)     # row-major Uv^T == column-major Uv
+        check(self._lib.sgp_set_posterior(self._h, ptr(mu), ptr(U)), self._h, "sgp_set_posterior")
+
     def carry_posterior(self, stream: int = 0):
         """prior <- posterior of the last sweep, on the device (the minibatch carry, regression_kin40k.ipynb:205-212)."""
         check(self._lib.sgp_carry_posterior(self._h, C.c_void_p(stream)), self._h, "sgp_carry_posterior")

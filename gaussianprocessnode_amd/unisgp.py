@@ -4,10 +4,10 @@ error behaviour, batched on the device.
 The reference's rules run once per data point and the N-fold Gaussian product folds N rank-1 M x M messages
 (GPnode/UniSGPnode.jl:62-73,144-173).  Here the per-point `:v` rule returns an O(1) token and the product runs
 ONE device sweep when the N-th token is folded -- the same `counter == N` hook the reference uses to refresh
-`meta.Uv` (:64-71).  The PointMass-input rules (`q_in::PointMass`) are the hot path; of the uncertain-input variants the
-`:v` (:125-140) and `:out` (:85-93) rules run on the device as cubature-weighted data.  The per-node clamped `:w` /
-average-energy variants (:177-192,290-313), `:in` and the `:theta` closures (:242-287) raise NotImplementedError
-(next).
+`meta.Uv` (:64-71).  The PointMass-input rules (`q_in::PointMass`) are the hot path; the uncertain-input variants run on
+the device as cubature-weighted data: `:v` (:125-140) and `:out` (:85-93) inside the sweep, the per-node clamped `:w` /
+average-energy variants (:177-192,290-313,390-409), the `:in` closure (:107-122) and the `:theta` closures (:242-287)
+as stand-alone per-point evaluations at whatever q_v / meta.Uv the caller passes.
 
 Nothing here computes the node's mathematics on the CPU: every number comes from `meta.engine`
 (`SGPDevice`, the C ABI).  Without the HIP library and a gfx950 GPU the first sweep raises.
@@ -176,31 +176,88 @@ def prod(left, right: BufferUniSGP):
     return MvNormalMeanCovariance(mu_v, Sigma_v)
 
 
-def _point_stats(q_in, q_v, meta: UniSGPMeta):
-    """(I1_n, I2_n) of one point of the last swept batch, from the device's per-point pass."""
-    if not _is_pointmass(q_in):
-        raise NotImplementedError("uncertain inputs are not on the device path yet")
-    if "index" not in meta._batch:
-        raise RuntimeError("UniSGP(:w)/average energy before q(v) was computed for this batch")
-    if not np.allclose(np.asarray(q_v.mean()), meta._batch["mu_v"], rtol=1e-12, atol=0):
-        raise NotImplementedError("q_v differs from the marginal of the last sweep: the device evaluates the :w rule "
-                                  "at its resident posterior")
+def _aux_engine(meta: UniSGPMeta, n: int):
+    """A second device object for stand-alone rule evaluations (it replaces data and posterior, so it must not be the
+    engine that holds the last swept batch)."""
+    M, D = meta.Xu.shape
+    eng = meta._batch.get("aux_engine")
+    if eng is None or eng.n_max < n:
+        from .device import SGPDevice
+        if eng is not None:
+            eng.close()
+        eng = SGPDevice(max(n, 64), M, D, 1, device=meta.device, keep_kuf=True)
+        eng.set_inducing(meta.Xu)
+        meta._batch["aux_engine"] = eng
+    return eng
+
+
+def _stats_at(meta: UniSGPMeta, theta, X, y, vy, mu_v, Uv):
+    """Per-point (I1_n, I2_n) of GPnode/UniSGPnode.jl:196-238 for arbitrary points, at kernel(theta) and at the q(v) given by
+    (mu_v, Uv = chol(Sigma_v + mu mu').U): K_uu chain and K_uf on the device, then the per-point quadratic forms."""
+    X = np.asarray(X, dtype=np.float64).reshape(len(y), -1)
+    eng = _aux_engine(meta, len(y))
+    sigma2, ell = meta.kernel(np.atleast_1d(np.asarray(theta, dtype=np.float64)))
+    eng.set_data(X, y, vy)
+    eng.set_kernel(sigma2, ell, meta.jitter)
+    eng.sweep_local()
+    eng.set_posterior(mu_v, Uv)
+    return eng.w_stats()
+
+
+def _uv_of(q_v, meta: UniSGPMeta):
+    """chol(Sigma_v + mu mu').U of an explicit q_v, factored on the device."""
+    from .device import potrf
+    mu, Sig = q_v.mean_cov()
+    mu = np.asarray(mu, dtype=np.float64)
+    return potrf(np.asarray(Sig, dtype=np.float64) + np.outer(mu, mu), meta.device).T
+
+
+def _node_I(q_out, q_in, mu_v, Uv, theta, meta: UniSGPMeta, jitter_psi2: float, clamp: bool):
+    """(I1, I2) of ONE node whose input is uncertain: Psi-statistics by meta.method's cubature, Psi2 + jitter_psi2 I, clamped
+    like the reference (GPnode/UniSGPnode.jl:186-190)."""
+    if meta.method is None:
+        raise ValueError("an uncertain input needs meta.method (a cubature rule)")
+    pts, wts = meta.method.points_weights(q_in.mean(), q_in.var())
+    wts = np.asarray(wts, dtype=np.float64)
+    mu_y = float(q_out.mean())
+    v_y = 0.0 if _is_pointmass(q_out) else float(q_out.var())
+    I1q, I2q = _stats_at(meta, theta, pts, np.full(len(wts), mu_y), None, mu_v, Uv)
+    I1 = float(wts @ I1q)
+    I2 = float(wts @ I2q) + mu_y * mu_y * (1.0 - float(wts.sum())) + v_y
+    if jitter_psi2:
+        from .device import potri
+        KuuL = np.asarray(meta.KuuL, dtype=np.float64)
+        I1 -= jitter_psi2 * float(np.trace(potri(KuuL @ KuuL.T, meta.device)))     # tr(Kuu^-1 (jitter I))
+        I2 += jitter_psi2 * float(np.sum(np.asarray(Uv) ** 2))                      # tr(Uv'Uv (jitter I))
+    if clamp:
+        I1, I2 = min(max(I1, 1e-12), 1e12), min(max(I2, 1e-12), 1e12)
+    return I1, I2
+
+
+def _point_stats(q_out, q_in, q_v, q_theta, meta: UniSGPMeta):
+    """(I1_n, I2_n) of one PointMass-input node: from the per-point pass over the last swept batch when the point and q_v
+    belong to it, else evaluated stand-alone at (q_v, meta.Uv) like the reference's rule would."""
     x = np.atleast_1d(np.asarray(q_in.mean(), dtype=np.float64))
-    try:
-        i = meta._batch["index"][x.tobytes()]
-    except KeyError as e:
-        raise KeyError("this input point was not part of the last swept batch") from e
-    if meta._batch["I"] is None:
-        meta._batch["I"] = meta.engine.w_stats()
-    I1, I2 = meta._batch["I"]
-    return float(I1[i]), float(I2[i])
+    mu_v = np.asarray(q_v.mean(), dtype=np.float64)
+    b = meta._batch
+    if "index" in b and x.tobytes() in b["index"] and np.allclose(mu_v, b["mu_v"], rtol=1e-12, atol=0):
+        if b["I"] is None:
+            b["I"] = meta.engine.w_stats()
+        i = b["index"][x.tobytes()]
+        return float(b["I"][0][i]), float(b["I"][1][i])
+    v_y = None if _is_pointmass(q_out) else np.array([float(q_out.var())])
+    I1, I2 = _stats_at(meta, q_theta.mean(), x[None, :], np.array([float(q_out.mean())]), v_y, mu_v, meta.Uv)
+    return float(I1[0]), float(I2[0])
 
 
 # ------------------------------------------------------------------------------------------------
-# :w  (GPnode/UniSGPnode.jl:196-216 regression, :219-238 classification)
+# :w  (GPnode/UniSGPnode.jl:196-216 regression, :219-238 classification, :177-192 uncertain input)
 # ------------------------------------------------------------------------------------------------
 def rule_w(q_out, q_in, q_v, q_theta, meta: UniSGPMeta) -> GammaShapeRate:
-    I1, I2 = _point_stats(q_in, q_v, meta)
+    if _is_pointmass(q_in):
+        I1, I2 = _point_stats(q_out, q_in, q_v, q_theta, meta)
+    else:
+        I1, I2 = _node_I(q_out, q_in, np.asarray(q_v.mean(), dtype=np.float64), meta.Uv, q_theta.mean(), meta, 1e-8, True)
     return GammaShapeRate(1.5, 0.5 * (I1 + I2))
 
 
@@ -239,7 +296,16 @@ def predict(Xstar, q_v, q_theta, meta: UniSGPMeta) -> np.ndarray:
 # @average_energy  (GPnode/UniSGPnode.jl:337-359 Gamma w; :363-387 classification; :411-436 PointMass w)
 # ------------------------------------------------------------------------------------------------
 def average_energy(q_out, q_in, q_v, q_w, q_theta, meta: UniSGPMeta) -> float:
-    I1, I2 = _point_stats(q_in, q_v, meta)
+    if _is_pointmass(q_in):
+        I1, I2 = _point_stats(q_out, q_in, q_v, q_theta, meta)
+    elif isinstance(q_w, GammaShapeRate):
+        # :290-313 -- meta.KuuL / meta.Uv, Psi2 + 1e-8 I, clamped
+        I1, I2 = _node_I(q_out, q_in, np.asarray(q_v.mean(), dtype=np.float64), meta.Uv, q_theta.mean(), meta, 1e-8, True)
+    else:
+        # :390-409 (q_w::PointMass) -- Sigma_v + mu mu' from q_v itself.  The reference also adds 1e-8 to EVERY ENTRY of
+        # Kuu, Psi1 and Psi2 there (`.+ 1e-8`); that quirk moves the result by < 1e-6 (GPtest.jl:337-348 tests it against
+        # the clean formula at 1e-6) and is not reproduced.
+        I1, I2 = _node_I(q_out, q_in, np.asarray(q_v.mean(), dtype=np.float64), _uv_of(q_v, meta), q_theta.mean(), meta, 0.0, True)
     w_bar = _mean_w(q_w)
     return 0.5 * (I1 * w_bar - _elog_w(q_w) + LOG2PI + I2 * w_bar)
 
@@ -250,13 +316,68 @@ def average_energy_summed(meta: UniSGPMeta) -> float:
 
 
 # ------------------------------------------------------------------------------------------------
-# cold rules: present in the interface, not on the device path this round
+# :in and :theta return log-density closures (ContinuousUnivariateLogPdf / ContinuousMultivariateLogPdf in ReactiveMP);
+# here a callable whose every evaluation is one batched device pass
 # ------------------------------------------------------------------------------------------------
-def rule_in(q_out, q_v, q_w, q_theta, meta: UniSGPMeta):
-    raise NotImplementedError("UniSGP(:in) (GPnode/UniSGPnode.jl:107-122) returns a log-pdf closure evaluated by "
-                              "quadrature in ReactiveMP; not on the device path yet (SURVEY.md §8 a15)")
+class LogPdfClosure:
+    def __init__(self, fn, multivariate: bool = False):
+        self.fn = fn
+        self.multivariate = multivariate
+
+    def logpdf(self, x):
+        return self.fn(x)
+
+    __call__ = logpdf
 
 
-def rule_theta(q_out, q_in, q_v, q_w, meta: UniSGPMeta):
-    raise NotImplementedError("UniSGP(:theta) (GPnode/UniSGPnode.jl:242-287) returns a log-pdf closure; the "
-                              "hyper-parameter objective is SURVEY.md §8 f1 (sgp_theta_objective)")
+def rule_in(q_out, q_v, q_w, q_theta, meta: UniSGPMeta) -> LogPdfClosure:
+    """GPnode/UniSGPnode.jl:107-122: x -> -w/2 A(x) + w mu_y B(x).mu_v - w/2 |Uv B(x)|^2 with A(x) = k(x,x) - |KuuL^-1 B(x)|^2
+    = -w/2 (I1(x) + I2(x) - mu_y^2).  Accepts a scalar or an array of inputs (one device pass for all of them)."""
+    w_bar, mu_y = _mean_w(q_w), float(q_out.mean())
+    mu_v = np.asarray(q_v.mean(), dtype=np.float64)
+    theta, Uv = q_theta.mean(), meta.Uv
+
+    def log_backwardmess(x):
+        xs = np.atleast_1d(np.asarray(x, dtype=np.float64))
+        X = xs.reshape(-1, meta.Xu.shape[1])
+        I1, I2 = _stats_at(meta, theta, X, np.full(len(X), mu_y), None, mu_v, Uv)
+        val = -0.5 * w_bar * (I1 + I2 - mu_y * mu_y)
+        return float(val[0]) if np.ndim(x) == 0 or (meta.Xu.shape[1] > 1 and np.ndim(x) == 1) else val
+    return LogPdfClosure(log_backwardmess)
+
+
+def rule_theta(q_out, q_in, q_v, q_w, meta: UniSGPMeta) -> LogPdfClosure:
+    """GPnode/UniSGPnode.jl:242-287: theta -> w mu_y Psi1(theta).mu_v - w/2 (Psi0(theta) + tr(Psi2(theta) (Rv - Kuu^-1(theta))))
+    = -w/2 (sum_q omega_q (I1_q + I2_q) - mu_y^2 sum_q omega_q), Rv from q_v itself.  The batch-summed version of this is
+    the hyper-parameter objective `SGPDevice.theta_objective` (helper_functions/derivative_helper.jl:23-39)."""
+    if not _is_pointmass(q_in) and meta.method is None:
+        raise ValueError("UniSGP(:theta) with an uncertain input needs meta.method (a cubature rule)")
+    w_bar, mu_y = _mean_w(q_w), float(q_out.mean())
+    mu_v = np.asarray(q_v.mean(), dtype=np.float64)
+    Uv = _uv_of(q_v, meta)
+    if _is_pointmass(q_in):
+        pts, wts = np.atleast_1d(np.asarray(q_in.mean(), dtype=np.float64))[None, :], np.ones(1)
+    else:
+        pts, wts = meta.method.points_weights(q_in.mean(), q_in.var())
+    wts = np.asarray(wts, dtype=np.float64)
+
+    def log_backwardmess(theta):
+        I1, I2 = _stats_at(meta, theta, pts, np.full(len(wts), mu_y), None, mu_v, Uv)
+        return float(-0.5 * w_bar * (wts @ (I1 + I2) - mu_y * mu_y * wts.sum()))
+    return LogPdfClosure(log_backwardmess, multivariate=True)
+
+
+def prod_logpdf(left, right):
+    """ReactiveMP.prod(GenericProd, Gaussian, ContinuousUnivariateLogPdf) and its mirror image (GPnode/UniSGPnode.jl:39-54):
+    moments of N(x) exp(logpdf(x)) by ghcubature(21); `v + 1e-6` only when the Gaussian is on the left; NaN moments return
+    the Gaussian unchanged."""
+    from .cubature import ghcubature
+    gauss, closure, pad = (left, right, 1e-6) if isinstance(right, LogPdfClosure) else (right, left, 0.0)
+    pts, wts = ghcubature(21).points_weights(gauss.mean(), gauss.var())
+    g = np.exp(np.asarray(closure.logpdf(pts[:, 0]), dtype=np.float64))
+    Z = float(wts @ g)
+    m = float(wts @ (pts[:, 0] * g)) / Z if Z != 0.0 else float("nan")
+    v = float(wts @ ((pts[:, 0] - m) ** 2 * g)) / Z if Z != 0.0 else float("nan")
+    if math.isnan(m) or math.isnan(v):
+        return gauss
+    return NormalMeanVariance(m, v + pad)

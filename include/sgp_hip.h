@@ -139,6 +139,12 @@ int sgp_get_wishart_invscale(sgp_handle* h, double* S);
  * (which re-evaluates the statistics at the new theta). */
 int sgp_carry_posterior(sgp_handle* h, void* stream);
 
+/* sgp_set_posterior: install an externally given q(v) -- mu_v (d_out*M) and Uv = chol(Sigma_v + mu mu').U (Q x Q
+ * column-major, upper) -- for the per-point outputs.  The reference's cold rules are called with an arbitrary q_v /
+ * meta.Uv (GPnode/UniSGPnode.jl:107-122,177-192,242-287; GPtest.jl:173-181,221-229,257-292): after sgp_set_data +
+ * sgp_sweep_local (K_uu chain and K_uf at the current theta) + this call, sgp_w_stats evaluates I1_n / I2_n there. */
+int sgp_set_posterior(sgp_handle* h, const double* mu_v, const double* Uv);
+
 /* sgp_w_stats: per-point :w rule quantities (GPnode/UniSGPnode.jl:196-238):
  * I1_n = k_nn - |L^-1 k_n|^2 (the Q_ff diagonal term) and I2_n.  Needs SGP_FLAG_KEEP_KUF and a finished sweep.
  * Either output may be NULL. */

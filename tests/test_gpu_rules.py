@@ -14,6 +14,7 @@ from gaussianprocessnode_amd import unisgp as U
 from gaussianprocessnode_amd.distributions import GammaShapeRate, MvNormalMeanCovariance, NormalMeanVariance, PointMass
 from oracle import sgp_oracle as O
 
+LOG2PI = math.log(2.0 * math.pi)
 THETA = np.array([1.0, 1.0])                 # GPtest.jl:16
 XU = np.arange(1.0, 11.0)                    # GPtest.jl:19
 KERNEL = Mt.SEARDKernel()                    # GPtest.jl:21
@@ -278,3 +279,98 @@ def test_banana_classification_driver():
     assert res["error_rate"] < 0.12, res
     assert math.isclose(res["qw"][0], 0.01 + 30 * 20 * 100.0, rel_tol=1e-12)
     assert 0.2 < res["qw"][0] / res["qw"][1] < 5.0                       # mean(q_w) stays O(1)
+
+
+# ------------------------------------------------------------------------------------------------
+# the cold rules called stand-alone with an arbitrary q_v / meta.Uv, exactly as GPtest.jl calls them
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def standalone():
+    """GPtest.jl:114-151: q_out = N(1, 2), q_w = Gamma(1, 1), q_v = N(sin(rand), I), q_x = N(0, 1), theta = [1, 1],
+    meta with KuuL = chol(Kuu).L and Uv = chol(R_v).U."""
+    from gaussianprocessnode_amd.cubature import ghcubature
+    rng = np.random.default_rng(21)
+    q_out, q_w, q_x = NormalMeanVariance(1.0, 2.0), GammaShapeRate(1.0, 1.0), NormalMeanVariance(0.0, 1.0)
+    q_v = MvNormalMeanCovariance(np.sin(rng.random(10)), np.eye(10))
+    R_v = np.outer(q_v.m, q_v.m) + q_v.S
+    Kuu = kmat(XU, XU)
+    meta = Mt.make_uni_meta(ghcubature(21), XU, KERNEL, 1, KuuL=np.linalg.cholesky(Kuu), Uv=np.linalg.cholesky(R_v).T)
+    pts, wts = O.ghcubature_1d(21, 0.0, 1.0)
+    P0, P1, P2 = O.psi_statistics(XU[:, None], pts[:, None], wts, 1.0, np.array([1.0]))
+    return dict(q_out=q_out, q_w=q_w, q_x=q_x, q_v=q_v, R_v=R_v, Kinv=np.linalg.inv(Kuu), meta=meta, q_theta=PointMass(THETA),
+                P0=P0, P1=P1, P2=P2)
+
+
+def test_rule_in_is_the_log_backward_message(standalone):
+    """GPtest.jl:173-181."""
+    s = standalone
+    nu_x = U.rule_in(s["q_out"], s["q_v"], s["q_w"], s["q_theta"], s["meta"])
+    w, mu_y, mu_v = s["q_w"].mean(), s["q_out"].mean(), s["q_v"].m
+
+    def gt(x):
+        B = kmat([x], XU)                                         # 1 x Nu
+        A = 1.0 - (B @ s["Kinv"] @ B.T).item()
+        return -0.5 * w * (A + (B @ s["R_v"] @ B.T).item() - 2.0 * mu_y * (B @ mu_v).item())
+    for x in (1.0, math.sqrt(2.0), 4.2):
+        assert math.isclose(nu_x.logpdf(x), gt(x), rel_tol=1e-9, abs_tol=1e-11)
+    xs = np.array([0.3, 2.5, 7.7])
+    np.testing.assert_allclose(nu_x.logpdf(xs), [gt(x) for x in xs], rtol=1e-9, atol=1e-11)    # batched: one device pass
+    # the product with a Gaussian (GPnode/UniSGPnode.jl:39-46): moments by ghcubature(21), variance + 1e-6
+    q = U.prod_logpdf(NormalMeanVariance(3.0, 0.5), nu_x)
+    pts, wts = O.ghcubature_1d(21, 3.0, 0.5)
+    g = np.exp([gt(x) for x in pts])
+    m = float(wts @ (pts * g) / (wts @ g))
+    v = float(wts @ ((pts - m) ** 2 * g) / (wts @ g))
+    assert math.isclose(q.mean(), m, rel_tol=1e-9) and math.isclose(q.var(), v + 1e-6, rel_tol=1e-9)
+
+
+def test_rule_w_and_energy_with_uncertain_input(standalone):
+    """GPtest.jl:221-229 (:w, q_out, q_in::Normal), :325-335 (energy, Gamma w), :337-348 (energy, PointMass w)."""
+    s = standalone
+    mu_y, v_y, mu_v = s["q_out"].mean(), s["q_out"].var(), s["q_v"].m
+    I1 = s["P0"] - np.trace(s["Kinv"] @ s["P2"])
+    I2 = mu_y ** 2 + v_y - 2.0 * mu_y * float(s["P1"] @ mu_v) + np.trace(s["R_v"] @ s["P2"])
+    nu_w = U.rule_w(s["q_out"], s["q_x"], s["q_v"], s["q_theta"], s["meta"])
+    assert nu_w.shape() == 1.5 and math.isclose(nu_w.rate(), 0.5 * (I1 + I2), abs_tol=1e-5)     # the rule adds 1e-8 I to Psi2
+    exact = 0.5 * (I1 - 1e-8 * np.trace(s["Kinv"]) + I2 + 1e-8 * np.trace(s["R_v"]))
+    assert math.isclose(nu_w.rate(), exact, rel_tol=1e-9)
+    U_node = U.average_energy(s["q_out"], s["q_x"], s["q_v"], s["q_w"], s["q_theta"], s["meta"])
+    U_gt = 0.5 * LOG2PI - 0.5 * s["q_w"].mean_log() + 0.5 * s["q_w"].mean() * (I1 + I2)
+    assert math.isclose(U_node, U_gt, abs_tol=1e-5)
+    w = 5.0
+    U_node = U.average_energy(s["q_out"], s["q_x"], s["q_v"], PointMass(w), s["q_theta"], s["meta"])
+    assert math.isclose(U_node, 0.5 * LOG2PI - 0.5 * math.log(w) + 0.5 * w * (I1 + I2), abs_tol=1e-6)
+
+
+def test_rules_for_theta_are_log_density_closures(standalone):
+    """GPtest.jl:257-292: the three :theta rules at theta = [1, 2] and [0.5, 1.4]."""
+    s = standalone
+    w, mu_v, R_v = s["q_w"].mean(), s["q_v"].m, s["R_v"]
+
+    def gt(theta, pts, wts, mu_y):
+        s2, ell = KERNEL(np.asarray(theta, dtype=float))
+        P0, P1, P2 = O.psi_statistics(XU[:, None], np.reshape(pts, (-1, 1)), wts, s2, ell)
+        Kinv = np.linalg.inv(O.kernelmatrix(s2, ell, XU[:, None]))
+        return -0.5 * w * (P0 + np.trace(P2 @ (R_v - Kinv))) + w * mu_y * float(P1 @ mu_v)
+    gh = O.ghcubature_1d(21, 0.0, 1.0)
+    cases = [(s["q_out"], s["q_x"], gh[0], gh[1], 1.0, 1e-7),
+             (s["q_out"], PointMass(1.0), np.array([1.0]), np.ones(1), 1.0, 1e-9),
+             (PointMass(2.0), PointMass(1.0), np.array([1.0]), np.ones(1), 2.0, 1e-9)]
+    for q_out, q_in, pts, wts, mu_y, atol in cases:
+        nu = U.rule_theta(q_out, q_in, s["q_v"], s["q_w"], s["meta"])
+        assert nu.multivariate
+        for theta in ([1.0, 2.0], [0.5, 1.4]):
+            assert math.isclose(nu.logpdf(theta), gt(theta, pts, wts, mu_y), abs_tol=atol), (theta, mu_y)
+
+
+def test_pointmass_rules_stand_alone(standalone):
+    """GPtest.jl:231-255: the PointMass-input :w rules called on their own, with q_v and meta.Uv as given (no sweep before)."""
+    s = standalone
+    mu_v = s["q_v"].m
+    B = kmat([1.0], XU)
+    I1 = 1.0 - (B @ s["Kinv"] @ B.T).item()
+    for q_out, extra in ((PointMass(2.0), 0.0), (s["q_out"], s["q_out"].var())):
+        mu_y = q_out.mean()
+        I2 = mu_y ** 2 + extra - 2.0 * mu_y * (B @ mu_v).item() + (B @ s["R_v"] @ B.T).item()
+        nu = U.rule_w(q_out, PointMass(1.0), s["q_v"], s["q_theta"], s["meta"])
+        assert nu.shape() == 1.5 and math.isclose(nu.rate(), 0.5 * (I1 + I2), rel_tol=1e-9)

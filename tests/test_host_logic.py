@@ -112,8 +112,11 @@ def test_wrong_N_and_mixed_parameters_are_errors():
         U.rule_v(PointMass(0.1), PointMass(0.6), PointMass(3.0), th, meta)              # different q_w in one graph
     with pytest.raises((NotImplementedError, ValueError)):
         U.rule_v(PointMass(0.1), NormalMeanVariance(0.0, 1.0), PointMass(2.0), th, meta)   # mixed / no cubature rule
-    with pytest.raises(NotImplementedError):
-        U.rule_theta(None, None, None, None, meta)
+    # the :theta rule needs a cubature rule for an uncertain input (no CPU evaluation anywhere: the closure itself is
+    # device-backed and covered by the GPU tests)
+    with pytest.raises(ValueError):
+        U.rule_theta(PointMass(0.1), NormalMeanVariance(0.0, 1.0), MvNormalMeanCovariance(np.zeros(3), np.eye(3)),
+                     PointMass(2.0), meta)
 
 
 def test_pack_unpack_and_shards():
