@@ -2,10 +2,10 @@
 //
 // The handle owns every device buffer of one rank's shard; a sweep is two launch sequences
 // (sgp_sweep_local, sgp_sweep_finish) with the packed statistics buffer as the only hand-off, so that a
-// multi-GPU caller can sum-all-reduce that buffer in between (RCCL through torch.distributed).  Each
-// sequence is captured once into a hipGraph and replayed (the tail is a chain of ~70 small dependent
-// kernels: eager launches would be host-bound); per-sweep scalars travel through a pinned Params block
-// that the graph's first node copies to the device.
+// multi-GPU caller can sum-all-reduce that buffer in between (RCCL through torch.distributed).  Launches
+// are eager by default (~45 kernels per sweep, enqueued well ahead of the GPU); SGP_FLAG_GRAPH captures each
+// sequence once into a hipGraph and replays it -- bitwise the same results, measured ~20 us per sweep slower.
+// Per-sweep scalars travel through a pinned Params block that each sequence's first kernel mirrors on the device.
 #include "../../include/sgp_hip.h"
 #include "sgp_kernels.hip.h"
 
@@ -501,11 +501,12 @@ extern "C" int sgp_bind_stats(sgp_handle* h, void* stats_dev) {
 // ------------------------------------------------------------------------------------------------
 // launch sequences
 // ------------------------------------------------------------------------------------------------
-// The sweep is four launch sequences, each captured once into a hipGraph and replayed:
-//   K  (side stream) : K_uu chain -- theta and Xu only: K_uu, its Cholesky factor, inverse factor and inverse
+// The sweep is four launch sequences:
+//   K  (side stream) : K_uu chain -- theta and Xu only: K_uu, its Cholesky factor, inverse factor and inverse;
+//                      starts with the sweep, joined before F2                                  [sgp_sweep_local]
 //   L  (main stream) : data-sized work -- K_uf, Psi2 / B partials, packed statistics          [sgp_sweep_local]
-//   F1 (main stream) : Lambda chain -- Lambda, Cholesky, inverse, mu, R, Uv                   [sgp_sweep_finish]
-//   F2 (main stream) : traces and scalars, after the join with the side stream
+//   F1 (main stream) : Lambda chain -- Lambda formed in step 0, Cholesky + inverse factor, mu, p, scan, Uv pass 1
+//   F2 (main stream) : Sigma, R, both traces, Uv pass 2, scalars                               [sgp_sweep_finish]
 // The two chains are latency-bound pivot sequences that use a handful of CUs each; they overlap only when they sit on
 // different streams (parallel branches inside ONE captured graph were observed to execute back to back).
 static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
