@@ -68,7 +68,7 @@ struct sgp_handle {
     double* dXusK = nullptr;
     hipStream_t own = nullptr, side = nullptr;
     hipEvent_t evSide = nullptr, evDone = nullptr;
-    int nchunks = 1, chunk = 0, nblk = 0, ntiles = 0;
+    int nchunks = 1, chunk = 0, nblk = 0, ntiles = 0, num_cus = 256;
     int64_t stats_count = 0;
     size_t slab_capacity = 0;
     Graph gLocal, gFinish, gFinish2, gKuu;
@@ -113,11 +113,28 @@ static int quiesce(sgp_handle* h) {
     return 0;
 }
 
-// streaming-SYRK grid: tiles x point-chunks.  ~4.5 blocks per CU (3 resident, the rest dispatched as CUs free up) evens
-// out the 2-vs-3 blocks-per-CU imbalance a 2-blocks-per-CU grid leaves; the price is more partial slabs to sum.
+// streaming-SYRK grid: tiles x point-chunks, sized to ONE resident round: the kernel's 40 KB of LDS let 4 workgroups
+// share a CU, i.e. 1024 slots on 256 CUs.  A grid just above that (the first version: 1152) leaves a straggler round in
+// which 128 workgroups run one to a CU at a fraction of the matrix-core rate -- PMC: the CUs were busy 71 % of the launch;
+// the largest chunk count with tiles x chunks <= slots (1008 at M = 512) keeps every CU at 4 workgroups from start to end.
+// `align`: chunk counts are rounded so that tiles x chunks is a multiple of the 8 XCDs (see k_syrk_stream's block map).
+// In a sweep the K_uu chain runs beside this kernel and its Cholesky steps (<= 36 workgroups of 82 KB LDS) take most of
+// the LDS of up to 36 CUs: SYRK_RESERVED_CUS are left out of the slot count so that the round still fits.
 #ifndef SYRK_BLOCKS_PER_CU
 #define SYRK_BLOCKS_PER_CU 4
 #endif
+#ifndef SYRK_RESERVED_CUS
+#define SYRK_RESERVED_CUS 40
+#endif
+static void syrk_chunking(int ntiles, int num_cus, int* want, int* align) {
+    int a = 8;
+    for (int g = 2; g <= 8; g *= 2)
+        if (ntiles % g == 0) a = 8 / g;                  // smallest a with (ntiles * a) % 8 == 0
+    int w = std::max(1, SYRK_BLOCKS_PER_CU * std::max(8, num_cus - SYRK_RESERVED_CUS) / ntiles);
+    if (w > a) w = w / a * a;
+    *want = w;
+    *align = a;
+}
 
 // ------------------------------------------------------------------------------------------------
 // dense building blocks (launch sequences)
@@ -189,8 +206,15 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     h->ntiles = h->T * (h->T + 1) / 2;
     const size_t Mp = h->Mp, Qp = h->Qp, nmax = (size_t)h->n_max;
     h->stats_count = (int64_t)(Mp * Mp + Mp * h->dout + SGP_S_COUNT + (size_t)h->dout * h->dout);
-    // worst-case slab count: enough chunks to put ~2 blocks on each of the 256 CUs
-    int max_chunks = (std::max(1, (SYRK_BLOCKS_PER_CU * 256 + h->ntiles - 1) / h->ntiles) + 7) / 8 * 8 + 8;
+    // worst-case slab count
+    {
+        hipDeviceProp_t prop;
+        h->num_cus = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+                         ? prop.multiProcessorCount : 256;
+    }
+    int want_chunks = 1, align_chunks = 1;
+    syrk_chunking(h->ntiles, h->num_cus, &want_chunks, &align_chunks);
+    int max_chunks = want_chunks + align_chunks;
     h->slab_capacity = (size_t)max_chunks * h->ntiles * TB * TB;
     const size_t nblk_max = (nmax + TB - 1) / TB;
 
@@ -352,14 +376,14 @@ extern "C" int sgp_set_data(sgp_handle* h, const double* X, const double* y_mean
     h->has_yv = y_var != nullptr;
     h->have_data = true;
     h->nblk = (int)((n + TB - 1) / TB);
-    // split the point axis so that tiles x chunks ~ 2 blocks per CU, chunk a multiple of the stage size
-    int want = std::max(1, (SYRK_BLOCKS_PER_CU * 256 + h->ntiles - 1) / h->ntiles);
-    want = (want + 7) / 8 * 8;                                   // a multiple of the 8 XCDs (see k_syrk_stream)
+    // split the point axis into one resident round of workgroups (see syrk_chunking), chunk a multiple of the stage size
+    int want = 1, align = 1;
+    syrk_chunking(h->ntiles, h->num_cus, &want, &align);
     int64_t per = (n + want - 1) / want;
     per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);
     h->chunk = (int)per;
     h->nchunks = (int)std::max<int64_t>(1, (n + per - 1) / per);
-    if (h->nchunks > 8) h->nchunks = (h->nchunks + 7) / 8 * 8;    // trailing chunks may be empty (zero slabs)
+    if (h->nchunks > align) h->nchunks = (h->nchunks + align - 1) / align * align;   // trailing chunks may be empty (zero slabs)
     if ((size_t)h->nchunks * h->ntiles * TB * TB > h->slab_capacity)
         return fail(h, SGP_ERR_ARG, "sgp_set_data: internal slab capacity exceeded");
     h->swept = h->swept_local = false;

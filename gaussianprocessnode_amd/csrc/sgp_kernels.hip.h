@@ -343,13 +343,15 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
     stamp_enter(stamps);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     // XCD-aware block -> (tile, chunk) map: workgroups are dealt round-robin over the 8 XCDs, so ids congruent mod 8
-    // share an L2.  All tiles of one point-chunk read the same K_uf columns: give every chunk to ONE XCD so that its
-    // columns are fetched into one L2 once (nchunks is a multiple of 8 whenever there is enough work; speed only).
+    // share an L2.  All tiles of one point-chunk read the same K_uf columns: the work items, ordered chunk-major, are cut
+    // into 8 contiguous runs, one per XCD, so that a chunk's columns are fetched into (at most two) L2s once.  Needs the
+    // item count to be a multiple of 8 (the host picks nchunks accordingly whenever there is enough work; speed only).
     int tile_id, chunk_id;
-    if ((nchunks & 7) == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        chunk_id = xcd + 8 * (j / ntiles);
-        tile_id = j % ntiles;
+    const int nitems = ntiles * nchunks;
+    if ((nitems & 7) == 0) {
+        const int item = (blockIdx.x & 7) * (nitems >> 3) + (blockIdx.x >> 3);
+        chunk_id = item / ntiles;
+        tile_id = item % ntiles;
     } else {
         chunk_id = blockIdx.x / ntiles;
         tile_id = blockIdx.x % ntiles;
