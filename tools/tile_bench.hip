@@ -1,5 +1,5 @@
 // Micro-benchmark of the sequential 64 x 64 tile routines (one block, as on the critical path of the
-// blocked Cholesky): potf2_tile, trsm_tile, k_trtri_diag and one k_potrf_step launch.
+// blocked Cholesky): potf2_tile and trsm_tile, with a validation of potf2_tile against a host Cholesky.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tile_bench tile_bench.hip
 #include "../gaussianprocessnode_amd/csrc/sgp_kernels.hip.h"
 #include <cstdio>
@@ -82,10 +82,5 @@ int main() {
         printf("diag:"); for (int i = 0; i < 24; ++i) printf(" %.4f/%.4f", L[i * n + i], R[i * n + i]); printf("\n");
         printf("row 8:"); for (int j = 0; j <= 8; ++j) printf(" %.4f/%.4f", L[j * n + 8], R[j * n + 8]); printf("\n");
     }
-    // k_trtri_diag and k_potrf_step single launches
-    float ms;
-    k_trtri_diag<<<1, 256>>>(dA, dA + n * n, n); CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0)); for (int i = 0; i < 50; ++i) k_trtri_diag<<<1, 256>>>(dA, dA + n * n, n); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-    CK(hipEventElapsedTime(&ms, e0, e1)); printf("k_trtri_diag launch      %8.2f us\n", 1e3 * ms / 50);
     return 0;
 }
