@@ -243,7 +243,7 @@ def test_kin40k_training_run_reproduces_the_reference_end_to_end():
     theta_init over 500 epochs x 20 minibatches (10 000 sweeps, posterior carries, analytic-gradient AdaMax steps) with
     the reference's own inducing inputs, then the 30 000-point prediction (:288-304).  Golden values: the saved
     `params_optimal_kin40k.jld`, `qv_kin40k.jld` and the printed SMSE 0.08343114079545057 (:315).  The whole trajectory
-    has to agree for these to match; ~11 s on one MI355X (the notebook says "approx 3h30min")."""
+    has to agree for these to match; ~7 s on one MI355X (the notebook says "approx 3h30min")."""
     import gaussianprocessnode_amd as G
     from gaussianprocessnode_amd.meta import SMSE, softplus
     from gaussianprocessnode_amd.train import AdaMax, perform_inference

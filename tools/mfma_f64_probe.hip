@@ -77,7 +77,7 @@ int main() {
     if (!okA && !okB) { for (int l = 0; l < 64; ++l) printf("lane %d: %g %g %g %g\n", l, D[l*4], D[l*4+1], D[l*4+2], D[l*4+3]); }
     // ---- rate
     int blocks = p.multiProcessorCount * 2;   // 2 blocks x 4 waves = 2 waves per SIMD
-    double* dout; CK(hipMalloc(&dout, (size_t)blocks * 4 * 256 * 8));
+    double* dout; CK(hipMalloc(&dout, (size_t)blocks * 8 * 256 * 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     int iters = 20000;
     auto timeit = [&](auto launch, const char* name, double flop_per_thread_block) {
@@ -86,12 +86,13 @@ int main() {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-28s %8.3f ms  %8.2f TFLOP/s\n", name, ms, flop_per_thread_block / (ms * 1e-3) / 1e12);
     };
-    for (int nb = 1; nb <= 4; nb *= 2) {
+    for (int nb = 1; nb <= 8; nb *= 2) {
         int g = p.multiProcessorCount * nb;
         double fl = (double)g * 4 /*waves*/ * iters * 2048.0;
         char nm[64];
         snprintf(nm, 64, "mfma f64 acc=1 blk/CU=%d", nb); timeit([&] { rate_mfma<1><<<g, 256>>>(dout, iters); }, nm, fl * 1);
         snprintf(nm, 64, "mfma f64 acc=4 blk/CU=%d", nb); timeit([&] { rate_mfma<4><<<g, 256>>>(dout, iters); }, nm, fl * 4);
+        snprintf(nm, 64, "mfma f64 acc=8 blk/CU=%d", nb); timeit([&] { rate_mfma<8><<<g, 256>>>(dout, iters); }, nm, fl * 8);
         snprintf(nm, 64, "valu fma f64 x16 blk/CU=%d", nb); timeit([&] { rate_valu<<<g, 256>>>(dout, iters); }, nm, (double)g * 256 * iters * 16 * 2.0);
     }
     return 0;
