@@ -208,7 +208,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             reps, t_cpu = 0, 0.0
-            while t_cpu < 10.0 and reps < 20:                    # bounded sample: ~10 s of CPU work
+            while t_cpu < 10.0 and reps < 100:                   # bounded sample: ~10 s of CPU work
                 t1 = time.perf_counter()
                 cpu_sweep()
                 t_cpu += time.perf_counter() - t1

@@ -602,8 +602,11 @@ __device__ __forceinline__ void load16(double (&t)[16], const double* p) {
 //   (2) wave cb factors its diagonal 16 x 16 block: 4 lanes per row, entries in registers, the pivot column exchanged
 //       through a 16-entry LDS vector -- all inside ONE wave, so the 16 pivots need no workgroup barrier;
 //   (3) after a barrier the waves below solve their 16 x 16 block against it (rows independent, in registers).
-// Two workgroup barriers per 16 pivots instead of one per pivot.
-__device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv, int* info, int col_base, int n_valid) {
+// Two workgroup barriers per 16 pivots instead of one per pivot.  `idle_work(cb)` is called by the three waves that wait
+// while wave cb runs its 16 pivots (k_potrf_step gives them a slice of the block's own rank-64 update).
+template <class IdleWork>
+__device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv, int* info, int col_base, int n_valid,
+                                           IdleWork&& idle_work) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = 16 * wave;
     const int li = lane & 15, lk = lane >> 4;
@@ -660,6 +663,8 @@ __device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv
             });
 #pragma unroll
             for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = lo[i];
+        } else {
+            idle_work(cb);                                // three waves have nothing to do during these 16 pivots
         }
         __syncthreads();
         if (wave > cb) {
@@ -687,6 +692,10 @@ __device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv
         }
         __syncthreads();
     });
+}
+
+__device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv, int* info, int col_base, int n_valid) {
+    potf2_tile(S, colw, rinv, info, col_base, n_valid, [](int) {});
 }
 
 // Solve X L^T = B in place: X (LDS tile, stride LT) holds B on entry and X on exit; S holds L (normal layout, as written
@@ -1024,8 +1033,10 @@ __device__ __forceinline__ void winv_row_tile(const double* __restrict__ L, doub
 __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
                                                     int n_valid, double* __restrict__ scratch, double* __restrict__ Winv,
                                                     LamForm form) {
-    // LDS: two MFMA operand panels (2 x 64 x PS) during the update, re-used afterwards as two 64 x 64 tiles
+    // LDS: two MFMA operand panels (2 x 64 x PS) and two 64 x 64 tiles.  The panels stay valid while the diagonal tile is
+    // factored: the waves that idle during the pivot runs use them for the block's own rank-64 update.
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
+    __shared__ __attribute__((aligned(16))) double tiles[2 * TB * LT];
     __shared__ double colw[16];
     __shared__ double rinv[TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
@@ -1044,8 +1055,8 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     const int i0 = (j + a) * TB, k0 = (j + b) * TB, j0 = j * TB;
     double* P0 = lds;
     double* P1 = lds + TB * PS;
-    double* S = lds;                                      // diagonal tile A_jj (panel column blocks only)
-    double* X = lds + TB * LT;                            // this block's own tile
+    double* S = tiles;                                    // diagonal tile A_jj (panel column blocks only)
+    double* X = tiles + TB * LT;                          // this block's own tile
     Acc4 accX, accD;
     acc_zero(accX);
     acc_zero(accD);
@@ -1087,28 +1098,13 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
         if (a != b) load_panel_n(P1, A, ld, k0, p0, TB, tid);   // L_{k, j-1}
         __syncthreads();
         if (panel && a != 0) {
-            // own tile (P0 P1^T) and, redundantly, the diagonal tile (P1 P1^T): eight independent accumulators per k-step
-            const int li = lane & 15, lk = lane >> 4;
-            const double* ap = P0 + lk * PS + wr * 32 + li;
-            const double* dp = P1 + lk * PS + wr * 32 + li;
-            const double* bp = P1 + lk * PS + wc * 32 + li;
-#pragma unroll 2
-            for (int k4 = 0; k4 < TB; k4 += 4) {
-                double a0 = ap[0], a1 = ap[16], d0 = dp[0], d1 = dp[16], b0 = bp[0], b1 = bp[16];
-                accX.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, accX.t[0][0], 0, 0, 0);
-                accD.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(d0, b0, accD.t[0][0], 0, 0, 0);
-                accX.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, accX.t[0][1], 0, 0, 0);
-                accD.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(d0, b1, accD.t[0][1], 0, 0, 0);
-                accX.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, accX.t[1][0], 0, 0, 0);
-                accD.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(d1, b0, accD.t[1][0], 0, 0, 0);
-                accX.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accX.t[1][1], 0, 0, 0);
-                accD.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(d1, b1, accD.t[1][1], 0, 0, 0);
-                ap += 4 * PS; dp += 4 * PS; bp += 4 * PS;
-            }
+            // redundantly, the diagonal tile's update (P1 P1^T); the block's own tile (P0 P1^T) waits for the idle slots
+            // of the factorisation below
+            tile_mma(accD, P1, P1, TB, lane, wr, wc);
         } else {
             tile_mma(accX, P0, (a != b) ? P1 : P0, TB, lane, wr, wc);
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (!panel) {
         // plain trailing tile: A_ik -= acc, through LDS for coalesced global access
@@ -1122,19 +1118,39 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     tile_r2s(S, rS);
     if (a != 0) tile_r2s(X, rX);
     __syncthreads();
-    if (a == 0) tile_sub_acc(S, accX, lane, wr, wc);
-    else {
-        tile_sub_acc(S, accD, lane, wr, wc);
-        tile_sub_acc(X, accX, lane, wr, wc);
-    }
+    tile_sub_acc(S, (a == 0) ? accX : accD, lane, wr, wc);
     __syncthreads();
-    potf2_tile(S, colw, rinv, info, j0, n_valid);
+    if (a != 0 && j > 0) {
+        // K-slice s of the own-tile update: k in [16 s, 16 s + 16), this wave's 32 x 32 quadrant (16 MFMAs)
+        auto own_slice = [&](int sl) {
+            const int li = lane & 15, lk = lane >> 4;
+            const double* ap = P0 + (16 * sl + lk) * PS + wr * 32 + li;
+            const double* bp = P1 + (16 * sl + lk) * PS + wc * 32 + li;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
+                accX.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, accX.t[0][0], 0, 0, 0);
+                accX.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, accX.t[0][1], 0, 0, 0);
+                accX.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, accX.t[1][0], 0, 0, 0);
+                accX.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accX.t[1][1], 0, 0, 0);
+                ap += 4 * PS; bp += 4 * PS;
+            }
+        };
+        // during the 16 pivots of column block cb the other three waves do slice cb; every wave then catches up on the one
+        // slice it missed (its own pivot run): 16 MFMAs on the critical path instead of 64
+        potf2_tile(S, colw, rinv, info, j0, n_valid, own_slice);
+        own_slice(wave);
+        tile_sub_acc(X, accX, lane, wr, wc);
+        __syncthreads();
+    } else {
+        potf2_tile(S, colw, rinv, info, j0, n_valid);
+    }
     if (a == 0) {
         if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);       // no other block reads A_jj in the last step
         else
             for (int e = tid; e < TB * TB; e += 256) scratch[e] = S[(e & 63) * LT + (e >> 6)];   // column-major tile
         if (Winv) {
-            trtri_tile(S, rinv, X, lds + 2 * TB * LT);
+            trtri_tile(S, rinv, X, lds);
             tile_s2g(X, Winv, ld, j0, j0);
         }
         return;
