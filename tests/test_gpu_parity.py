@@ -510,3 +510,35 @@ def test_full_size_configs_and_size_independent_properties(G):
     idx = rng.choice(N2, 4000, replace=False)
     K = O.kernelmatrix(s2, ell, Xu2, X2[idx])
     assert np.all(np.diag(P2) >= np.sum(K * K, axis=1) - 1e-9)
+
+
+def test_large_m_and_empty_data(G):
+    """M well past the north-star size (18 and 32 tile rows: more Cholesky steps, inverse-factor rows and slab tiles than any
+    other test) against the oracle, and the empty batch: with no data the posterior is the prior, every sum zero."""
+    for N, M, D in [(3000, 1100, 3), (2000, 2048, 4)]:
+        rng = np.random.default_rng(3)
+        X = rng.uniform(-1.7, 1.7, (N, D))
+        Xu = rng.uniform(-1.7, 1.7, (M, D))
+        y = np.sin(X.sum(axis=1))
+        s2, ell, w = 0.8, np.full(D, 0.6), 50.0
+        with G.SGPDevice(N, M, D) as dev:
+            dev.set_inducing(Xu); dev.set_data(X, y); dev.set_kernel(s2, ell, 1e-6)
+            dev.set_prior_isotropic(50.0); dev.set_noise([[w]])
+            dev.sweep()
+            mu, Sig, Uv = dev.posterior()
+            sc = dev.scalars()
+        ref = O.vmp_sweep(Xu, X, y, None, s2, ell, w, jitter=1e-6, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
+        assert relF(mu, ref.mu_v) < 1e-7 and relF(Sig, ref.Sigma_v) < 1e-7 and relF(Uv, ref.Uv) < 1e-7
+        assert math.isclose(sc.sum_I2, ref.sum_I2, rel_tol=1e-7)
+        assert abs(sc.sum_I1 - ref.sum_I1) < 1e-4 * N * s2          # cancels against s_kk: cond(Kuu) * eps * s_kk
+    M = 100
+    with G.SGPDevice(1, M, 2) as dev:
+        dev.set_inducing(np.random.default_rng(0).uniform(-1, 1, (M, 2)))
+        dev.set_data(np.zeros((0, 2)), np.zeros(0))
+        dev.set_kernel(1.0, np.ones(2), 1e-6); dev.set_prior_isotropic(50.0); dev.set_noise([[10.0]])
+        dev.sweep()
+        mu, Sig, Uv = dev.posterior()
+        sc = dev.scalars()
+    assert np.all(mu == 0.0) and np.abs(Sig - 50.0 * np.eye(M)).max() < 1e-12
+    assert np.abs(Uv - math.sqrt(50.0) * np.eye(M)).max() < 1e-12
+    assert sc.sum_I1 == 0.0 and sc.sum_I2 == 0.0 and sc.energy == 0.0
