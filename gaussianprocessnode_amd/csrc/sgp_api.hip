@@ -59,6 +59,8 @@ struct sgp_handle {
     double *dLambda0 = nullptr, *dXi0 = nullptr, *dOut = nullptr, *dWishart = nullptr, *dTrace = nullptr, *dTmp = nullptr;
     double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr, *dOut2 = nullptr, *dUvWork = nullptr;
     double *dGradM = nullptr, *dGradPart = nullptr, *dGrad = nullptr;   // theta-gradient scratch (allocated on first use)
+    double* dCall = nullptr;       // scratch of the per-call outputs (sgp_predict, sgp_w_stats): grows, never shrinks
+    size_t call_capacity = 0;
     int* dInfo = nullptr;
     int64_t* dStamps = nullptr;
     int64_t* dStampTotals = nullptr;
@@ -104,6 +106,21 @@ static hipError_t create_low_priority_stream(hipStream_t* s) {
 // Setters change state that an enqueued sweep reads WHEN IT EXECUTES (the pinned parameter block, the data buffers, the
 // prior): they first wait for any sweep still in flight.  The library's streams are non-blocking, so the implicit
 // synchronisation of hipMemcpy with the legacy default stream does not cover them.
+// per-call device scratch: a training loop calls sgp_predict / sgp_w_stats every minibatch, hipMalloc + hipFree per call
+// was ~0.1 ms each
+static int call_scratch(sgp_handle* h, size_t count, double** out) {
+    if (count > h->call_capacity) {
+        if (h->dCall) hipFree(h->dCall);
+        h->dCall = nullptr;
+        h->call_capacity = 0;
+        const size_t want = count + count / 2;
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dCall), sizeof(double) * want));
+        h->call_capacity = want;
+    }
+    *out = h->dCall;
+    return 0;
+}
+
 static int quiesce(sgp_handle* h) {
     if (h->in_flight) {
         HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -310,7 +327,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
                     h->dDataScal, h->dKuu, h->dWk, h->dKinv, h->dLam, h->dWl, h->dSigma, h->dR, h->dTmp, h->dLambda0,
                     h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
                     h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals, h->dUvWork,
-                    h->dGradM, h->dGradPart, h->dGrad};
+                    h->dGradM, h->dGradPart, h->dGrad, h->dCall};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evSide) hipEventDestroy(h->evSide);
@@ -871,9 +888,9 @@ extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) 
     const int64_t n = h->n;
     if (n == 0) return 0;
     double *dI1 = nullptr, *dI2 = nullptr;
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dI1), sizeof(double) * n));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dI2), sizeof(double) * n));
     HIPCHK(h, hipDeviceSynchronize());
+    if (int crc = call_scratch(h, 2 * (size_t)n, &dI1)) return crc;
+    dI2 = dI1 + n;
     // |L^-1 k_n|^2 with the explicit inverse factor W_k, |Uv k_n|^2 = |L_R^T k_n|^2
     hipLaunchKernelGGL(k_quadform_cols, dim3(h->nblk, h->T), dim3(256), 0, s, h->dWk, h->dKuf, h->dPa, h->Mp, h->T, n, 0);
     hipLaunchKernelGGL(k_quadform_cols, dim3(h->nblk, h->T), dim3(256), 0, s, h->dUvT, h->dKuf, h->dPb, h->Mp, h->T, n, 1);
@@ -883,8 +900,6 @@ extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) 
     HIPCHK(h, hipGetLastError());
     if (I1) HIPCHK(h, hipMemcpy(I1, dI1, sizeof(double) * n, hipMemcpyDeviceToHost));
     if (I2) HIPCHK(h, hipMemcpy(I2, dI2, sizeof(double) * n, hipMemcpyDeviceToHost));
-    hipFree(dI1);
-    hipFree(dI2);
     return 0;
 }
 
@@ -907,12 +922,12 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
     h->in_flight = false;
     hipStream_t s = h->own;
     double *dXs = nullptr, *dMean = nullptr, *dMuTmp = nullptr;
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dXs), sizeof(double) * ns * h->D));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dMean), sizeof(double) * ns * h->dout));
+    if (int crc = call_scratch(h, (size_t)ns * (h->D + h->dout) + (mu_v ? (size_t)h->Q : 0), &dXs)) return crc;
+    dMean = dXs + (size_t)ns * h->D;
     HIPCHK(h, hipMemcpy(dXs, Xstar, sizeof(double) * ns * h->D, hipMemcpyHostToDevice));
     const double* dMu = h->dMu;
     if (mu_v) {
-        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dMuTmp), sizeof(double) * h->Q));
+        dMuTmp = dMean + (size_t)ns * h->dout;
         HIPCHK(h, hipMemcpy(dMuTmp, mu_v, sizeof(double) * h->Q, hipMemcpyHostToDevice));
         dMu = dMuTmp;
     }
@@ -929,9 +944,6 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpy(mean, dMean, sizeof(double) * ns * h->dout, hipMemcpyDeviceToHost));
-    hipFree(dXs);
-    hipFree(dMean);
-    if (dMuTmp) hipFree(dMuTmp);
     return 0;
 }
 
