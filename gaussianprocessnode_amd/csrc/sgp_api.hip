@@ -59,6 +59,7 @@ struct sgp_handle {
     double *dLambda0 = nullptr, *dXi0 = nullptr, *dOut = nullptr, *dWishart = nullptr, *dTrace = nullptr, *dTmp = nullptr;
     double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr, *dOut2 = nullptr, *dUvWork = nullptr;
     double *dGradM = nullptr, *dGradPart = nullptr, *dGrad = nullptr;   // theta-gradient scratch (allocated on first use)
+    double* dSaccK = nullptr;      // K_uu chain: Sigma-style accumulator of K_uu^-1 = W_K^T W_K (see sigma_row_tile)
     double* dCall = nullptr;       // scratch of the per-call outputs (sgp_predict, sgp_w_stats): grows, never shrinks
     size_t call_capacity = 0;
     int* dInfo = nullptr;
@@ -160,27 +161,36 @@ static void syrk_chunking(int ntiles, int num_cus, int* want, int* align) {
 // diagonal workgroup; extra workgroups of step j's launch finish block row j - 1 of W and pre-accumulate block row j (see
 // winv_row_tile), so that the one short launch after the last step only has two products per tile left for the last row.
 // form (may be nullptr): step 0 evaluates the matrix on the fly (Lambda = Lambda0 + W (x) Psi2, see LamForm) instead of
-// reading it from A.
+// reading it from A.  Sacc (may be nullptr; needs Winv): collects Sigma = W^T W row by row during the steps
+// (sigma_row_tile); pass the same buffer to launch_ata, which then only adds the last block row.
 static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, double* scratch, hipStream_t s,
-                         double* Winv = nullptr, const LamForm* form = nullptr) {
+                         double* Winv = nullptr, const LamForm* form = nullptr, double* Sacc = nullptr) {
     LamForm none;
     memset(&none, 0, sizeof none);
+    // extra workgroups of launch j (j >= 2): finish block row j - 1 of W, pre-accumulate block row j (not in the last,
+    // potrf-free launch j = Tn), and -- with Sacc -- add block row j - 2's contribution to Sigma = W^T W
+    auto extras = [&](int j) {
+        if (!Winv || j < 2) return 0;
+        int e = 2 * (j - 1) * (j < Tn ? 2 : 1);
+        if (Sacc) e += (j - 1) * j / 2;
+        return e;
+    };
     for (int j = 0; j < Tn; ++j) {
         const int nt = Tn - j;
-        const int extra = (Winv && j >= 2) ? 2 * (j - 1) * (j <= Tn - 1 ? 2 : 1) : 0;   // finish row j-1 (+ pre-accumulate row j)
-        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + extra), dim3(256), 0, s, A, ld, j, Tn, info, n_valid, scratch,
-                           Winv, (j == 0 && form) ? *form : none);
+        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + extras(j)), dim3(256), 0, s, A, ld, j, Tn, info, n_valid,
+                           scratch, Winv, Sacc, (j == 0 && form) ? *form : none);
     }
     if (Winv && Tn >= 2)
-        hipLaunchKernelGGL(k_potrf_step, dim3(2 * (Tn - 1)), dim3(256), 0, s, A, ld, Tn, Tn, info, n_valid, scratch, Winv, none);
+        hipLaunchKernelGGL(k_potrf_step, dim3(extras(Tn)), dim3(256), 0, s, A, ld, Tn, Tn, info, n_valid, scratch, Winv, Sacc,
+                           none);
 }
 // C = W^T W (rev: written index-reversed).  With mu: also R = C + mu mu^T, and with Psi2 the per-block shares of tr(R Psi2).
 static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s, int rev = 0, const double* mu = nullptr,
                        double* R = nullptr, const double* Psi2 = nullptr, const double* Kinv = nullptr,
-                       double* trace_part = nullptr, const UvArgs* uv = nullptr) {
+                       double* trace_part = nullptr, const UvArgs* uv = nullptr, const double* Sacc = nullptr) {
     const int extra = uv ? Tn * Tn : 0;                  // pass 2 of Uv rides in the same launch (uv_cols_role)
     hipLaunchKernelGGL(k_gemm32, dim3(Tn * (Tn + 1) / 2 * 4 + extra), dim3(256), 0, s, W, W, C, ld, Tn, 0, 0, rev, mu, R, Psi2,
-                       Kinv, trace_part, uv ? *uv : UvArgs{});
+                       Kinv, trace_part, uv ? *uv : UvArgs{}, Sacc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -259,6 +269,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dKuu, Mp * Mp);
     ALLOC(h->dWk, Mp * Mp);
     ALLOC(h->dKinv, Mp * Mp);
+    ALLOC(h->dSaccK, Mp * Mp);
     ALLOC(h->dLam, Qp * Qp);
     ALLOC(h->dWl, Qp * Qp);
     ALLOC(h->dSigma, Qp * Qp);
@@ -327,7 +338,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
                     h->dDataScal, h->dKuu, h->dWk, h->dKinv, h->dLam, h->dWl, h->dSigma, h->dR, h->dTmp, h->dLambda0,
                     h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
                     h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals, h->dUvWork,
-                    h->dGradM, h->dGradPart, h->dGrad, h->dCall};
+                    h->dGradM, h->dGradPart, h->dGrad, h->dCall, h->dSaccK};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evSide) hipEventDestroy(h->evSide);
@@ -555,8 +566,8 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, (const Params*)h->hParams,
                        h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0);
     hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
-    launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk);
-    launch_ata(h->dWk, h->dKinv, Mp, T, s);
+    launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk, nullptr, h->dSaccK);
+    launch_ata(h->dWk, h->dKinv, Mp, T, s, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->dSaccK);
 }
 
 static void enqueue_local(sgp_handle* h, hipStream_t s) {
@@ -585,7 +596,7 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     form.stats = h->dStats; form.Lambda0 = h->dLambda0; form.xi0 = h->dXi0; form.xi = h->dXi; form.P = h->dParams;
     form.M = M; form.Mp = Mp; form.d_out = h->dout; form.Q = Q; form.prior_form = h->prior_form;
     form.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
-    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl, &form);
+    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl, &form, h->dTmp);
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
     // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
     double* uvp = h->dXi;                    // xi is consumed by k_trmv_t; p lands in the same vector afterwards
@@ -616,11 +627,11 @@ static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
     uv.Wp = h->dWl; uv.p = uvp; uv.ck = uvck; uv.ak = uvak; uv.partial = uvpart; uv.LR = h->dUvT;
     uv.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
     if (h->dout == 1) {
-        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, h->dStats, h->dKinv, traceR, &uv);
+        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, h->dStats, h->dKinv, traceR, &uv, h->dTmp);
         partK = traceR + nata;
         nK = nR = nata;
     } else {
-        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, nullptr, nullptr, nullptr, &uv);
+        launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, nullptr, nullptr, nullptr, &uv, h->dTmp);
         hipLaunchKernelGGL(k_trace_kinv, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dTrace, M, Mp);
         hipLaunchKernelGGL(k_trace_R, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dR, traceR, M, Mp, h->dout, Qp,
                            (int64_t*)nullptr);
@@ -1022,9 +1033,9 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     const int n_uf = h->n > 0 ? h->nblk * T : 0;
     hipLaunchKernelGGL(k_form_G, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->dR, h->dKinv, dG, cnt);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)h->dKinv, (const double*)h->dStats, dT1,
-                       Mp, T, 3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{});
+                       Mp, T, 3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{}, (const double*)nullptr);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)dT1, (const double*)h->dKinv, dH, Mp, T,
-                       3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{});
+                       3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{}, (const double*)nullptr);
     if (h->n > 0)
         hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
                            h->has_omega ? h->dOmega : nullptr, h->dMu, h->dParams, part_uf, Mp, T, h->D, h->n);

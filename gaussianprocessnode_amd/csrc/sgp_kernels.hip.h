@@ -1030,9 +1030,42 @@ __device__ __forceinline__ void winv_row_tile(const double* __restrict__ L, doub
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sigma = W^T W rides along as well: Sigma(I,J) = sum_{k >= I} W(k,I)^T W(k,J), and block row k of W is final one launch
+// after step k.  Extra workgroups of launch j add row j - 2's contribution W(j-2,I)^T W(j-2,J) to every lower tile (I, J),
+// I <= j - 2, of the accumulator Sacc (first contribution of a tile: plain store), one 64 x 64 x 64 product each.  The
+// product launch after the factorisation (k_gemm32 mode 0) then only adds the LAST block row and runs its epilogue.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sigma_row_tile(const double* __restrict__ W, double* __restrict__ Sacc, int ld, int i, int I,
+                                               int J, double* panels, double* tile) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    double* As = panels;
+    double* Bs = panels + TB * PS;
+    load_panel_t(As, W, ld, i * TB, I * TB, TB, tid);              // As[kk][r] = W[i*64 + kk, I*64 + r]
+    if (I != J) load_panel_t(Bs, W, ld, i * TB, J * TB, TB, tid);  // Bs[kk][c] = W[i*64 + kk, J*64 + c]
+    if (I == i) {
+        for (int e = tid; e < TB * LT; e += 256) tile[e] = 0.0;    // first contribution to this tile
+    } else {
+        tile_g2s(tile, Sacc, ld, I * TB, J * TB);
+    }
+    __syncthreads();
+    Acc4 acc;
+    acc_zero(acc);
+    tile_mma(acc, As, (I != J) ? Bs : As, TB, lane, wr, wc);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.t[ti][tj][r] = -acc.t[ti][tj][r];
+    tile_sub_acc(tile, acc, lane, wr, wc);                        // tile += product
+    __syncthreads();
+    tile_s2g(tile, Sacc, ld, I * TB, J * TB);
+}
+
 __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
                                                     int n_valid, double* __restrict__ scratch, double* __restrict__ Winv,
-                                                    LamForm form) {
+                                                    double* __restrict__ Sacc, LamForm form) {
     // LDS: two MFMA operand panels (2 x 64 x PS) and two 64 x 64 tiles.  The panels stay valid while the diagonal tile is
     // factored: the waves that idle during the pivot runs use them for the block's own rank-64 update.
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
@@ -1043,10 +1076,16 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     {
         const int npot = (Tn - j) * (Tn - j + 1) / 2;     // this step's own tiles; the workgroups beyond them work on
         if ((int)blockIdx.x >= npot) {                    // the inverse factor (winv_row_tile): finish block row j - 1,
-            int e = blockIdx.x - npot;                    // then pre-accumulate block row j
-            const int nfin = 2 * (j - 1);
+            int e = blockIdx.x - npot;                    // then pre-accumulate block row j; and Sigma = W^T W
+            const int nfin = 2 * (j - 1);                 // collects the contribution of block row j - 2 (sigma_row_tile)
+            const int npre = (j < Tn) ? nfin : 0;
             if (e < nfin) winv_row_tile(A, Winv, ld, j - 1, e >> 1, e & 1, lds, 2);
-            else { e -= nfin; winv_row_tile(A, Winv, ld, j, e >> 1, e & 1, lds, 1); }
+            else if (e < nfin + npre) { e -= nfin; winv_row_tile(A, Winv, ld, j, e >> 1, e & 1, lds, 1); }
+            else {
+                int I, J;
+                tile_from_index(e - nfin - npre, I, J);   // I >= J, I <= j - 2
+                sigma_row_tile(Winv, Sacc, ld, j - 2, I, J, lds, tiles);
+            }
             return;
         }
     }
@@ -1218,7 +1257,8 @@ __device__ __forceinline__ void uv_cols_role(const UvArgs& u, int Qp, int kb, in
 __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
                                                 int ld, int Tn, int mode, int s, int rev, const double* __restrict__ mu,
                                                 double* __restrict__ R, const double* __restrict__ Psi2,
-                                                const double* __restrict__ Kinv, double* __restrict__ trace_part, UvArgs uv) {
+                                                const double* __restrict__ Kinv, double* __restrict__ trace_part, UvArgs uv,
+                                                const double* __restrict__ Sacc) {
     __shared__ double As[64 * PS32];
     __shared__ double Bs[64 * PS32];
     __shared__ double tred[4];
@@ -1236,7 +1276,8 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
     int I, J, kbeg, kend;
     if (mode == 0) {
         tile_from_index(blockIdx.x >> 2, I, J);
-        kbeg = I; kend = Tn;
+        kbeg = Sacc ? max(I, Tn - 1) : I;                                // with Sacc only the last block row is left to add
+        kend = Tn;
     } else {                                                             // mode 3: general C = A B, every tile
         const int t = blockIdx.x >> 2;
         I = t / Tn; J = t % Tn; kbeg = 0; kend = Tn;
@@ -1244,6 +1285,10 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
     const int r0 = I * TB + qi * 32, c0 = J * TB + qj * 32;
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
     const int li = lane & 15, lk = lane >> 4;
+    if (mode == 0 && Sacc && I < Tn - 1) {                               // the block rows before the last, collected by
+#pragma unroll                                                           // sigma_row_tile during the factorisation
+        for (int r = 0; r < 4; ++r) acc[r] = Sacc[(size_t)(c0 + wc * 16 + li) * ld + r0 + wr * 16 + lk + 4 * r];
+    }
     for (int k = kbeg; k < kend; ++k) {
         __syncthreads();
         if (mode == 0) load_panel32_t(As, A, ld, k * TB, r0, tid);      // As[kk][i] = W[k*64+kk, r0+i]
