@@ -1289,6 +1289,24 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
 #pragma unroll                                                           // sigma_row_tile during the factorisation
         for (int r = 0; r < 4; ++r) acc[r] = Sacc[(size_t)(c0 + wc * 16 + li) * ld + r0 + wr * 16 + lk + 4 * r];
     }
+    // mode 0: the epilogue's operands (this thread's 4-row run of Psi2 / Kuu^-1 and its mu entries, see below) are fetched
+    // now, so that their latency hides behind the product instead of following it
+    const int oc = tid >> 3, o4 = (tid & 7) * 4;
+    const int gcA = rev ? ld - 1 - (c0 + oc) : c0 + oc, grA = rev ? ld - 1 - (r0 + o4 + 3) : r0 + o4;
+    const int gcB = rev ? ld - 1 - (r0 + oc) : r0 + oc, grB = rev ? ld - 1 - (c0 + o4 + 3) : c0 + o4;
+    const size_t offA = (size_t)gcA * ld + grA, offB = (size_t)gcB * ld + grB;
+    double2 p0 = make_double2(0.0, 0.0), p1 = p0, q0 = p0, q1 = p0;
+    double muA[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, muB[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (mode == 0 && mu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { muA[e] = mu[grA + e]; muB[e] = mu[grB + e]; }
+        muA[4] = mu[gcA];
+        muB[4] = mu[gcB];
+        if (Psi2) {
+            p0 = *reinterpret_cast<const double2*>(Psi2 + offA); p1 = *reinterpret_cast<const double2*>(Psi2 + offA + 2);
+            q0 = *reinterpret_cast<const double2*>(Kinv + offA); q1 = *reinterpret_cast<const double2*>(Kinv + offA + 2);
+        }
+    }
     for (int k = kbeg; k < kend; ++k) {
         __syncthreads();
         if (mode == 0) load_panel32_t(As, A, ld, k * TB, r0, tid);      // As[kk][i] = W[k*64+kk, r0+i]
@@ -1301,29 +1319,54 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
         for (int k4 = 0; k4 < 16; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k4 * 4 * PS32], bp[k4 * 4 * PS32], acc, 0, 0, 0);
     }
     double tsum = 0.0, tsumK = 0.0;
+    if (mode != 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int row = r0 + wr * 16 + lk + 4 * r, col = c0 + wc * 16 + li;
-        double v = acc[r];
-        if (mode == 0) {
-            if (rev) { row = ld - 1 - row; col = ld - 1 - col; }
-            C[(size_t)col * ld + row] = v;
-            C[(size_t)row * ld + col] = v;       // mirror (on diagonal tiles two quadrants write the same bits twice)
-            if (mu) {
-                const double rv = fma(mu[row], mu[col], v);
-                R[(size_t)col * ld + row] = rv;
-                R[(size_t)row * ld + col] = rv;
-                if (Psi2) {
-                    const double ps = Psi2[(size_t)col * ld + row];
-                    tsum = fma(rv, ps, tsum);
-                    tsumK = fma(Kinv[(size_t)col * ld + row], ps, tsumK);
-                }
+        for (int r = 0; r < 4; ++r)
+            C[(size_t)(c0 + wc * 16 + li) * ld + r0 + wr * 16 + lk + 4 * r] = acc[r];
+        return;
+    }
+    // mode 0 epilogue through LDS: the accumulator layout scatters a wave's store over 16 columns (32-byte pieces of 16
+    // different lines); staged as a 32 x 32 quadrant, every thread owns 4 consecutive rows of one column, 8 threads a
+    // 256-byte run -- for the quadrant itself and, with rows and columns exchanged, for its mirror image.  (The direct form
+    // held this launch at 15 us for 9 MB of traffic.)
+    __syncthreads();
+    double* Qd = As;                                                     // Qd[c][r], stride 33
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Qd[(wc * 16 + li) * 33 + wr * 16 + lk + 4 * r] = acc[r];
+    __syncthreads();
+    {   // the quadrant: column c0 + oc, rows r0 + o4 .. + 3 (index-reversed: a descending, still contiguous run)
+        double v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = Qd[oc * 33 + o4 + (rev ? 3 - e : e)];
+        *reinterpret_cast<double2*>(C + offA) = make_double2(v[0], v[1]);
+        *reinterpret_cast<double2*>(C + offA + 2) = make_double2(v[2], v[3]);
+        if (mu) {
+            double rv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rv[e] = fma(muA[e], muA[4], v[e]);
+            *reinterpret_cast<double2*>(R + offA) = make_double2(rv[0], rv[1]);
+            *reinterpret_cast<double2*>(R + offA + 2) = make_double2(rv[2], rv[3]);
+            if (Psi2) {
+                tsum = fma(rv[0], p0.x, fma(rv[1], p0.y, fma(rv[2], p1.x, rv[3] * p1.y)));
+                tsumK = fma(q0.x, p0.x, fma(q0.y, p0.y, fma(q1.x, p1.x, q1.y * p1.y)));
             }
-        } else {
-            C[(size_t)col * ld + row] = v;
         }
     }
-    if (mode == 0 && trace_part) {
+    {   // the mirror image: column r0 + oc, rows c0 + o4 .. + 3 (on diagonal tiles two quadrants write the same bits twice)
+        double v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = Qd[(o4 + (rev ? 3 - e : e)) * 33 + oc];
+        *reinterpret_cast<double2*>(C + offB) = make_double2(v[0], v[1]);
+        *reinterpret_cast<double2*>(C + offB + 2) = make_double2(v[2], v[3]);
+        if (mu) {
+            double rv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rv[e] = fma(muB[e], muB[4], v[e]);
+            *reinterpret_cast<double2*>(R + offB) = make_double2(rv[0], rv[1]);
+            *reinterpret_cast<double2*>(R + offB + 2) = make_double2(rv[2], rv[3]);
+        }
+    }
+    if (trace_part) {
         // off-diagonal tiles stand for both mirror images; on diagonal tiles all four quadrants are computed
         if (I != J) { tsum *= 2.0; tsumK *= 2.0; }
         tsum = block_sum(tsum, tred);
