@@ -577,24 +577,6 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
     return y;
 }
 
-// ---- permuted LDS layouts of the sequential tile routines --------------------------------------------------
-// A lane (row r, quarter q) owns the row's entries of columns c = q (mod 4).  Whatever it needs per pivot from
-// OTHER rows (the pivot column / a row or column of L) is stored so that its 16 values are contiguous and 16-byte
-// aligned: index (q, i) <-> column or row 4 i + q, with 32 slots per q (slots 16..31 are a dead zone read by the
-// sliding register window past column 63).  One ds_read_b128 then brings two values (ds_read_b64 needs ~4 waves
-// per SIMD to reach its rate, ds_read_b128 does with the one wave per SIMD these kernels run at).
-constexpr int QS = 34;                 // slots per quarter: 32 + 2 so that the four quarters fall on different banks
-constexpr int PR = 4 * QS;             // doubles per permuted row
-
-__device__ __forceinline__ void load16(double (&t)[16], const double* p) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        double2 v = *reinterpret_cast<const double2*>(p + 2 * u);
-        t[2 * u] = v.x;
-        t[2 * u + 1] = v.y;
-    }
-}
-
 // Factor the 64 x 64 tile S (LDS, S[r][c], stride LT, lower part valid) in place: on exit S holds L (strict upper part
 // zero) and rinv[c] = 1 / L_cc.  colw: 16 doubles of LDS.  Blocked by 16 columns, wave w owns rows 16 w .. 16 w + 15:
 //   (1) every wave w >= cb subtracts the contribution of the block columns to the left from its 16 x 16 block (one MFMA
