@@ -165,6 +165,13 @@ def main():
                      "achieved_alone": syrk_flops / (syrk_us_alone * 1e-6) / 1e12,
                      "algorithmic_flops_per_launch": syrk_flops,
                      "peak_note": "78.6 = MI355X FP64 matrix spec; a back-to-back MFMA loop (tools/mfma_f64_probe.hip) saturates at 49, v_fma_f64 at 63-67"},
+        # second data-sized kernel (SURVEY.md §8d asks for HBM GB/s on K_uf): k_gram_uf writes 8 n Mp bytes of K_uf once
+        "roofline_k_uf": {"kernel": "k_gram_uf (K_uf assembly, coalesced 32-B stores)", "bound": "hbm",
+                          "achieved": 8.0 * n_loc * dev.stats_layout()[2] / (tick_us(_lib.SGP_T_GRAM) * 1e-6) / 1e9,
+                          "peak": 8000.0, "unit": "GB/s",
+                          "frac": 8.0 * n_loc * dev.stats_layout()[2] / (tick_us(_lib.SGP_T_GRAM) * 1e-6) / 1e9 / 8000.0,
+                          "algorithmic_bytes_per_launch": 8.0 * n_loc * dev.stats_layout()[2],
+                          "note": "41 MB at T: the write stays in the 256 MiB Infinity Cache; PMC WRITE_SIZE 41.6 MB"},
         "phases_us": {"sweep_device": tick_us(_lib.SGP_T_SWEEP), "gram_uf": tick_us(_lib.SGP_T_GRAM),
                       "gram_uf_alone_hip_events": gram_us_alone, "syrk": syrk_us,
                       "local": tick_us(_lib.SGP_T_LOCAL), "gap_local_to_finish": tick_us(_lib.SGP_T_GAP_LOCAL_FINISH),

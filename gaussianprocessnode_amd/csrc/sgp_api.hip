@@ -575,8 +575,12 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, (const Params*)h->hParams,
                        h->dParams, (int*)nullptr, M, Mp, D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP);
     if (h->n > 0) {
-        hipLaunchKernelGGL(k_gram_uf, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
-                           h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM);
+        if (D <= 8)
+            hipLaunchKernelGGL(k_gram_uf<8>, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
+                               h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM);
+        else
+            hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
+                               h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM);
         hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                            h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, h->ntiles, h->nchunks,
                            h->dStamps + STAMP_STRIDE * SGP_T_SYRK);
@@ -864,8 +868,11 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
     auto launch = [&]() {
-        if (which == SGP_T_GRAM)
-            hipLaunchKernelGGL(k_gram_uf, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
+        if (which == SGP_T_GRAM && h->D <= 8)
+            hipLaunchKernelGGL(k_gram_uf<8>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
+                               h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr);
+        else if (which == SGP_T_GRAM)
+            hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr);
         else
             hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,

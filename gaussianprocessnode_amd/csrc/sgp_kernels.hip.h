@@ -165,13 +165,16 @@ __global__ void __launch_bounds__(256) k_gram_uu(const double* __restrict__ Xus,
 //   X   : D x N AoS (one point per column), unscaled;  Yw : N x d_out column-major
 //   Kuf : Mp x N column-major;  bpart : [nblk][d_out][Mp]
 // ------------------------------------------------------------------------------------------------
+// DCAP: capacity of the LDS coordinate panels (8 for D <= 8 -- 18 KB of LDS per workgroup instead of 42 KB, i.e. 8
+// instead of 3 resident workgroups per CU for this store-bound kernel -- else MAXD)
+template <int DCAP>
 __global__ void __launch_bounds__(256) k_gram_uf(const double* __restrict__ Xus, const double* __restrict__ X,
                                                  const double* __restrict__ Yw, double* __restrict__ Kuf,
                                                  double* __restrict__ bpart, const Params* __restrict__ P,
                                                  int M, int Mp, int D, int64_t N, int d_out, int64_t* stamps) {
-    __shared__ double us[MAXD * TB];
+    __shared__ double us[DCAP * TB];
     stamp_enter(stamps);
-    __shared__ double xs[MAXD * TB];
+    __shared__ double xs[DCAP * TB];
     __shared__ double ys[MAXO * TB];
     __shared__ double red[16 * TB];
     const int I = blockIdx.y * TB;                           // m tile on grid.y, point block on grid.x (no 65535 limit)
