@@ -585,7 +585,7 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
                            h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, h->ntiles, h->nchunks,
                            h->dStamps + STAMP_STRIDE * SGP_T_SYRK);
     }
-    hipLaunchKernelGGL(k_assemble, dim3(T, T, 4), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
+    hipLaunchKernelGGL(k_assemble, dim3(T, T, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
                        h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
                        SGP_S_COUNT + h->dout * h->dout, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL, h->dInfo + 1);
 }

@@ -430,55 +430,60 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
                                                   const double* __restrict__ data_scalars, double* __restrict__ stats,
                                                   int Mp, int ntiles, int nchunks, int nblk, int d_out, int nscal, int64_t* stamps,
                                                   int* __restrict__ info_reset) {
-    // grid (T, T, 4): block z sums rows [16 z, 16 z + 16) of the slab tile (I, J), I >= J, and writes both mirror images
-    __shared__ double tile[16 * LT];
+    // grid (T, T, 16): block z sums rows [4 z, 4 z + 4) of the slab tile (I, J), I >= J -- one entry per thread, up to 12
+    // chunk loads in flight (the kernel is latency-bound: the first version, 4 entries per thread in rounds of 4 chunks on a
+    // quarter of the workgroups, took 12 us for 28 MB) -- and writes both mirror images
+    __shared__ double tile[4 * LT];
     const int I = blockIdx.x, J = blockIdx.y, z = blockIdx.z;
     const int tid = threadIdx.x;
     if (I >= J) {
         const int t = I * (I + 1) / 2 + J;
-        const double* base = slabs + (size_t)t * (TB * TB) + z * 16 * TB;
+        const double* base = slabs + (size_t)t * (TB * TB) + z * 4 * TB + tid;
         const size_t cstride = (size_t)ntiles * (TB * TB);
-        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        double s = 0.0;
         int c = 0;
-        for (; c + 4 <= nchunks; c += 4) {                 // 16 independent loads in flight per thread
-            double v[4][4];
+        for (; c + 12 <= nchunks; c += 12) {
+            double v[12];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 12; ++u) v[u] = base[(size_t)(c + u) * cstride];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[u][e] = base[(size_t)(c + u) * cstride + e * 256 + tid];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)                      // fixed summation order: chunk 0, 1, 2, ...
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s[e] += v[u][e];
+            for (int u = 0; u < 12; ++u) s += v[u];          // fixed summation order: chunk 0, 1, 2, ...
         }
-        for (; c < nchunks; ++c)
+        for (; c + 4 <= nchunks; c += 4) {
+            double v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] += base[(size_t)c * cstride + e * 256 + tid];
+            for (int u = 0; u < 4; ++u) v[u] = base[(size_t)(c + u) * cstride];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int idx = e * 256 + tid;                         // = i_local * 64 + j
-            tile[(idx >> 6) * LT + (idx & 63)] = s[e];
+            for (int u = 0; u < 4; ++u) s += v[u];
         }
+        for (; c < nchunks; ++c) s += base[(size_t)c * cstride];
+        tile[(tid >> 6) * LT + (tid & 63)] = s;              // tid = i_local * 64 + j
         __syncthreads();
-        for (int e = tid; e < 16 * TB; e += 256) {
-            int j = e >> 4, il = e & 15;                     // 16 consecutive i per column j
-            stats[(size_t)(J * TB + j) * Mp + I * TB + z * 16 + il] = tile[il * LT + j];
+        {
+            const int j = tid >> 2, il = tid & 3;            // 4 consecutive i per column j
+            stats[(size_t)(J * TB + j) * Mp + I * TB + z * 4 + il] = tile[il * LT + j];
         }
-        if (I != J)
-            for (int e = tid; e < 16 * TB; e += 256) {
-                int il = e >> 6, j = e & 63;                 // mirror: 64 consecutive j per row i
-                stats[(size_t)(I * TB + z * 16 + il) * Mp + J * TB + j] = tile[il * LT + j];
-            }
+        if (I != J) {
+            const int il = tid >> 6, j = tid & 63;           // mirror: 64 consecutive j per row i
+            stats[(size_t)(I * TB + z * 4 + il) * Mp + J * TB + j] = tile[il * LT + j];
+        }
     }
-    // B = sum of the per-block partials: blocks (I, 0, z) take outputs o = z, z + 4, ...; 4 threads per entry walk
-    // the partials with a stride of 4 (independent loads in flight), combined in a fixed order through LDS
+    // B = sum of the per-block partials: blocks (I, 0, z) take outputs o = z, z + 16, ...; 4 threads per entry walk
+    // the partials with a stride of 4 (16 independent loads in flight), combined in a fixed order through LDS
     if (J == 0) {
         __shared__ double red[4 * TB];
         double* B = stats + (size_t)Mp * Mp;
         const int m = tid & 63, part = tid >> 6;
-        for (int o = z; o < d_out; o += 4) {
+        for (int o = z; o < d_out; o += 16) {
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             int b = part;
+            for (; b + 60 < nblk; b += 64) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + I * TB + m];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[u & 3] += v[u];
+            }
             for (; b + 12 < nblk; b += 16) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc[u] += bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + I * TB + m];
