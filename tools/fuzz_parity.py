@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Random-shape parity fuzz: device sweep vs oracle over ragged sizes, weights, uncertain outputs and prior forms."""
+import math, sys
+import numpy as np
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import gaussianprocessnode_amd as G
+from oracle import sgp_oracle as O
+
+def relF(a, b): return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+worst, fails = 0.0, 0
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+    N = int(rng.choice([1, 2, 17, 63, 64, 65, 130, 500, 1000, 2500]))
+    M = int(rng.choice([1, 3, 20, 63, 64, 65, 100, 129, 200, 300, 450]))
+    D = int(rng.integers(1, 11))
+    X = rng.uniform(-1.7, 1.7, (N, D)); Xu = rng.uniform(-1.7, 1.7, (M, D))
+    y = np.sin(X.sum(1)) + 0.1 * rng.normal(size=N)
+    vy = rng.uniform(0.05, 0.5, N) if rng.random() < 0.3 else None
+    wts = rng.uniform(0.3, 1.5, N) if rng.random() < 0.3 else None
+    iso = rng.random() < 0.3
+    ell = np.full(D, rng.uniform(0.8, 2.5)) if iso else rng.uniform(0.8, 2.5, D)
+    s2, w, jit = float(rng.uniform(0.3, 2.0)), float(10 ** rng.uniform(-1, 3)), 1e-6
+    form = int(rng.integers(0, 3))
+    A = rng.normal(size=(M, M)); Sig0 = A @ A.T / M + 0.5 * np.eye(M); mu0 = 0.3 * rng.normal(size=M)
+    if form == 2: Sig0, mu0 = 50.0 * np.eye(M), np.zeros(M)
+    with G.SGPDevice(N, M, D, keep_kuf=True) as dev:
+        dev.set_inducing(Xu); dev.set_data(X, y, vy, wts); dev.set_kernel(s2, ell[:1] if iso else ell, jit); dev.set_noise([[w]])
+        if form == 0: dev.set_prior_meancov(mu0, Sig0)
+        elif form == 1: L0 = np.linalg.inv(Sig0); dev.set_prior_precision(L0 @ mu0, L0)
+        else: dev.set_prior_isotropic(50.0)
+        dev.sweep()
+        mu, Sig, Uv = dev.posterior(); sc = dev.scalars()
+    Xo, yo, vyo = X, y, vy
+    ref = None
+    if wts is None:
+        ref = O.vmp_sweep(Xu, X, y, vy, s2, ell, w, jitter=jit, mu0=mu0, Sigma0=Sig0)
+        mu_r, Sig_r, Uv_r, I2_r = ref.mu_v, ref.Sigma_v, ref.Uv, ref.sum_I2
+    else:                                           # weighted statistics by hand
+        K = O.kernelmatrix(s2, ell, Xu, X)
+        Psi2 = (K * wts) @ K.T; b = K @ (wts * y)
+        Lam = np.linalg.inv(Sig0) + w * Psi2; Sig_r = np.linalg.inv(Lam); mu_r = Sig_r @ (np.linalg.inv(Sig0) @ mu0 + w * b)
+        R = Sig_r + np.outer(mu_r, mu_r); Uv_r = np.linalg.cholesky(R).T
+        I2_r = float(np.sum(wts * (y * y + (vy if vy is not None else 0.0))) - 2 * b @ mu_r + np.sum(R * Psi2))
+    cond = np.linalg.cond(np.linalg.inv(Sig_r))
+    tol = min(1e-4, max(1e-9, 100 * np.finfo(float).eps * cond))
+    e = max(relF(mu, mu_r), relF(Sig, Sig_r), relF(Uv, Uv_r))
+    e2 = abs(sc.sum_I2 - I2_r) / max(abs(I2_r), 1e-300)
+    ok = e < tol and e2 < max(1e-7, tol)
+    worst = max(worst, e / tol)
+    fails += (not ok)
+    print(f"{'ok ' if ok else 'BAD'} N={N:5d} M={M:4d} D={D:2d} vy={vy is not None!s:5} wts={wts is not None!s:5} iso={iso!s:5} prior={form} w={w:8.2f} "
+          f"cond={cond:8.1e} err={e:8.1e} I2err={e2:8.1e} tol={tol:8.1e}", flush=True)
+print("fails", fails, "worst err/tol", worst)
+sys.exit(1 if fails else 0)
