@@ -100,6 +100,11 @@ class HipEngine:
     def synchronize(self):
         self.torch.cuda.synchronize()
 
+    def theta_objective_local(self, n_ell=None):
+        """This shard's part of the hyper-parameter objective and of its gradient (both are additive over shards).  The
+        device re-evaluates its LOCAL statistics for this: the bound buffer holds the all-reduced ones after a sweep."""
+        return self.dev.theta_objective(want_grad=True, n_ell=n_ell)
+
 
 class ShardedSweep:
     """local statistics -> all-reduce(sum) -> replicated tail.  `engine` provides sweep_local(),
@@ -127,3 +132,18 @@ class ShardedSweep:
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
+
+    def theta_objective(self, n_ell=None):
+        """neg_log_backwardmess_fast and its gradient over ALL shards (helper_functions/derivative_helper.jl:23-39,55-63):
+        each rank contributes its points' terms at the replicated q(v); one small all-reduce (2 + n_ell doubles)."""
+        import numpy as np
+        value, grad = self.engine.theta_objective_local(n_ell)
+        packed = np.concatenate([[value], np.asarray(grad, dtype=np.float64)])
+        if self.world > 1:
+            import torch
+            t = torch.from_numpy(packed)
+            if self.dist.get_backend(self.group) == "nccl":
+                t = t.to(self.engine.stats.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            packed = t.cpu().numpy()
+        return float(packed[0]), packed[1:].copy()

@@ -93,3 +93,11 @@ class OracleShardEngine:
         st = O.SuffStats(Psi2, B, np.array([[s_yy]]), self.s2 * s_w, n)
         self.res = O.vmp_sweep(self.Xu, None, None, None, self.s2, self.ell, self.w, jitter=self.jitter,
                                Lambda0=np.eye(self.M) / self.prior_var, xi0=np.zeros(self.M), stats=st)
+
+    def theta_objective_local(self, n_ell=None):
+        """This shard's terms of neg_log_backwardmess_fast at the replicated q(v), gradient by central differences."""
+        r = self.res
+        f = lambda p: O.theta_objective(self.Xu, self.X, self.y, p[0], p[1:], r.mu_v, r.Uv, self.w, jitter=self.jitter)
+        p0 = np.concatenate([[self.s2], self.ell])
+        g = np.array([(f(p0 + 1e-6 * e) - f(p0 - 1e-6 * e)) / 2e-6 for e in np.eye(len(p0))])
+        return f(p0), g

@@ -160,6 +160,11 @@ ref = O.vmp_sweep(Xu, X, y, None, s2, ell, w, jitter=1e-8, Lambda0=np.eye(M) / 5
 assert np.linalg.norm(eng.res.mu_v - ref.mu_v) / np.linalg.norm(ref.mu_v) < 1e-10
 assert np.linalg.norm(eng.res.Sigma_v - ref.Sigma_v) / np.linalg.norm(ref.Sigma_v) < 1e-10
 assert abs(eng.res.sum_I2 - ref.sum_I2) < 1e-9 * abs(ref.sum_I2) and eng.res.stats.n == N
+val, grad = sw.theta_objective()           # additive over shards: one more (tiny) all-reduce
+f = lambda p: O.theta_objective(Xu, X, y, p[0], p[1:], ref.mu_v, ref.Uv, w, jitter=1e-8)
+p0 = np.concatenate([[s2], ell])
+g_ref = np.array([(f(p0 + 1e-6 * e) - f(p0 - 1e-6 * e)) / 2e-6 for e in np.eye(3)])
+assert abs(val - f(p0)) < 1e-8 * abs(f(p0)) and np.allclose(grad, g_ref, rtol=1e-5, atol=1e-6)
 print(f"rank {rank} ok", flush=True)
 dist.destroy_process_group()
 '''

@@ -32,13 +32,18 @@ for it in range(3):
     sw.sweep()
     eng.synchronize()
 mu, Sig, _ = dev.posterior(want_uv=False)
+val_s, grad_s = sw.theta_objective(n_ell=D)
 say("single-rank reference")
 with G.SGPDevice(N, M, D) as ref:
     ref.set_inducing(Xu); ref.set_data(X, y); ref.set_kernel(0.9, np.full(D, 1.5), 1e-8)
     ref.set_prior_isotropic(50.0); ref.set_noise([[100.0]]); ref.sweep()
     mu1, Sig1, _ = ref.posterior(want_uv=False)
+    val_1, grad_1 = ref.theta_objective(want_grad=True, n_ell=D)
 err = np.linalg.norm(mu - mu1) / np.linalg.norm(mu1), np.linalg.norm(Sig - Sig1) / np.linalg.norm(Sig1)
 say(f"sharded vs single-rank: mu {err[0]:.2e} Sigma {err[1]:.2e}")
+gerr = abs(val_s - val_1) / abs(val_1), np.linalg.norm(grad_s - grad_1) / np.linalg.norm(grad_1)
+say(f"sharded theta objective / gradient vs single-rank: {gerr[0]:.2e} {gerr[1]:.2e}")
+assert max(gerr) < 1e-6
 assert max(err) < 1e-7          # the two halves of Psi2 are summed in a different order: cond(Lambda) * eps
 dist.barrier()
 dist.destroy_process_group()
