@@ -1028,7 +1028,7 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     if (!h->dGradM) {
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGradM), sizeof(double) * 3 * (size_t)Mp * Mp));
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGradPart),
-                            sizeof(double) * ((size_t)std::max(nblk_max, 1) * T + (size_t)T * T) * GRAD_SLOTS));
+                            sizeof(double) * ((size_t)std::max(std::max(nblk_max, 1) * T, 512 + T) + (size_t)T * T) * GRAD_SLOTS));
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGrad), sizeof(double) * GRAD_SLOTS));
     }
     double* dG = h->dGradM;
@@ -1037,14 +1037,16 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     double* part_uu = h->dGradPart;
     double* part_uf = h->dGradPart + (size_t)T * T * GRAD_SLOTS;
     const size_t cnt = (size_t)Mp * Mp;
-    const int n_uf = h->n > 0 ? h->nblk * T : 0;
+    // split the K loop of the G K_uf product when there are few point blocks (minibatches), so that the launch fills the chip
+    const int KS = h->n > 0 ? std::max(1, std::min(T, 512 / std::max(1, h->nblk * T))) : 1;
+    const int n_uf = h->n > 0 ? h->nblk * T * KS : 0;
     hipLaunchKernelGGL(k_form_G, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->dR, h->dKinv, dG, cnt);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)h->dKinv, (const double*)h->dStats, dT1,
                        Mp, T, 3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{}, (const double*)nullptr);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)dT1, (const double*)h->dKinv, dH, Mp, T,
                        3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{}, (const double*)nullptr);
     if (h->n > 0)
-        hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
+        hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T, KS), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
                            h->has_omega ? h->dOmega : nullptr, h->dMu, h->dParams, part_uf, Mp, T, h->D, h->n);
     hipLaunchKernelGGL(k_theta_grad_uu, dim3(T, T), dim3(256), 0, s, dH, h->dXus, h->dParams, part_uu, h->M, Mp, h->D);
     hipLaunchKernelGGL(k_theta_grad_finish, dim3(1), dim3(64), 0, s, part_uf, n_uf, part_uu, T * T,

@@ -1861,6 +1861,9 @@ __global__ void __launch_bounds__(256) k_theta_grad_uf(const double* __restrict_
                                                        const double* __restrict__ Yw, const double* __restrict__ omega,
                                                        const double* __restrict__ mu, const Params* __restrict__ P,
                                                        double* __restrict__ partial, int Mp, int T, int D, int64_t N) {
+    // grid (nblk, T, KS): with few points (minibatches) the K loop is split over blockIdx.z so that the launch fills the
+    // chip; the contraction is linear in G K_uf, so every split contributes its own partial sums (the y mu term rides
+    // with split 0)
     __shared__ double lds[2 * TB * PS];
     __shared__ double ys[TB], om[TB], mus[TB];
     __shared__ double wsum[4][GRAD_SLOTS];
@@ -1871,7 +1874,9 @@ __global__ void __launch_bounds__(256) k_theta_grad_uf(const double* __restrict_
     double* Bs = lds + TB * PS;
     Acc4 acc;
     acc_zero(acc);
-    for (int k = 0; k < T; ++k) {
+    const int ks = blockIdx.z, KS = gridDim.z;
+    const int kbeg = (int)((int64_t)T * ks / KS), kend = (int)((int64_t)T * (ks + 1) / KS);
+    for (int k = kbeg; k < kend; ++k) {
         __syncthreads();
         load_panel_n(As, G, Mp, I * TB, k * TB, TB, tid);          // As[kk][i] = G[I*64 + i, k*64 + kk]  (G symmetric)
         for (int t = tid; t < TB * 16; t += 256) {                 // Bs[kk][j] = Kuf[k*64 + kk, n0 + j]
@@ -1922,7 +1927,7 @@ __global__ void __launch_bounds__(256) k_theta_grad_uf(const double* __restrict_
             for (int r = 0; r < 4; ++r) {
                 const int row = acc_row(lane, wr, ti, r);
                 const double kv = (n < N) ? Kuf[(size_t)n * Mp + I * TB + row] : 0.0;
-                const double v = 2.0 * (om[col] * acc.t[ti][tj][r] - ys[col] * mus[row]) * kv;
+                const double v = 2.0 * (om[col] * acc.t[ti][tj][r] - (ks == 0 ? ys[col] * mus[row] : 0.0)) * kv;
                 z[ti][tj][r] = v;
                 e0 += v;
             }
@@ -1947,7 +1952,7 @@ __global__ void __launch_bounds__(256) k_theta_grad_uf(const double* __restrict_
     }
     __syncthreads();
     if (tid <= D)
-        partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GRAD_SLOTS + tid] =
+        partial[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * GRAD_SLOTS + tid] =
             (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
 }
 
