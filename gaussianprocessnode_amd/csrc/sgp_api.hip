@@ -1049,7 +1049,7 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
         hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T, KS), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
                            h->has_omega ? h->dOmega : nullptr, h->dMu, h->dParams, part_uf, Mp, T, h->D, h->n);
     hipLaunchKernelGGL(k_theta_grad_uu, dim3(T, T), dim3(256), 0, s, dH, h->dXus, h->dParams, part_uu, h->M, Mp, h->D);
-    hipLaunchKernelGGL(k_theta_grad_finish, dim3(1), dim3(64), 0, s, part_uf, n_uf, part_uu, T * T,
+    hipLaunchKernelGGL(k_theta_grad_finish, dim3(1), dim3(256), 0, s, part_uf, n_uf, part_uu, T * T,
                        h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, h->dParams, h->dGrad, h->D, h->n_ell);
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());

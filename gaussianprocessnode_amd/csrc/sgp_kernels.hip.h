@@ -2009,21 +2009,37 @@ __global__ void __launch_bounds__(256) k_theta_grad_uu(const double* __restrict_
 }
 
 // grad[0] = df/dsigma2, grad[1 ..] = df/dell (n_ell = 1: one shared lengthscale, else one per dimension)
-__global__ void __launch_bounds__(64) k_theta_grad_finish(const double* __restrict__ part_uf, int n_uf,
-                                                          const double* __restrict__ part_uu, int n_uu,
-                                                          const double* __restrict__ stats_scal, const Params* __restrict__ P,
-                                                          double* __restrict__ grad, int D, int n_ell) {
+__global__ void __launch_bounds__(256) k_theta_grad_finish(const double* __restrict__ part_uf, int n_uf,
+                                                           const double* __restrict__ part_uu, int n_uu,
+                                                           const double* __restrict__ stats_scal, const Params* __restrict__ P,
+                                                           double* __restrict__ grad, int D, int n_ell) {
+    // thread t sums the partial blocks t, t + 256, ... for ALL slots at once (independent loads; a first version walked the
+    // blocks slot by slot with one wave: 31 us of load latency), then one workgroup reduction per slot -- fixed order
+    __shared__ double red[4];
     __shared__ double tot[GRAD_SLOTS];
-    const int lane = threadIdx.x;
-    for (int slot = 0; slot <= D; ++slot) {
-        double v = 0.0;
-        for (int b = lane; b < n_uf; b += 64) v += part_uf[(size_t)b * GRAD_SLOTS + slot];
-        for (int b = lane; b < n_uu; b += 64) v += part_uu[(size_t)b * GRAD_SLOTS + slot];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) tot[slot] = v;
+    const int tid = threadIdx.x;
+    double acc[GRAD_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < GRAD_SLOTS; ++sl) acc[sl] = 0.0;
+    for (int b = tid; b < n_uf; b += 256) {
+#pragma unroll
+        for (int sl = 0; sl < GRAD_SLOTS; ++sl)
+            if (sl <= D) acc[sl] += part_uf[(size_t)b * GRAD_SLOTS + sl];
+    }
+    for (int b = tid; b < n_uu; b += 256) {
+#pragma unroll
+        for (int sl = 0; sl < GRAD_SLOTS; ++sl)
+            if (sl <= D) acc[sl] += part_uu[(size_t)b * GRAD_SLOTS + sl];
+    }
+#pragma unroll
+    for (int sl = 0; sl < GRAD_SLOTS; ++sl) {
+        if (sl <= D) {                                   // uniform
+            const double v = block_sum(acc[sl], red);
+            if (tid == 0) tot[sl] = v;
+        }
     }
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
         const double hw = 0.5 * P->W[0];
         grad[0] = hw * (stats_scal[1] + tot[0] / P->sigma2);
         if (n_ell == 1) {
