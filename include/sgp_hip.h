@@ -180,7 +180,7 @@ enum { SGP_T_SWEEP = 0, SGP_T_GRAM = 1, SGP_T_SYRK = 2, SGP_T_FINISH1 = 3, SGP_T
        SGP_T_GAP_LOCAL_FINISH = 5, SGP_T_KUU = 6, SGP_T_LOCAL = 7, SGP_T_COUNT = 8 };
 int sgp_get_timestamps(sgp_handle* h, int64_t* out /* 2*SGP_T_COUNT */);
 /* Running totals of the per-sweep phase durations (same slots, 100 MHz ticks) over all sweeps since the last reset, and
- * the number of sweeps counted: the per-launch averages of the kernels INSIDE the timed graph replays. */
+ * the number of sweeps counted: the per-launch averages of the kernels INSIDE the timed sweeps. */
 int sgp_get_phase_totals(sgp_handle* h, int64_t* totals /* SGP_T_COUNT */, int64_t* count, int32_t reset);
 /* HIP-event timing of one data-sized kernel (which = SGP_T_GRAM or SGP_T_SYRK) launched eagerly `iters` times on
  * `stream` with the resident data of the last sweep; returns the average launch duration in microseconds. */
