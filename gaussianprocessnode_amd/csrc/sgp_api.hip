@@ -164,25 +164,31 @@ static void syrk_chunking(int ntiles, int num_cus, int* want, int* align) {
 // reading it from A.  Sacc (may be nullptr; needs Winv): collects Sigma = W^T W row by row during the steps
 // (sigma_row_tile); pass the same buffer to launch_ata, which then only adds the last block row.
 static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, double* scratch, hipStream_t s,
-                         double* Winv = nullptr, const LamForm* form = nullptr, double* Sacc = nullptr) {
+                         double* Winv = nullptr, const LamForm* form = nullptr, double* Sacc = nullptr,
+                         const double* tv_xi = nullptr, double* tv_t = nullptr) {
     LamForm none;
     memset(&none, 0, sizeof none);
-    // extra workgroups of launch j (j >= 2): finish block row j - 1 of W, pre-accumulate block row j (not in the last,
-    // potrf-free launch j = Tn), and -- with Sacc -- add block row j - 2's contribution to Sigma = W^T W
+    // extra workgroups of launch j: (j >= 2) finish block row j - 1 of W, pre-accumulate block row j (not in the last,
+    // potrf-free launch j = Tn), with Sacc add block row j - 2's contribution to Sigma = W^T W; (j >= 1, with tv_t) one
+    // workgroup computes block j - 1 of the forward solve t = W (P xi)
     auto extras = [&](int j) {
-        if (!Winv || j < 2) return 0;
-        int e = 2 * (j - 1) * (j < Tn ? 2 : 1);
-        if (Sacc) e += (j - 1) * j / 2;
+        if (!Winv) return 0;
+        int e = 0;
+        if (j >= 2) {
+            e += 2 * (j - 1) * (j < Tn ? 2 : 1);
+            if (Sacc) e += (j - 1) * j / 2;
+        }
+        if (tv_t && j >= 1) e += 1;
         return e;
     };
     for (int j = 0; j < Tn; ++j) {
         const int nt = Tn - j;
         hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + extras(j)), dim3(256), 0, s, A, ld, j, Tn, info, n_valid,
-                           scratch, Winv, Sacc, (j == 0 && form) ? *form : none);
+                           scratch, Winv, Sacc, tv_xi, tv_t, (j == 0 && form) ? *form : none);
     }
-    if (Winv && Tn >= 2)
+    if (Winv && extras(Tn) > 0)
         hipLaunchKernelGGL(k_potrf_step, dim3(extras(Tn)), dim3(256), 0, s, A, ld, Tn, Tn, info, n_valid, scratch, Winv, Sacc,
-                           none);
+                           tv_xi, tv_t, none);
 }
 // C = W^T W (rev: written index-reversed).  With mu: also R = C + mu mu^T, and with Psi2 the per-block shares of tr(R Psi2).
 static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s, int rev = 0, const double* mu = nullptr,
@@ -600,15 +606,15 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     form.stats = h->dStats; form.Lambda0 = h->dLambda0; form.xi0 = h->dXi0; form.xi = h->dXi; form.P = h->dParams;
     form.M = M; form.Mp = Mp; form.d_out = h->dout; form.Q = Q; form.prior_form = h->prior_form;
     form.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
-    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl, &form, h->dTmp);
+    double* uvt0 = h->dUvWork + 2 * (size_t)Qp;     // t = W' P xi, advanced block by block during the factorisation
+    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl, &form, h->dTmp, h->dXi, uvt0);
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
     // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
-    double* uvp = h->dXi;                    // xi is consumed by k_trmv_t; p lands in the same vector afterwards
+    double* uvp = h->dXi;                    // xi is consumed by the forward solve; p lands in the same vector afterwards
     double* uvck = h->dUvWork;               // C_kk
     double* uvak = h->dUvWork + Qp;          // p_k / sqrt(alpha_k alpha_{k+1})
-    double* uvt = h->dUvWork + 2 * (size_t)Qp;      // TQ x Qp tile contributions to t = W' P xi
+    double* uvt = uvt0;
     double* uvpart = uvt + (size_t)TQ * Qp;         // TQ x Qp tile partial sums
-    hipLaunchKernelGGL(k_trmv_t, dim3(TQ * (TQ + 1) / 2), dim3(256), 0, s, (const double*)h->dWl, (const double*)h->dXi, uvt, Qp);
     // mu, p, the alpha scan and (extra workgroups) pass 1 of Uv in one launch
     hipLaunchKernelGGL(k_trmv_mu_scan, dim3(Qp / 4 + 1 + TQ * (TQ + 1) / 2), dim3(256), 0, s, (const double*)h->dWl,
                        (const double*)uvt, h->dMu, uvp, uvck, uvak, uvpart, Qp);

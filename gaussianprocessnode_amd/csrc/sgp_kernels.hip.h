@@ -1053,9 +1053,44 @@ __device__ __forceinline__ void sigma_row_tile(const double* __restrict__ W, dou
     tile_s2g(tile, Sacc, ld, I * TB, J * TB);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The forward solve t = W (P xi) = L^-1 (P xi) rides along too (one workgroup per launch): block i of t is
+//   t_i = W_ii (xi'_i - sum_{k<i} L_ik t_k),   xi'_m = xi[ld - 1 - m],
+// computable one launch after step i (W_ii) -- so t is complete when the factorisation is, and mu = P W^T t (and p = P t for
+// the closed-form Uv) follow with ONE mat-vec launch instead of two.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tvec_role(const double* __restrict__ L, const double* __restrict__ W,
+                                          const double* __restrict__ xi, double* __restrict__ t, int ld, int i, double* lds) {
+    double* red = lds;                  // [4][64]
+    double* rvec = lds + 4 * TB;        // [64]
+    const int tid = threadIdx.x, r = tid & 63, part = tid >> 6;
+    double acc = 0.0;
+    for (int k = 0; k < i; ++k) {
+        const double* base = L + (size_t)(k * TB + 16 * part) * ld + i * TB + r;
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = base[(size_t)u * ld];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = fma(v[u], t[k * TB + 16 * part + u], acc);
+    }
+    red[part * TB + r] = acc;
+    __syncthreads();
+    if (part == 0) rvec[r] = xi[ld - 1 - (i * TB + r)] - ((red[r] + red[TB + r]) + (red[2 * TB + r] + red[3 * TB + r]));
+    __syncthreads();
+    const double* wb = W + (size_t)(i * TB + 16 * part) * ld + i * TB + r;       // W_ii: lower triangular, zeros above
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s = fma(wb[(size_t)u * ld], rvec[16 * part + u], s);
+    __syncthreads();
+    red[part * TB + r] = s;
+    __syncthreads();
+    if (part == 0) t[i * TB + r] = (red[r] + red[TB + r]) + (red[2 * TB + r] + red[3 * TB + r]);
+}
+
 __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
                                                     int n_valid, double* __restrict__ scratch, double* __restrict__ Winv,
-                                                    double* __restrict__ Sacc, LamForm form) {
+                                                    double* __restrict__ Sacc, const double* __restrict__ tv_xi,
+                                                    double* __restrict__ tv_t, LamForm form) {
     // LDS: two MFMA operand panels (2 x 64 x PS) and two 64 x 64 tiles.  The panels stay valid while the diagonal tile is
     // factored: the waves that idle during the pivot runs use them for the block's own rank-64 update.
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
@@ -1066,15 +1101,18 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     {
         const int npot = (Tn - j) * (Tn - j + 1) / 2;     // this step's own tiles; the workgroups beyond them work on
         if ((int)blockIdx.x >= npot) {                    // the inverse factor (winv_row_tile): finish block row j - 1,
-            int e = blockIdx.x - npot;                    // then pre-accumulate block row j; and Sigma = W^T W
-            const int nfin = 2 * (j - 1);                 // collects the contribution of block row j - 2 (sigma_row_tile)
-            const int npre = (j < Tn) ? nfin : 0;
+            int e = blockIdx.x - npot;                    // then pre-accumulate block row j; Sigma = W^T W collects the
+            const int nfin = (j >= 2) ? 2 * (j - 1) : 0;  // contribution of block row j - 2 (sigma_row_tile); and one
+            const int npre = (j < Tn) ? nfin : 0;         // workgroup advances the forward solve t = W (P xi) (tvec_role)
+            const int nsig = (Sacc && j >= 2) ? (j - 1) * j / 2 : 0;
             if (e < nfin) winv_row_tile(A, Winv, ld, j - 1, e >> 1, e & 1, lds, 2);
             else if (e < nfin + npre) { e -= nfin; winv_row_tile(A, Winv, ld, j, e >> 1, e & 1, lds, 1); }
-            else {
+            else if (e < nfin + npre + nsig) {
                 int I, J;
                 tile_from_index(e - nfin - npre, I, J);   // I >= J, I <= j - 2
                 sigma_row_tile(Winv, Sacc, ld, j - 2, I, J, lds, tiles);
+            } else {
+                tvec_role(A, Winv, tv_xi, tv_t, ld, j - 1, lds);
             }
             return;
         }
@@ -1393,7 +1431,7 @@ __global__ void __launch_bounds__(256) k_symv(const double* __restrict__ S, cons
 // it is accumulated directly, not as x_j minus a prefix).
 // p costs nothing extra: mu = Sigma xi = P W'^T W' P xi, so with t = W' (P xi) one has mu = P W'^T t and
 // p = P L'^T P mu = P L'^T W'^T t = P t.
-//   k_trmv_t       : t = W' (P xi)
+//   tvec_role      : t = W' (P xi), block by block during the factorisation
 //   k_trmv_mu_scan : mu = P W'^T t, p = P t, alpha scan -> C_kk and p_k / sqrt(alpha_k alpha_{k+1})
 //   k_uv_partial : per 64-row tile and column, sum_m p_m V[m][j]   (so that tiles can start their suffix sums independently)
 //   k_uv_cols    : one wave per 64 x 64 tile, 64 rows in registers, writes the rows of Uv
@@ -1402,45 +1440,15 @@ __global__ void __launch_bounds__(256) k_symv(const double* __restrict__ S, cons
 // ------------------------------------------------------------------------------------------------
 constexpr int CU_MAXQ = 4096;
 
-// t = W' (P xi): lower-triangular mat-vec.  One workgroup per 64 x 64 tile (I, kt), kt <= I, of W' -- every thread issues
-// its 16 loads at once (a whole row block per workgroup was latency-bound: 15 us) -- writing the tile's contribution
-// tpart[kt][64 I + r]; k_trmv_mu_scan adds the <= TQ contributions in a fixed order.
-// (W' column-major: a fixed column is contiguous over the rows, so the lanes walk rows and each wave owns 16 columns.)
-__global__ void __launch_bounds__(256) k_trmv_t(const double* __restrict__ W, const double* __restrict__ xi,
-                                                double* __restrict__ tpart, int Qp) {
-    __shared__ double red[4][64];
-    int I, kt;
-    tile_from_index(blockIdx.x, I, kt);                  // I >= kt
-    const int r = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int k0 = 64 * kt + 16 * part;                  // the strict upper part of a diagonal tile is stored as zeros
-    const double* base = W + (size_t)k0 * Qp + 64 * I + r;
-    double w[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) w[u] = base[(size_t)u * Qp];
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int u = 0; u < 16; u += 2) {
-        s0 = fma(w[u], xi[Qp - 1 - (k0 + u)], s0);
-        s1 = fma(w[u + 1], xi[Qp - 2 - (k0 + u)], s1);
-    }
-    red[part][r] = s0 + s1;
-    __syncthreads();
-    if (part == 0) tpart[(size_t)kt * Qp + 64 * I + r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
-}
-
 // mu = P W'^T t (one wave per column of W'), p = P t, and -- in the extra last workgroup -- the alpha scan of p:
 // ck[k] = C_kk, ak[k] = p_k / sqrt(alpha_k alpha_{k+1}).
-__global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__ W, const double* __restrict__ tpart,
+__global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__ W, const double* __restrict__ tpart /* t */,
                                                       double* __restrict__ mu, double* __restrict__ p,
                                                       double* __restrict__ ck, double* __restrict__ ak,
                                                       double* __restrict__ uvpart, int Qp) {
     __shared__ double ts[CU_MAXQ];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < Qp; i += 256) {        // t_i = sum of the tile contributions kt = 0 .. i / 64
-        double v = 0.0;
-        for (int kt = 0; kt <= (i >> 6); ++kt) v += tpart[(size_t)kt * Qp + i];
-        ts[i] = v;
-    }
+    for (int i = threadIdx.x; i < Qp; i += 256) ts[i] = tpart[i];     // t = W' (P xi), advanced block by block by tvec_role
     __syncthreads();
     if ((int)blockIdx.x > Qp / 4) {
         // workgroups beyond the mat-vec and the scan: pass 1 of Uv, one wave per 64 x 64 tile (kb <= jb) of V:
