@@ -837,7 +837,10 @@ __device__ __forceinline__ double lambda_entry(const LamForm& f, int gi, int gj,
     double prior, w;
     if constexpr (DENSE) prior = f.Lambda0[(size_t)sj * Qp + si]; else prior = diag * prior_iso;
     if constexpr (MULTI) w = f.P->W[a + b * f.d_out]; else w = w00;
-    return inside ? fma(w, psi, prior) : diag;
+    // arithmetic mask instead of a select on the loaded values: with `inside ? fma(w, psi, prior) : diag` the compiler sinks
+    // the loads into a per-entry branch (s_cbranch_execz + load + s_waitcnt vmcnt(0), sixteen times over) -- seen in the ISA
+    const double m = inside ? 1.0 : 0.0;
+    return fma(m * w, psi, fma(m, prior, (1.0 - m) * diag));
 }
 // tile (row0.., col0..) of P Lambda P: entry (r, c) is Lambda[Qp-1-r][Qp-1-c]
 template <bool DENSE, bool MULTI>
