@@ -282,7 +282,8 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dR, Qp * Qp);
     ALLOC(h->dTmp, Qp * Qp);
     ALLOC(h->dUvT, Qp * Qp);
-    ALLOC(h->dScratch, 3 * TB * TB);
+    ALLOC(h->dScratch, 9 * TB * TB);   // per factorisation chain: L_jj parking tile + two tiles of trsm_tile_next
+    hipMemset(h->dScratch, 0, sizeof(double) * 9 * TB * TB);   // (the unwritten upper tiles of those are read, never used)
     ALLOC(h->dOut2, SGP_R_COUNT);
     ALLOC(h->dUvWork, (2 + 2 * (size_t)h->TQ) * Qp);
     ALLOC(h->dLambda0, Qp * Qp);
@@ -506,7 +507,7 @@ extern "C" int sgp_set_prior(sgp_handle* h, const double* vec, const double* mat
     if (rc) return rc;
     hipStream_t s = h->own;
     HIPCHK(h, hipMemsetAsync(h->dInfo + 2, 0, sizeof(int), s));
-    launch_potrf(h->dTmp, h->Qp, h->TQ, h->dInfo + 2, h->Q, h->dScratch + 2 * TB * TB, s, h->dWl);
+    launch_potrf(h->dTmp, h->Qp, h->TQ, h->dInfo + 2, h->Q, h->dScratch + 6 * TB * TB, s, h->dWl);
     launch_ata(h->dWl, h->dLambda0, h->Qp, h->TQ, s);
     HIPCHK(h, hipMemcpyAsync(h->dMu, v.data(), Qp * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_symv, dim3((h->Qp + 3) / 4), dim3(256), 0, s, h->dLambda0, h->dMu, h->dXi0, h->Qp, h->Qp);
@@ -607,7 +608,7 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     form.M = M; form.Mp = Mp; form.d_out = h->dout; form.Q = Q; form.prior_form = h->prior_form;
     form.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
     double* uvt0 = h->dUvWork + 2 * (size_t)Qp;     // t = W' P xi, advanced block by block during the factorisation
-    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + TB * TB, s, h->dWl, &form, h->dTmp, h->dXi, uvt0);
+    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + 3 * TB * TB, s, h->dWl, &form, h->dTmp, h->dXi, uvt0);
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
     // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
     double* uvp = h->dXi;                    // xi is consumed by the forward solve; p lands in the same vector afterwards
@@ -1123,7 +1124,8 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
     HIPCHK(h, hipMemset(dInfo, 0, sizeof(int)));
     HIPCHK(h, hipMemcpy(dA, tmp.data(), sizeof(double) * np * np, hipMemcpyHostToDevice));
     double* dScr = nullptr;
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dScr), sizeof(double) * TB * TB));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dScr), sizeof(double) * 3 * TB * TB));
+    HIPCHK(h, hipMemset(dScr, 0, sizeof(double) * 3 * TB * TB));
     if (inverse) {
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dW), sizeof(double) * np * np));
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dC), sizeof(double) * np * np));

@@ -728,6 +728,96 @@ __device__ __forceinline__ void trsm_tile(double* X, const double* S, const doub
     });
 }
 
+// trsm_tile for the workgroup that owns tile (j + 1, j): while it solves X = L_{j+1,j}, the matrix cores (idle during the
+// pivot runs, which are bound by instruction issue) also form the NEXT diagonal tile's update  X X^T  -- one MFMA per pivot,
+// on the 16-column slice of X finished by the previous column block -- and the lower 16 x 16 tiles of it go to Dn (64 x 64,
+// column-major, ld 64).  Step j + 1 then subtracts Dn from A_{j+1,j+1} instead of recomputing the product in front of its
+// factorisation (64 MFMAs per wave on the critical path of every step).  Ten tiles over four waves: waves 0 and 3
+// (DIAGW) take (b,b), (b+1,b), (b+1,b+1) for b = 0, 2; waves 1 and 2 take (3,0),(3,1) and (2,0),(2,1).  The products are
+// formed transposed (A operand = the column tile) so that the stores run along Dn's columns.  One workgroup barrier per
+// column block (the slice must be complete in all 64 rows); every wave passes the same four barriers.
+template <bool DIAGW>
+__device__ __forceinline__ void trsm_tile_next(double* X, const double* S, const double* rinv, double* __restrict__ Dn) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = 16 * wave;
+    const int li = lane & 15, lk = lane >> 4;
+    const int rr = lane >> 2, q = lane & 3;
+    const int tb = (wave == 0) ? 0 : 2;                  // DIAGW: first tile of the diagonal pair
+    const int tR = (wave == 1) ? 3 : 2;                  // !DIAGW: the row tile
+    const double* p0 = X + ((DIAGW ? 16 * tb : 16 * tR) + li) * LT + lk;
+    const double* p1 = X + ((DIAGW ? 16 * (tb + 1) : 0) + li) * LT + lk;
+    const double* p2 = X + (16 + li) * LT + lk;
+    d4 g0 = (d4){0.0, 0.0, 0.0, 0.0}, g1 = g0, g2 = g0;
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    auto syrk_step = [&](auto sc, auto mc) {
+        constexpr int sl = decltype(sc)::value, m = decltype(mc)::value;
+        constexpr int per = DIAGW ? 3 : 2;
+        if constexpr (m < 4 * per) {
+            constexpr int off = 16 * sl + 4 * (m / per), t = m % per;
+            if constexpr (t == 0) {
+                x0 = p0[off];
+                x1 = p1[off];
+                if constexpr (!DIAGW) x2 = p2[off];
+            }
+            if constexpr (DIAGW) {
+                if constexpr (t == 0) g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, g0, 0, 0, 0);
+                else if constexpr (t == 1) g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, g1, 0, 0, 0);
+                else g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, g2, 0, 0, 0);
+            } else {
+                if constexpr (t == 0) g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, g0, 0, 0, 0);
+                else g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, x0, g1, 0, 0, 0);
+            }
+        }
+    };
+    static_for<4>([&](auto cbc) {
+        constexpr int cb = decltype(cbc)::value;
+        if constexpr (cb > 0) {
+            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+            const double* ap = X + (r0 + li) * LT + lk;
+            const double* bp = S + (16 * cb + li) * LT + lk;
+#pragma unroll
+            for (int s4 = 0; s4 < 4 * cb; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s4], bp[4 * s4], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= acc[r];
+        }
+        double x[4], xo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q]; xo[i] = 0.0; }
+        static_for<16>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int kq = k & 3, ki = k >> 2;
+            const double v = quad_bcast<kq>(x[ki]) * rinv[16 * cb + k];
+            if (q == kq) xo[ki] = v;
+#pragma unroll
+            for (int i = ki; i < 4; ++i) {
+                const int c = 4 * i + q;
+                double t = (c > k) ? S[(16 * cb + c) * LT + 16 * cb + k] : 0.0;
+                x[i] = fma(-v, t, x[i]);
+            }
+            if constexpr (cb > 0) syrk_step(std::integral_constant<int, cb - 1>{}, kc);
+        });
+#pragma unroll
+        for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = xo[i];
+        __syncthreads();
+    });
+    static_for<12>([&](auto mc) { syrk_step(std::integral_constant<int, 3>{}, mc); });
+    // value (row 16 R + li, column 16 C + lk + 4 r) of tile (R, C)
+    if constexpr (DIAGW) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Dn[(16 * tb + lk + 4 * r) * TB + 16 * tb + li] = g0[r];
+            Dn[(16 * tb + lk + 4 * r) * TB + 16 * (tb + 1) + li] = g1[r];
+            Dn[(16 * (tb + 1) + lk + 4 * r) * TB + 16 * (tb + 1) + li] = g2[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Dn[(lk + 4 * r) * TB + 16 * tR + li] = g0[r];
+            Dn[(16 + lk + 4 * r) * TB + 16 * tR + li] = g1[r];
+        }
+    }
+}
+
 // Invert the 64 x 64 lower-triangular tile S (LDS, S[r][c], stride LT; rinv[c] = 1 / L_cc) into Wt (LDS, same layout,
 // strict upper part zero).  Recursive doubling at 16-column granularity, like the matrix-level launch_trtri:
 //   (1) wave w inverts its own diagonal 16 x 16 block (4 lanes per row, right-to-left pivots, in registers, wave-local);
@@ -1127,16 +1217,20 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     double* P1 = lds + TB * PS;
     double* S = tiles;                                    // diagonal tile A_jj (panel column blocks only)
     double* X = tiles + TB * LT;                          // this block's own tile
-    Acc4 accX, accD;
+    Acc4 accX;
     acc_zero(accX);
-    acc_zero(accD);
     const bool panel = (b == 0);
+    // scratch: tile 0 parks L_jj; tiles 1 and 2 (alternating with the step's parity: a late workgroup of step j + 1 may
+    // still read one while step j + 1's owner of tile (j + 2, j + 1) writes the other) carry the next diagonal tile's
+    // update L_{j+1,j} L_{j+1,j}^T from the workgroup that solved L_{j+1,j} to the next launch (trsm_tile_next)
+    double* Dn_out = scratch + (size_t)(1 + (j & 1)) * TB * TB;
+    const double* Dn_in = scratch + (size_t)(2 - (j & 1)) * TB * TB;
     if (j > 0 && a == 0 && b == 0) {                      // move the previous step's L_{j-1,j-1} into place
         const int q0 = (j - 1) * TB;
         for (int e = tid; e < TB * TB; e += 256) A[(size_t)(q0 + (e >> 6)) * ld + q0 + (e & 63)] = scratch[e];
     }
     // the tiles this block updates are fetched into registers now, so that their latency hides behind the MFMA phase
-    TileRegs rX, rS;
+    TileRegs rX, rS, rD;
     if (j == 0 && form.stats) {
         // step 0 of the Lambda chain forms its tiles instead of loading them; the last workgroup also writes xi
         stamp_enter(form.stamps);
@@ -1162,19 +1256,17 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
         tile_g2r(rS, A, ld, j0, j0);
         if (a != 0) tile_g2r(rX, A, ld, i0, j0);
     }
-    if (j > 0) {
+    if (panel && j > 0) tile_g2r(rD, Dn_in, TB, 0, 0);    // the diagonal tile's rank-64 update, formed by the previous launch
+    if (j > 0 && !(panel && a == 0)) {
         const int p0 = (j - 1) * TB;
         load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
         if (a != b) load_panel_n(P1, A, ld, k0, p0, TB, tid);   // L_{k, j-1}
-        __syncthreads();
-        if (panel && a != 0) {
-            // redundantly, the diagonal tile's update (P1 P1^T); the block's own tile (P0 P1^T) waits for the idle slots
-            // of the factorisation below
-            tile_mma(accD, P1, P1, TB, lane, wr, wc);
-        } else {
+        if (!panel) {
+            __syncthreads();
             tile_mma(accX, P0, (a != b) ? P1 : P0, TB, lane, wr, wc);
             __syncthreads();
         }
+        // panel blocks: their own tile's update (P0 P1^T) waits for the idle slots of the factorisation below
     }
     if (!panel) {
         // plain trailing tile: A_ik -= acc, through LDS for coalesced global access
@@ -1185,10 +1277,12 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
         tile_s2g(X, A, ld, i0, k0);
         return;
     }
+    if (j > 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) rS.v[u] -= rD.v[u];
+    }
     tile_r2s(S, rS);
     if (a != 0) tile_r2s(X, rX);
-    __syncthreads();
-    tile_sub_acc(S, (a == 0) ? accX : accD, lane, wr, wc);
     __syncthreads();
     if (a != 0 && j > 0) {
         // K-slice s of the own-tile update: k in [16 s, 16 s + 16), this wave's 32 x 32 quadrant (16 MFMAs)
@@ -1225,8 +1319,13 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
         }
         return;
     }
-    trsm_tile(X, S, rinv);
-    __syncthreads();
+    if (a == 1) {
+        if (wave == 0 || wave == 3) trsm_tile_next<true>(X, S, rinv, Dn_out);
+        else trsm_tile_next<false>(X, S, rinv, Dn_out);
+    } else {
+        trsm_tile(X, S, rinv);
+        __syncthreads();
+    }
     tile_s2g(X, A, ld, i0, j0);
 }
 
