@@ -585,6 +585,33 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
     return y;
 }
 
+// One 16-pivot triangular solve  x D^T = b  for the lane's row (4 lanes per row, lane q holds columns q, q + 4, ...): D is
+// the 16 x 16 diagonal block at Dblk (LDS, stride LT), ri its reciprocal diagonal.  Everything the pivots need from LDS
+// (the 40 entries D[4 i + q][k], i >= k / 4, and the reciprocals) is fetched into registers BEFORE the loop, unconditionally:
+// with the reads inside it the compiler exec-masks each of them (~35 instructions and a wait per pivot, measured 166
+// cycles per pivot; the loop is bound by instruction issue).  The entries with 4 i + q <= k that come along are harmless:
+// they are zeros above the diagonal, or they touch column k of x, which is finished at pivot k.
+template <class F>
+__device__ __forceinline__ void solve16(double (&x)[4], double (&xo)[4], const double* Dblk, const double* ri, int q,
+                                        F&& per_pivot) {
+    double dk[16][4], rv[16];
+    static_for<16>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, ki = k >> 2;
+        rv[k] = ri[k];
+#pragma unroll
+        for (int i = ki; i < 4; ++i) dk[k][i] = Dblk[(4 * i + q) * LT + k];
+    });
+    static_for<16>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int kq = k & 3, ki = k >> 2;
+        const double v = quad_bcast<kq>(x[ki]) * rv[k];
+        if (q == kq) xo[ki] = v;
+#pragma unroll
+        for (int i = ki; i < 4; ++i) x[i] = fma(-v, dk[k][i], x[i]);
+        per_pivot(kc);
+    });
+}
+
 // Factor the 64 x 64 tile S (LDS, S[r][c], stride LT, lower part valid) in place: on exit S holds L (strict upper part
 // zero) and rinv[c] = 1 / L_cc.  colw: 16 doubles of LDS.  Blocked by 16 columns, wave w owns rows 16 w .. 16 w + 15:
 //   (1) every wave w >= cb subtracts the contribution of the block columns to the left from its 16 x 16 block (one MFMA
@@ -661,18 +688,7 @@ __device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv
             double x[4], xo[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { x[i] = S[(r0 + rr) * LT + 16 * cb + 4 * i + q]; xo[i] = 0.0; }
-            static_for<16>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                constexpr int kq = k & 3, ki = k >> 2;
-                const double v = quad_bcast<kq>(x[ki]) * rinv[16 * cb + k];
-                if (q == kq) xo[ki] = v;
-#pragma unroll
-                for (int i = ki; i < 4; ++i) {
-                    const int c = 4 * i + q;
-                    double t = (c > k) ? S[(16 * cb + c) * LT + 16 * cb + k] : 0.0;
-                    x[i] = fma(-v, t, x[i]);
-                }
-            });
+            solve16(x, xo, S + (16 * cb) * LT + 16 * cb, rinv + 16 * cb, q, [](auto) {});
 #pragma unroll
             for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = xo[i];
         } else if (wave < cb) {
@@ -700,29 +716,26 @@ __device__ __forceinline__ void trsm_tile(double* X, const double* S, const doub
     static_for<4>([&](auto cbc) {
         constexpr int cb = decltype(cbc)::value;
         if constexpr (cb > 0) {
-            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+            // four independent accumulators: a dependent v_mfma_f64 chain costs ~200 cycles per link, independent ones ~140
+            d4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
             const double* ap = X + (r0 + li) * LT + lk;              // A[i][k] = X[r0 + i][k]
             const double* bp = S + (16 * cb + li) * LT + lk;         // B[k][j] = L[16 cb + j][k]
+            double av[4 * cb], bv[4 * cb];                           // all operands first: one LDS latency, not one per pair
 #pragma unroll
-            for (int s4 = 0; s4 < 4 * cb; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s4], bp[4 * s4], acc, 0, 0, 0);
+            for (int s4 = 0; s4 < 4 * cb; ++s4) { av[s4] = ap[4 * s4]; bv[s4] = bp[4 * s4]; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= acc[r];
+            for (int s4 = 0; s4 < 4 * cb; ++s4)
+                acc[s4 & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc[s4 & 3], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
         }
         double x[4], xo[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q]; xo[i] = 0.0; }
-        static_for<16>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            constexpr int kq = k & 3, ki = k >> 2;
-            const double v = quad_bcast<kq>(x[ki]) * rinv[16 * cb + k];          // X_rk
-            if (q == kq) xo[ki] = v;
-#pragma unroll
-            for (int i = ki; i < 4; ++i) {
-                const int c = 4 * i + q;
-                double t = (c > k) ? S[(16 * cb + c) * LT + 16 * cb + k] : 0.0;    // L_ck inside the diagonal 16 x 16 block
-                x[i] = fma(-v, t, x[i]);
-            }
-        });
+        solve16(x, xo, S + (16 * cb) * LT + 16 * cb, rinv + 16 * cb, q, [](auto) {});
 #pragma unroll
         for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = xo[i];
     });
@@ -783,17 +796,7 @@ __device__ __forceinline__ void trsm_tile_next(double* X, const double* S, const
         double x[4], xo[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q]; xo[i] = 0.0; }
-        static_for<16>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            constexpr int kq = k & 3, ki = k >> 2;
-            const double v = quad_bcast<kq>(x[ki]) * rinv[16 * cb + k];
-            if (q == kq) xo[ki] = v;
-#pragma unroll
-            for (int i = ki; i < 4; ++i) {
-                const int c = 4 * i + q;
-                double t = (c > k) ? S[(16 * cb + c) * LT + 16 * cb + k] : 0.0;
-                x[i] = fma(-v, t, x[i]);
-            }
+        solve16(x, xo, S + (16 * cb) * LT + 16 * cb, rinv + 16 * cb, q, [&](auto kc) {
             if constexpr (cb > 0) syrk_step(std::integral_constant<int, cb - 1>{}, kc);
         });
 #pragma unroll
