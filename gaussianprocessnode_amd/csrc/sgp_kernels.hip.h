@@ -838,17 +838,21 @@ __device__ __forceinline__ void trtri_tile(const double* S, const double* rinv, 
         double w[4], wo[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { w[i] = (4 * i + q == rr) ? 1.0 : 0.0; wo[i] = 0.0; }
+        // operands into registers first, unconditionally (see solve16): L_kc for c = 4 i + q, i <= k / 4, and 1 / L_kk
+        double lk_[16][4], rv[16];
+        static_for<16>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, ki = k >> 2;
+            rv[k] = rinv[b0 + k];
+#pragma unroll
+            for (int i = 0; i <= ki; ++i) lk_[k][i] = S[(b0 + k) * LT + b0 + 4 * i + q];
+        });
         static_for<16>([&](auto kc) {
             constexpr int k = 15 - decltype(kc)::value;
             constexpr int kq = k & 3, ki = k >> 2;
-            const double v = quad_bcast<kq>(w[ki]) * rinv[b0 + k];               // W_rk (zero for k > r)
+            const double v = quad_bcast<kq>(w[ki]) * rv[k];                      // W_rk (zero for k > r)
             if (q == kq) wo[ki] = v;
 #pragma unroll
-            for (int i = 0; i <= ki; ++i) {
-                const int c = 4 * i + q;
-                double t = (c < k) ? S[(b0 + k) * LT + b0 + c] : 0.0;            // L_kc
-                w[i] = fma(-v, t, w[i]);
-            }
+            for (int i = 0; i <= ki; ++i) w[i] = fma(-v, lk_[k][i], w[i]);       // (c >= k: column k is finished, zeros above)
         });
 #pragma unroll
         for (int i = 0; i < 4; ++i) Wt[(b0 + rr) * LT + b0 + 4 * i + q] = wo[i];
@@ -1303,10 +1307,13 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
                 ap += 4 * PS; bp += 4 * PS;
             }
         };
-        // during the 16 pivots of column block cb the other three waves do slice cb; every wave then catches up on the one
-        // slice it missed (its own pivot run): 16 MFMAs on the critical path instead of 64
-        potf2_tile(S, colw, rinv, info, j0, n_valid, own_slice);
-        own_slice(wave);
+        // every wave idles during three of the four pivot runs: it does slices 0 and 1 in the first of them, then 2, then 3
+        // -- the whole rank-64 update of the block's own tile hides behind the factorisation
+        potf2_tile(S, colw, rinv, info, j0, n_valid, [&](int cb) {
+            const int ord = cb - (cb > wave ? 1 : 0);
+            if (ord == 0) { own_slice(0); own_slice(1); }
+            else own_slice(ord + 1);
+        });
         tile_sub_acc(X, accX, lane, wr, wc);
         __syncthreads();
     } else {
