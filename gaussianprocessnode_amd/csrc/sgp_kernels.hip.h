@@ -649,35 +649,45 @@ __device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv
                 a[i] = (c <= rr) ? S[(r0 + rr) * LT + 16 * cb + c] : 0.0;
                 lo[i] = 0.0;
             }
+            // The 16 pivots are one dependent chain (a dependent FP64 op costs ~20 cycles here), so the chain is kept as short
+            // as it can be: pivot -> v_rcp_f64 -> e = 1 - d r -> w = e + e^2 -> f = (v r)(1 + w) = a_rk / d (error e^3, i.e.
+            // rounding) -> rank-1 update -> next pivot.  1 / sqrt(d), the failure test and the stores hang off it sideways.
+            // A non-positive pivot is recorded (first one wins, reported after the run) and NOT patched: what follows it in
+            // the factor is then NaN / garbage, as LAPACK leaves it undefined.
+            int bad = 16;
+            double myri = 0.0;
             static_for<16>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 constexpr int kq = k & 3, ki = k >> 2;
                 double v = quad_bcast<kq>(a[ki]);
                 v = (rr >= k) ? v : 0.0;                      // rows above the pivot take no part
-                if (q == kq) colw[rr] = v;                    // pivot column (unnormalised), wave-local exchange
-                // the pivot itself comes straight from the owning lane (row k, quarter kq), so that 1/sqrt starts while the
-                // column is still on its way through LDS
-                double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[ki]), 4 * k + kq),
-                                            __builtin_amdgcn_readlane(__double2loint(a[ki]), 4 * k + kq));
-                // Scheduling fence: without it hipcc (ROCm 7.2) sinks the previous pivot's colw[] reads below this store
-                // (it defers their FMAs and the loads with them) and the update uses the NEXT pivot's column.  Verified
-                // on hardware with tools/tile_bench.hip: 4.8e-1 error without, 7e-16 with.
-                __builtin_amdgcn_wave_barrier();
-                if (!(d > 0.0)) {
-                    if (lane == 0 && col_base + 16 * cb + k < n_valid) atomicCAS(info, 0, col_base + 16 * cb + k + 1);
-                    d = 1.0;
-                }
-                const double ri = rsqrt_nr(d);
-                const double f = v * (ri * ri);               // a_rk / d
-                if (q == kq) lo[ki] = v * ri;                 // L_rk
-                if (lane == 0) rinv[16 * cb + k] = ri;
+                // the pivot column's entries A[4 i + q][k] that this lane's columns need sit in register a[ki] of lane
+                // 4 (4 i + q) + kq: fetched with ds_bpermute (one trip through the LDS crossbar, no memory) -- the exchange
+                // through an LDS vector (store, then load) was the longest thing in the pivot's dependent chain.  Entries
+                // of finished columns (4 i + q <= k) receive garbage updates; nothing reads them again.
+                double y[4];
 #pragma unroll
                 for (int i = ki; i < 4; ++i) {
-                    const int c = 4 * i + q;
-                    double t = (c > k) ? colw[c] : 0.0;
-                    a[i] = fma(-f, t, a[i]);
+                    const int src = 4 * (4 * (4 * i + q) + kq);
+                    y[i] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(a[ki])),
+                                            __builtin_amdgcn_ds_bpermute(src, __double2loint(a[ki])));
                 }
+                const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[ki]), 4 * k + kq),
+                                                  __builtin_amdgcn_readlane(__double2loint(a[ki]), 4 * k + kq));
+                bad = (!(d > 0.0) && bad == 16) ? k : bad;
+                const double r = __builtin_amdgcn_rcp(d);
+                const double e = fma(-d, r, 1.0);
+                const double w = fma(e, e, e);
+                const double vr = v * r;
+                const double f = fma(vr, w, vr);              // a_rk / d
+                const double ri = rsqrt_nr(d);
+                if (q == kq) lo[ki] = v * ri;                 // L_rk
+                myri = (lane == k) ? ri : myri;
+#pragma unroll
+                for (int i = ki; i < 4; ++i) a[i] = fma(-f, y[i], a[i]);
             });
+            if (lane < 16) rinv[16 * cb + lane] = myri;
+            if (bad < 16 && lane == 0 && col_base + 16 * cb + bad < n_valid) atomicCAS(info, 0, col_base + 16 * cb + bad + 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = lo[i];
         } else {
