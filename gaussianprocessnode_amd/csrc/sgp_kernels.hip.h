@@ -564,6 +564,16 @@ __device__ __forceinline__ double quad_bcast(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// lane N of each 16-lane DPP row to the whole row (row_newbcast)
+template <int N>
+__device__ __forceinline__ double row_bcast(double v) {
+    constexpr int ctrl = 0x150 + N;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 template <typename F, int... Is>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
     (f(std::integral_constant<int, Is>{}), ...);
@@ -642,54 +652,59 @@ __device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv
             }
         }
         if (wave == cb) {
+            // Pivot-phase coordinates: lane = 16 pq + pr holds row pr, columns 4 i + pq -- of the FULL symmetric block, so
+            // that the pivot ROW (the same numbers as the pivot column) is where a DPP row broadcast can reach it.
+            const int pr = lane & 15, pq = lane >> 4;
             double a[4], lo[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                int c = 4 * i + q;
-                a[i] = (c <= rr) ? S[(r0 + rr) * LT + 16 * cb + c] : 0.0;
+                const int c = 4 * i + pq;
+                a[i] = (c <= pr) ? S[(r0 + pr) * LT + 16 * cb + c] : S[(r0 + c) * LT + 16 * cb + pr];
                 lo[i] = 0.0;
             }
-            // The 16 pivots are one dependent chain (a dependent FP64 op costs ~20 cycles here), so the chain is kept as short
-            // as it can be: pivot -> v_rcp_f64 -> e = 1 - d r -> w = e + e^2 -> f = (v r)(1 + w) = a_rk / d (error e^3, i.e.
-            // rounding) -> rank-1 update -> next pivot.  1 / sqrt(d), the failure test and the stores hang off it sideways.
-            // A non-positive pivot is recorded (first one wins, reported after the run) and NOT patched: what follows it in
-            // the factor is then NaN / garbage, as LAPACK leaves it undefined.
-            int bad = 16;
-            double myri = 0.0;
+            // The loop is bound by what this one wave can issue (~7 cycles per instruction) and by the LDS crossbar
+            // (ds_bpermute: ~75 cycles, DPP: ~14), so everything that can wait does: the column is kept unnormalised (lo),
+            // lane k keeps pivot k, and 1 / sqrt(d), the scaling of the columns and the failure test happen once after the
+            // 16 pivots, for all of them in parallel.  On the dependent chain: pivot -> v_rcp_f64 -> e = 1 - d r ->
+            // w = e + e^2 -> f = (x r)(1 + w) = A[pr][k] / d (error e^3, i.e. rounding) -> rank-1 update -> next pivot.
+            // A non-positive pivot is reported and NOT patched: what follows it in the factor is NaN / garbage (LAPACK
+            // leaves it undefined).  Finished columns and the rows above the pivot receive garbage updates; nothing reads
+            // them again.
+            double dsave = 1.0;
             static_for<16>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 constexpr int kq = k & 3, ki = k >> 2;
-                double v = quad_bcast<kq>(a[ki]);
-                v = (rr >= k) ? v : 0.0;                      // rows above the pivot take no part
-                // the pivot column's entries A[4 i + q][k] that this lane's columns need sit in register a[ki] of lane
-                // 4 (4 i + q) + kq: fetched with ds_bpermute (one trip through the LDS crossbar, no memory) -- the exchange
-                // through an LDS vector (store, then load) was the longest thing in the pivot's dependent chain.  Entries
-                // of finished columns (4 i + q <= k) receive garbage updates; nothing reads them again.
+                // A[k][4 i + pq]: register a[i] of lane (pq, k) -- lane k of this lane's own DPP row
                 double y[4];
 #pragma unroll
-                for (int i = ki; i < 4; ++i) {
-                    const int src = 4 * (4 * (4 * i + q) + kq);
-                    y[i] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(a[ki])),
-                                            __builtin_amdgcn_ds_bpermute(src, __double2loint(a[ki])));
-                }
-                const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[ki]), 4 * k + kq),
-                                                  __builtin_amdgcn_readlane(__double2loint(a[ki]), 4 * k + kq));
-                bad = (!(d > 0.0) && bad == 16) ? k : bad;
+                for (int i = ki; i < 4; ++i) y[i] = row_bcast<k>(a[i]);
+                // A[pr][k]: register a[ki] of lane (kq, pr) -- another DPP row, through the LDS crossbar
+                // (v_permlane32_swap + v_permlane16_swap can do this without LDS, but measured slower: 9.0 vs 7.6 us per tile)
+                const int src = 4 * (16 * kq + pr);
+                const double x = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(a[ki])),
+                                                  __builtin_amdgcn_ds_bpermute(src, __double2loint(a[ki])));
+                const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[ki]), 16 * kq + k),
+                                                  __builtin_amdgcn_readlane(__double2loint(a[ki]), 16 * kq + k));
+                dsave = (lane == k) ? d : dsave;
                 const double r = __builtin_amdgcn_rcp(d);
                 const double e = fma(-d, r, 1.0);
                 const double w = fma(e, e, e);
-                const double vr = v * r;
-                const double f = fma(vr, w, vr);              // a_rk / d
-                const double ri = rsqrt_nr(d);
-                if (q == kq) lo[ki] = v * ri;                 // L_rk
-                myri = (lane == k) ? ri : myri;
+                const double xr = x * r;
+                const double f = fma(xr, w, xr);
+                lo[ki] = (pq == kq && pr >= k) ? x : lo[ki];  // L[pr][k] sqrt(d_k); rows above the pivot stay zero
 #pragma unroll
                 for (int i = ki; i < 4; ++i) a[i] = fma(-f, y[i], a[i]);
             });
-            if (lane < 16) rinv[16 * cb + lane] = myri;
-            if (bad < 16 && lane == 0 && col_base + 16 * cb + bad < n_valid) atomicCAS(info, 0, col_base + 16 * cb + bad + 1);
+            const unsigned long long failed = __ballot(lane < 16 && !(dsave > 0.0));
+            if (failed != 0ull && lane == 0) {
+                const int bad = __builtin_ctzll(failed);
+                if (col_base + 16 * cb + bad < n_valid) atomicCAS(info, 0, col_base + 16 * cb + bad + 1);
+            }
+            const double ri = rsqrt_nr(dsave);
+            if (lane < 16) rinv[16 * cb + lane] = ri;
+            __builtin_amdgcn_wave_barrier();                  // (same wave: the LDS queue keeps the order; this keeps the compiler's)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = lo[i];
+            for (int i = 0; i < 4; ++i) S[(r0 + pr) * LT + 16 * cb + 4 * i + pq] = lo[i] * rinv[16 * cb + 4 * i + pq];
         } else {
             idle_work(cb);                                // three waves have nothing to do during these 16 pivots
         }
