@@ -595,27 +595,29 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
     return y;
 }
 
-// One 16-pivot triangular solve  x D^T = b  for the lane's row (4 lanes per row, lane q holds columns q, q + 4, ...): D is
-// the 16 x 16 diagonal block at Dblk (LDS, stride LT), ri its reciprocal diagonal.  Everything the pivots need from LDS
-// (the 40 entries D[4 i + q][k], i >= k / 4, and the reciprocals) is fetched into registers BEFORE the loop, unconditionally:
-// with the reads inside it the compiler exec-masks each of them (~35 instructions and a wait per pivot, measured 166
-// cycles per pivot; the loop is bound by instruction issue).  The entries with 4 i + q <= k that come along are harmless:
-// they are zeros above the diagonal, or they touch column k of x, which is finished at pivot k.
+// One 16-pivot triangular solve  x D^T = b  for the lane's row (4 lanes per row, lane q holds columns q, q + 4, ...), in the
+// scaled form z_c = x_c / D_cc:  z_c <- (b_c / D_cc) - sum_{k < c} z_k (D_ck / D_cc), so that a pivot is one quad broadcast
+// and the FMAs -- no multiply by the reciprocal and no select on its dependent chain.  Dp (LDS, DPS doubles per row) is the
+// block prepared by potf2_tile: Dp[c][k] = D_ck / D_cc below the diagonal, ZERO on and above it (so the reads need no
+// masks: finished columns are left alone); ri = 1 / diag(D).  All operands are fetched into registers before the loop: with
+// the reads inside it the compiler exec-masks each of them (~35 instructions and a wait per pivot, the loop is bound by
+// instruction issue).  On exit x holds the solution.
+constexpr int DPS = 17;             // row stride of a prepared 16 x 16 block (odd: the four rows a quad reads differ in bank)
+constexpr int DPB = 16 * DPS;       // doubles per block
 template <class F>
-__device__ __forceinline__ void solve16(double (&x)[4], double (&xo)[4], const double* Dblk, const double* ri, int q,
-                                        F&& per_pivot) {
-    double dk[16][4], rv[16];
+__device__ __forceinline__ void solve16(double (&x)[4], const double* Dp, const double* ri, int q, F&& per_pivot) {
+    double dk[16][4];
     static_for<16>([&](auto kc) {
         constexpr int k = decltype(kc)::value, ki = k >> 2;
-        rv[k] = ri[k];
 #pragma unroll
-        for (int i = ki; i < 4; ++i) dk[k][i] = Dblk[(4 * i + q) * LT + k];
+        for (int i = ki; i < 4; ++i) dk[k][i] = Dp[(4 * i + q) * DPS + k];
     });
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] *= ri[4 * i + q];
     static_for<16>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int kq = k & 3, ki = k >> 2;
-        const double v = quad_bcast<kq>(x[ki]) * rv[k];
-        if (q == kq) xo[ki] = v;
+        const double v = quad_bcast<kq>(x[ki]);
 #pragma unroll
         for (int i = ki; i < 4; ++i) x[i] = fma(-v, dk[k][i], x[i]);
         per_pivot(kc);
@@ -623,16 +625,17 @@ __device__ __forceinline__ void solve16(double (&x)[4], double (&xo)[4], const d
 }
 
 // Factor the 64 x 64 tile S (LDS, S[r][c], stride LT, lower part valid) in place: on exit S holds L (strict upper part
-// zero) and rinv[c] = 1 / L_cc.  colw: 16 doubles of LDS.  Blocked by 16 columns, wave w owns rows 16 w .. 16 w + 15:
+// zero), rinv[c] = 1 / L_cc and Dp (4 DPB doubles of LDS) the four diagonal 16 x 16 blocks in the form solve16 reads.
+// Blocked by 16 columns, wave w owns rows 16 w .. 16 w + 15:
 //   (1) every wave w >= cb subtracts the contribution of the block columns to the left from its 16 x 16 block (one MFMA
 //       product, K = 16 cb, wave-local);
-//   (2) wave cb factors its diagonal 16 x 16 block: 4 lanes per row, entries in registers, the pivot column exchanged
-//       through a 16-entry LDS vector -- all inside ONE wave, so the 16 pivots need no workgroup barrier;
+//   (2) wave cb factors its diagonal 16 x 16 block: entries in registers, the pivot row / column exchanged by DPP row
+//       broadcast and ds_bpermute -- all inside ONE wave, so the 16 pivots need no workgroup barrier;
 //   (3) after a barrier the waves below solve their 16 x 16 block against it (rows independent, in registers).
 // Two workgroup barriers per 16 pivots instead of one per pivot.  `idle_work(cb)` is called by the three waves that wait
 // while wave cb runs its 16 pivots (k_potrf_step gives them a slice of the block's own rank-64 update).
 template <class IdleWork>
-__device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv, int* info, int col_base, int n_valid,
+__device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, int* info, int col_base, int n_valid,
                                            IdleWork&& idle_work) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = 16 * wave;
@@ -703,19 +706,25 @@ __device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv
             const double ri = rsqrt_nr(dsave);
             if (lane < 16) rinv[16 * cb + lane] = ri;
             __builtin_amdgcn_wave_barrier();                  // (same wave: the LDS queue keeps the order; this keeps the compiler's)
+            const double rrow = rinv[16 * cb + pr];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) S[(r0 + pr) * LT + 16 * cb + 4 * i + pq] = lo[i] * rinv[16 * cb + 4 * i + pq];
+            for (int i = 0; i < 4; ++i) {
+                const int c = 4 * i + pq;
+                const double l = lo[i] * rinv[16 * cb + c];
+                S[(r0 + pr) * LT + 16 * cb + c] = l;
+                Dp[cb * DPB + pr * DPS + c] = (c < pr) ? l * rrow : 0.0;
+            }
         } else {
             idle_work(cb);                                // three waves have nothing to do during these 16 pivots
         }
         __syncthreads();
         if (wave > cb) {
-            double x[4], xo[4];
+            double x[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { x[i] = S[(r0 + rr) * LT + 16 * cb + 4 * i + q]; xo[i] = 0.0; }
-            solve16(x, xo, S + (16 * cb) * LT + 16 * cb, rinv + 16 * cb, q, [](auto) {});
+            for (int i = 0; i < 4; ++i) x[i] = S[(r0 + rr) * LT + 16 * cb + 4 * i + q];
+            solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [](auto) {});
 #pragma unroll
-            for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = xo[i];
+            for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
         } else if (wave < cb) {
             // rows of finished waves: the strict upper part of this block column is zero
 #pragma unroll
@@ -725,15 +734,15 @@ __device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv
     });
 }
 
-__device__ __forceinline__ void potf2_tile(double* S, double* colw, double* rinv, int* info, int col_base, int n_valid) {
-    potf2_tile(S, colw, rinv, info, col_base, n_valid, [](int) {});
+__device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, int* info, int col_base, int n_valid) {
+    potf2_tile(S, Dp, rinv, info, col_base, n_valid, [](int) {});
 }
 
 // Solve X L^T = B in place: X (LDS tile, stride LT) holds B on entry and X on exit; S holds L (normal layout, as written
-// by potf2_tile with Lp == nullptr), rinv = 1 / diag(L).  Blocked by 16 columns and entirely WAVE-LOCAL (wave w owns rows
+// by potf2_tile, with Dp and rinv), rinv = 1 / diag(L).  Blocked by 16 columns and entirely WAVE-LOCAL (wave w owns rows
 // 16 w .. 16 w + 15, no workgroup barrier): for each 16-column block the contribution of the blocks to its left is one
 // MFMA product per wave (K = 16 cb), the 16 x 16 triangle is then solved with 4 lanes per row in registers.
-__device__ __forceinline__ void trsm_tile(double* X, const double* S, const double* rinv) {
+__device__ __forceinline__ void trsm_tile(double* X, const double* S, const double* Dp, const double* rinv) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = 16 * wave;
     const int li = lane & 15, lk = lane >> 4;            // MFMA operand coordinates
@@ -757,12 +766,12 @@ __device__ __forceinline__ void trsm_tile(double* X, const double* S, const doub
             for (int r = 0; r < 4; ++r)
                 X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
         }
-        double x[4], xo[4];
+        double x[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q]; xo[i] = 0.0; }
-        solve16(x, xo, S + (16 * cb) * LT + 16 * cb, rinv + 16 * cb, q, [](auto) {});
+        for (int i = 0; i < 4; ++i) x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q];
+        solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [](auto) {});
 #pragma unroll
-        for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = xo[i];
+        for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
     });
 }
 
@@ -775,7 +784,8 @@ __device__ __forceinline__ void trsm_tile(double* X, const double* S, const doub
 // formed transposed (A operand = the column tile) so that the stores run along Dn's columns.  One workgroup barrier per
 // column block (the slice must be complete in all 64 rows); every wave passes the same four barriers.
 template <bool DIAGW>
-__device__ __forceinline__ void trsm_tile_next(double* X, const double* S, const double* rinv, double* __restrict__ Dn) {
+__device__ __forceinline__ void trsm_tile_next(double* X, const double* S, const double* Dp, const double* rinv,
+                                               double* __restrict__ Dn) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = 16 * wave;
     const int li = lane & 15, lk = lane >> 4;
@@ -818,14 +828,14 @@ __device__ __forceinline__ void trsm_tile_next(double* X, const double* S, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= acc[r];
         }
-        double x[4], xo[4];
+        double x[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q]; xo[i] = 0.0; }
-        solve16(x, xo, S + (16 * cb) * LT + 16 * cb, rinv + 16 * cb, q, [&](auto kc) {
+        for (int i = 0; i < 4; ++i) x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q];
+        solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [&](auto kc) {
             if constexpr (cb > 0) syrk_step(std::integral_constant<int, cb - 1>{}, kc);
         });
 #pragma unroll
-        for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = xo[i];
+        for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
         __syncthreads();
     });
     static_for<12>([&](auto mc) { syrk_step(std::integral_constant<int, 3>{}, mc); });
@@ -1220,7 +1230,7 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     // factored: the waves that idle during the pivot runs use them for the block's own rank-64 update.
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
     __shared__ __attribute__((aligned(16))) double tiles[2 * TB * LT];
-    __shared__ double colw[16];
+    __shared__ double dprep[4 * DPB];                     // the diagonal tile's 16 x 16 blocks as solve16 reads them
     __shared__ double rinv[TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     {
@@ -1334,7 +1344,7 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
         };
         // every wave idles during three of the four pivot runs: it does slices 0 and 1 in the first of them, then 2, then 3
         // -- the whole rank-64 update of the block's own tile hides behind the factorisation
-        potf2_tile(S, colw, rinv, info, j0, n_valid, [&](int cb) {
+        potf2_tile(S, dprep, rinv, info, j0, n_valid, [&](int cb) {
             const int ord = cb - (cb > wave ? 1 : 0);
             if (ord == 0) { own_slice(0); own_slice(1); }
             else own_slice(ord + 1);
@@ -1342,7 +1352,7 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
         tile_sub_acc(X, accX, lane, wr, wc);
         __syncthreads();
     } else {
-        potf2_tile(S, colw, rinv, info, j0, n_valid);
+        potf2_tile(S, dprep, rinv, info, j0, n_valid);
     }
     if (a == 0) {
         if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);       // no other block reads A_jj in the last step
@@ -1355,10 +1365,10 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
         return;
     }
     if (a == 1) {
-        if (wave == 0 || wave == 3) trsm_tile_next<true>(X, S, rinv, Dn_out);
-        else trsm_tile_next<false>(X, S, rinv, Dn_out);
+        if (wave == 0 || wave == 3) trsm_tile_next<true>(X, S, dprep, rinv, Dn_out);
+        else trsm_tile_next<false>(X, S, dprep, rinv, Dn_out);
     } else {
-        trsm_tile(X, S, rinv);
+        trsm_tile(X, S, dprep, rinv);
         __syncthreads();
     }
     tile_s2g(X, A, ld, i0, j0);

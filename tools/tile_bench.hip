@@ -10,7 +10,7 @@ using namespace sgp;
 
 __global__ void __launch_bounds__(256) k_potf2_only(double* A, int ld, int reps, int* info) {
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
-    __shared__ double colp[16];
+    __shared__ double colp[4 * DPB];
     __shared__ double rinv[TB];
     for (int it = 0; it < reps; ++it) {
         tile_g2s(lds, A, ld, 0, 0);
@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(256) k_potf2_only(double* A, int ld, int reps,
 }
 __global__ void __launch_bounds__(256) k_trsm_only(double* A, int ld, int reps, int* info) {
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
-    __shared__ double colp[16];
+    __shared__ double colp[4 * DPB];
     __shared__ double rinv[TB];
     tile_g2s(lds, A, ld, 0, 0);
     __syncthreads();
@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) k_trsm_only(double* A, int ld, int reps, 
     for (int it = 0; it < reps; ++it) {
         tile_g2s(X, A, ld, 0, 0);
         __syncthreads();
-        trsm_tile(X, lds, rinv);
+        trsm_tile(X, lds, colp, rinv);
         __syncthreads();
     }
     tile_s2g(X, A + 64 * 64, ld, 0, 0);
