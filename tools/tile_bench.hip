@@ -35,6 +35,21 @@ __global__ void __launch_bounds__(256) k_trsm_only(double* A, int ld, int reps, 
     }
     tile_s2g(X, A + 64 * 64, ld, 0, 0);
 }
+__global__ void __launch_bounds__(256) k_trtri_only(double* A, int ld, int reps, int* info) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
+    __shared__ double work[32 * 33];
+    __shared__ double colp[4 * DPB];
+    __shared__ double rinv[TB];
+    tile_g2s(lds, A, ld, 0, 0);
+    __syncthreads();
+    potf2_tile(lds, colp, rinv, info, 0, 64);
+    double* X = lds + TB * LT;
+    for (int it = 0; it < reps; ++it) {
+        trtri_tile(lds, rinv, X, work);
+        __syncthreads();
+    }
+    tile_s2g(X, A + 64 * 64, ld, 0, 0);
+}
 __global__ void __launch_bounds__(256) k_copy_only(double* A, int ld, int reps) {
     __shared__ double lds[2 * TB * PS];
     for (int it = 0; it < reps; ++it) {
@@ -62,6 +77,7 @@ int main() {
     run("copy g2s only", [&] { k_copy_only<<<1, 256>>>(dA, n, reps); });
     run("potf2_tile (+copy)", [&] { k_potf2_only<<<1, 256>>>(dA, n, reps, dInfo); });
     run("trsm_tile (+copy)", [&] { k_trsm_only<<<1, 256>>>(dA, n, reps, dInfo); });
+    run("trtri_tile", [&] { k_trtri_only<<<1, 256>>>(dA, n, reps, dInfo); });
     // validation of potf2_tile against a host Cholesky
     {
         CK(hipMemset(dInfo, 0, 4));
