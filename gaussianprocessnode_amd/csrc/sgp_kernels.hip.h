@@ -1408,13 +1408,30 @@ __device__ __forceinline__ void uv_cols_role(const UvArgs& u, int Qp, int kb, in
     }
     double v[64];
     load_v_column(v, u.Wp, Qp, kb, j);
+    // rows below this tile, nearest first (fixed order).  Eight loads in flight per pass, unconditional (clamped index, the
+    // surplus multiplied away): with a load per loop trip this one wave waited out up to Tn - 1 memory latencies in a row
+    // and held the whole Sigma launch at 13 us (its product workgroups need 5).
     double T = 0.0;
-    for (int b = jb; b > kb; --b) T += u.partial[(size_t)b * Qp + j];     // rows below this tile, nearest first: fixed order
+    for (int b0 = jb; b0 > kb; b0 -= 8) {
+        double pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int b = b0 - e;
+            pv[e] = u.partial[(size_t)max(b, kb + 1) * Qp + j] * ((b > kb) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) T += pv[e];
+    }
+    // the tile's 64 coefficients: one coalesced load each (lane kk holds row 64 kb + kk's), handed out with v_readlane --
+    // as uniform loads inside the loop they were 192 scalar loads whose latencies this single wave sat out one after another
+    const double ckl = u.ck[64 * kb + lane], akl = u.ak[64 * kb + lane], pl = u.p[64 * kb + lane];
+    auto lane_value = [](double x, int src) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src), __builtin_amdgcn_readlane(__double2loint(x), src));
+    };
 #pragma unroll
     for (int kk = 63; kk >= 0; --kk) {
-        const int k = 64 * kb + kk;
-        out[(size_t)kk * Qp] = fma(u.ck[k], v[kk], u.ak[k] * T);
-        T = fma(u.p[k], v[kk], T);
+        out[(size_t)kk * Qp] = fma(lane_value(ckl, kk), v[kk], lane_value(akl, kk) * T);
+        T = fma(lane_value(pl, kk), v[kk], T);
     }
     stamp_exit(u.stamps);
 }
