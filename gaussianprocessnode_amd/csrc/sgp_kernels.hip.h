@@ -634,9 +634,11 @@ __device__ __forceinline__ void solve16(double (&x)[4], const double* Dp, const 
 //   (3) after a barrier the waves below solve their 16 x 16 block against it (rows independent, in registers).
 // Two workgroup barriers per 16 pivots instead of one per pivot.  `idle_work(cb)` is called by the three waves that wait
 // while wave cb runs its 16 pivots (k_potrf_step gives them a slice of the block's own rank-64 update).
-template <class IdleWork>
+// `solve_hook(cb, k)` is called once per pivot by the waves that solve below block cb, `solve_idle(cb)` by wave cb, which
+// waits there.
+template <class IdleWork, class SolveHook, class SolveIdle>
 __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, int* info, int col_base, int n_valid,
-                                           IdleWork&& idle_work) {
+                                           IdleWork&& idle_work, SolveHook&& solve_hook, SolveIdle&& solve_idle) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = 16 * wave;
     const int li = lane & 15, lk = lane >> 4;
@@ -722,10 +724,12 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
             double x[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = S[(r0 + rr) * LT + 16 * cb + 4 * i + q];
-            solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [](auto) {});
+            solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [&](auto kc) { solve_hook(cbc, kc); });
 #pragma unroll
             for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
-        } else if (wave < cb) {
+        } else if (wave == cb) {
+            solve_idle(cbc);
+        } else {
             // rows of finished waves: the strict upper part of this block column is zero
 #pragma unroll
             for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = 0.0;
@@ -735,7 +739,7 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
 }
 
 __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, int* info, int col_base, int n_valid) {
-    potf2_tile(S, Dp, rinv, info, col_base, n_valid, [](int) {});
+    potf2_tile(S, Dp, rinv, info, col_base, n_valid, [](int) {}, [](auto, auto) {}, [](auto) {});
 }
 
 // Solve X L^T = B in place: X (LDS tile, stride LT) holds B on entry and X on exit; S holds L (normal layout, as written
@@ -936,11 +940,15 @@ __device__ __forceinline__ void trtri_tile(const double* S, const double* rinv, 
 
 // coalesced copies between a column-major global tile and an LDS tile S[r][c]
 struct TileRegs { double v[16]; };
+// register u of thread tid holds element (r, c) = (2 (e & 31) + (u & 1), e >> 5), e = tid + 256 (u >> 1): two consecutive
+// rows per thread, so that a tile is 8 sixteen-byte loads per thread instead of 16 eight-byte ones
 __device__ __forceinline__ void tile_g2r(TileRegs& t, const double* __restrict__ A, size_t ld, int row0, int col0) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        int e = threadIdx.x + 256 * u, c = e >> 6, r = e & 63;
-        t.v[u] = A[(size_t)(col0 + c) * ld + row0 + r];
+    for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + 256 * u, c = e >> 5, r = (e & 31) * 2;
+        const double2 w = *reinterpret_cast<const double2*>(A + (size_t)(col0 + c) * ld + row0 + r);
+        t.v[2 * u] = w.x;
+        t.v[2 * u + 1] = w.y;
     }
 }
 // Lambda = Lambda0 + W (x) Psi2 in index-reversed order, evaluated on the fly: step 0 of the Lambda factorisation reads its
@@ -980,7 +988,7 @@ __device__ __forceinline__ void tile_form_r_impl(TileRegs& t, const LamForm& f, 
     const double prior_iso = f.P->prior_iso, w00 = f.P->W[0];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        int e = threadIdx.x + 256 * u, c = e >> 6, r = e & 63;
+        const int e = threadIdx.x + 256 * (u >> 1), c = e >> 5, r = (e & 31) * 2 + (u & 1);      // the layout of tile_g2r
         t.v[u] = lambda_entry<DENSE, MULTI>(f, Qp - 1 - (row0 + r), Qp - 1 - (col0 + c), Qp, prior_iso, w00);
     }
 }
@@ -992,7 +1000,7 @@ __device__ __forceinline__ void tile_form_r(TileRegs& t, const LamForm& f, int Q
 __device__ __forceinline__ void tile_r2s(double* S, const TileRegs& t) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        int e = threadIdx.x + 256 * u, c = e >> 6, r = e & 63;
+        const int e = threadIdx.x + 256 * (u >> 1), c = e >> 5, r = (e & 31) * 2 + (u & 1);
         S[r * LT + c] = t.v[u];
     }
 }
@@ -1343,12 +1351,14 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
             }
         };
         // every wave idles during three of the four pivot runs: it does slices 0 and 1 in the first of them, then 2, then 3
-        // -- the whole rank-64 update of the block's own tile hides behind the factorisation
+        // -- the whole rank-64 update of the block's own tile hides behind the factorisation.  (A slice, ~0.95 us, is
+        // about as long as a pivot run, so the doubled run stalls its barrier; putting the fourth slice into the solve
+        // phases instead -- as a whole while a wave waits there, or one MFMA per solve pivot -- measured 2-4 us worse.)
         potf2_tile(S, dprep, rinv, info, j0, n_valid, [&](int cb) {
             const int ord = cb - (cb > wave ? 1 : 0);
             if (ord == 0) { own_slice(0); own_slice(1); }
             else own_slice(ord + 1);
-        });
+        }, [](auto, auto) {}, [](auto) {});
         tile_sub_acc(X, accX, lane, wr, wc);
         __syncthreads();
     } else {
