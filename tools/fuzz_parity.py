@@ -39,7 +39,12 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         K = O.kernelmatrix(s2, ell, Xu, X)
         Psi2 = (K * wts) @ K.T; b = K @ (wts * y)
         Lam = np.linalg.inv(Sig0) + w * Psi2; Sig_r = np.linalg.inv(Lam); mu_r = Sig_r @ (np.linalg.inv(Sig0) @ mu0 + w * b)
-        R = Sig_r + np.outer(mu_r, mu_r); Uv_r = np.linalg.cholesky(R).T
+        R = Sig_r + np.outer(mu_r, mu_r); R = 0.5 * (R + R.T)
+        try:
+            Uv_r = np.linalg.cholesky(R).T
+        except np.linalg.LinAlgError:           # this naive host reference (explicit inverses) lost definiteness: no verdict
+            print(f"skip N={N} M={M} D={D} prior={form}: the host reference's R is not numerically positive definite", flush=True)
+            continue
         I2_r = float(np.sum(wts * (y * y + (vy if vy is not None else 0.0))) - 2 * b @ mu_r + np.sum(R * Psi2))
     cond = np.linalg.cond(np.linalg.inv(Sig_r))
     tol = min(1e-4, max(1e-9, 100 * np.finfo(float).eps * cond))
