@@ -136,13 +136,15 @@ static int quiesce(sgp_handle* h) {
 // which 128 workgroups run one to a CU at a fraction of the matrix-core rate -- PMC: the CUs were busy 71 % of the launch;
 // the largest chunk count with tiles x chunks <= slots (1008 at M = 512) keeps every CU at 4 workgroups from start to end.
 // `align`: chunk counts are rounded so that tiles x chunks is a multiple of the 8 XCDs (see k_syrk_stream's block map).
-// In a sweep the K_uu chain runs beside this kernel and its Cholesky steps (<= 36 workgroups of 82 KB LDS) take most of
-// the LDS of up to 36 CUs: SYRK_RESERVED_CUS are left out of the slot count so that the round still fits.
+// In a sweep the K_uu chain runs beside this kernel and each workgroup of its Cholesky steps takes the LDS of a whole CU.
+// SYRK_RESERVED_CUS are left out of the slot count for it.  Measured at T (sweeps/s, SYRK us): 40 reserved 3312 / 66.5,
+// 24 the same, 8: 3355 / 62.6, 0: 3202 / 76.7 (a second round).  The chain has ~45 us of slack at T since its steps got
+// short, so it can wait out most of this launch; with nothing reserved its resident workgroups push the round over.
 #ifndef SYRK_BLOCKS_PER_CU
 #define SYRK_BLOCKS_PER_CU 4
 #endif
 #ifndef SYRK_RESERVED_CUS
-#define SYRK_RESERVED_CUS 40
+#define SYRK_RESERVED_CUS 8
 #endif
 static void syrk_chunking(int ntiles, int num_cus, int* want, int* align) {
     int a = 8;
