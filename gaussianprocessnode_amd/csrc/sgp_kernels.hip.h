@@ -75,31 +75,55 @@ __device__ __forceinline__ void stamp_exit(int64_t* rec) {
 // end of a sweep (one wave): fold the spread exits, close the sweep stamp, totals[i] += end_i - begin_i, totals[count] += 1.
 // Slot 5 is derived: the idle time between the end of slot 7 (LOCAL) and the begin of slot 3 (FINISH1).  Slot numbers are
 // include/sgp_hip.h's SGP_T_*.
-__device__ __forceinline__ void stamp_accumulate(int64_t* stamps, int64_t* totals, int lane) {
-    constexpr int NSLOTS = 8, SWEEP = 0, FINISH1 = 3, FINISH2 = 4, GAP = 5, LOCAL = 7;
-    const int64_t now = realtime_ticks();
+// Runs at the very end of the sweep's last kernel, i.e. on the critical path of back-to-back sweeps: every load is issued
+// before the first store (one memory round trip), lane i then owns slot i (one read-modify-write of totals[i] per lane, in
+// parallel).  The first version walked the slots one after another -- a load, a fold and a store per slot, then 8 more
+// dependent round trips by lane 0 -- and kept the GPU ~9 us per sweep between k_scalars' exit stamp and the next sweep.
+struct StampFold { long long b, e, tot; };
+// part 1 (any time after the sweep's other kernels have finished -- k_scalars calls it first thing, so that the round trip
+// hides behind its own reductions): lane i < 8 gets slot i's begin, folded end and running total
+__device__ __forceinline__ StampFold stamp_fold_load(const int64_t* stamps, const int64_t* totals, int lane) {
+    constexpr int NSLOTS = 8;
+    long long ex[NSLOTS];
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) ex[i] = stamps[i * STAMP_STRIDE + 2 + lane];
+    const int slot = lane & (NSLOTS - 1);
+    StampFold f;
+    f.b = stamps[slot * STAMP_STRIDE];
+    f.e = stamps[slot * STAMP_STRIDE + 1];
+    f.tot = totals[slot];
+    long long mine = 0;
+#pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
-        long long e = stamps[i * STAMP_STRIDE + 2 + lane];
+        long long m = ex[i];
         for (int o = 32; o > 0; o >>= 1) {
-            long long other = __shfl_xor(e, o);
-            e = other > e ? other : e;
+            const long long other = __shfl_xor(m, o);
+            m = other > m ? other : m;
         }
-        if (lane == 0) {
-            int64_t* rec = stamps + i * STAMP_STRIDE;
-            if (e > rec[1]) rec[1] = e;
-        }
+        mine = (slot == i) ? m : mine;
     }
-    if (lane != 0) return;
-    stamps[SWEEP * STAMP_STRIDE + 1] = now;
-    stamps[FINISH2 * STAMP_STRIDE + 1] = now;             // this kernel is the end of FINISH2 (its own exit atomic may be in flight)
-    const int64_t gb = stamps[LOCAL * STAMP_STRIDE + 1], ge = stamps[FINISH1 * STAMP_STRIDE];
-    stamps[GAP * STAMP_STRIDE] = gb;
-    stamps[GAP * STAMP_STRIDE + 1] = (ge != 0x7fffffffffffffffLL) ? ge : gb;
-    for (int i = 0; i < NSLOTS; ++i) {
-        int64_t b = stamps[i * STAMP_STRIDE], e = stamps[i * STAMP_STRIDE + 1];
-        if (e > b && b != 0x7fffffffffffffffLL) totals[i] += e - b;
+    f.e = mine > f.e ? mine : f.e;
+    return f;
+}
+// part 2 (the very end of the sweep's last kernel): close the sweep, store
+__device__ __forceinline__ void stamp_fold_finish(StampFold f, int64_t* stamps, int64_t* totals, int lane) {
+    constexpr int NSLOTS = 8, SWEEP = 0, FINISH1 = 3, FINISH2 = 4, GAP = 5, LOCAL = 7;
+    constexpr long long UNSET = 0x7fffffffffffffffLL;
+    const long long now = realtime_ticks();
+    const int slot = lane & (NSLOTS - 1);
+    long long b = f.b, e = f.e;
+    if (slot == SWEEP || slot == FINISH2) e = now;        // this kernel is the end of both (its own exit atomic may be in flight)
+    const long long local_end = __shfl(e, LOCAL), finish1_begin = __shfl(b, FINISH1);
+    if (slot == GAP) { b = local_end; e = (finish1_begin != UNSET) ? finish1_begin : local_end; }
+    if (lane < NSLOTS) {
+        stamps[slot * STAMP_STRIDE] = b;
+        stamps[slot * STAMP_STRIDE + 1] = e;
+        if (e > b && b != UNSET) totals[slot] = f.tot + (e - b);
     }
-    totals[NSLOTS] += 1;
+    if (lane == 0) totals[NSLOTS] += 1;
+}
+__device__ __forceinline__ void stamp_accumulate(int64_t* stamps, int64_t* totals, int lane) {
+    stamp_fold_finish(stamp_fold_load(stamps, totals, lane), stamps, totals, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1736,7 +1760,10 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
     const int tid = threadIdx.x;
     if (d_out == 1) {
         // UniSGP: every thread's share of all five sums first (independent loads, one memory round trip), then ONE
-        // workgroup reduction -- this kernel is the last link of the critical path
+        // workgroup reduction -- this kernel is the last link of the critical path.  The last wave also fetches and folds
+        // the sweep's phase stamps now, so that closing them at the end is stores only.
+        StampFold fold = {0, 0, 0};
+        if (all_stamps && tid >= 192) fold = stamp_fold_load(all_stamps, totals, tid - 192);
         double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};         // tr(Kuu^-1 Psi2), tr(R Psi2), log|L_K|, log|L_Lambda|, b' mu
         for (int b = tid; b < nK; b += 256) v[0] += partK[b];
         for (int b = tid; b < nR; b += 256) v[1] += partR[b];
@@ -1770,8 +1797,7 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
             out[7] = 2.0 * t[3];
         }
         stamp_exit(stamps);
-        __syncthreads();
-        if (all_stamps && tid < 64) stamp_accumulate(all_stamps, totals, tid);
+        if (all_stamps && tid >= 192) stamp_fold_finish(fold, all_stamps, totals, tid - 192);
         return;
     }
     {   // wave w reduces slots w, w + 4, ... (slot 0: tr(Kuu^-1 Psi2), slot 1 + a + b d_out: tr(Rblk[a][b] Psi2)):
