@@ -142,10 +142,130 @@ def rule_v(q_out, q_in, q_w, q_theta: PointMass, meta: MultiSGPMeta) -> MvNormal
     return MvNormalWeightedMeanPrecision(xi, np.kron(W, Psi2))                         # :306
 
 
-def rule_in(*args, **kwargs):
-    raise NotImplementedError("MultiSGP(:in) (GPnode/MultiSGPnode.jl:162-236) returns a log-pdf closure / Laplace fit "
-                              "evaluated inside ReactiveMP; not on the device path yet (SURVEY.md §8 a14)")
+def _aux_engine(meta: MultiSGPMeta, n: int):
+    """A single-output device object for stand-alone closure evaluations (it replaces data and posterior, so it is not the
+    engine that holds the last swept sequence)."""
+    Xu = np.asarray(meta.Xu, dtype=np.float64)
+    M, D = Xu.shape
+    eng = getattr(meta, "_aux_engine", None)
+    if eng is None or eng.n_max < n:
+        from .device import SGPDevice
+        if eng is not None:
+            eng.close()
+        eng = SGPDevice(max(n, 64), M, D, 1, device=meta.device, keep_kuf=True)
+        eng.set_inducing(Xu)
+        meta._aux_engine = eng
+    return eng
 
 
-def rule_theta(*args, **kwargs):
-    raise NotImplementedError("MultiSGP(:theta) (GPnode/MultiSGPnode.jl:447-469) returns a log-pdf closure (SURVEY.md §8 f1)")
+def rule_in(q_out, q_v, q_w, q_theta: PointMass, meta: MultiSGPMeta, q_in=None):
+    """@rule MultiSGP(:in) (GPnode/MultiSGPnode.jl:162-184 Gaussian output, :186-208 point-mass output): the log-pdf closure
+        x -> -1/2 tr(W) I1(x) + s . k(x) - 1/2 k(x)' S k(x),      I1(x) = k(x,x) - k' Kuu^-1 k,
+        s = sum_d mu_v^(d) (mu_y' W)_d  (sum_diagonal_M),   S = sum_ij W_ij Rv_blk[i][j]  (create_blockmatrix), Rv = Sigma_v + mu mu'.
+    Both quadratic forms are per-point quantities the device already produces: with the pseudo-posterior (mean s, factor
+    chol(S).U) and pseudo-observations y = 1, sgp_w_stats returns I1(x) and I2(x) = 1 - 2 s.k + k' S k, so the closure is
+    -1/2 tr(W) I1 - 1/2 (I2 - 1) -- one device pass for any number of inputs (K_uu chain, K_uf, the two quadratic forms).
+    K_uu^-1 is the device's own at (theta, meta.jitter); the reference reads the copy stored in its meta (:168), made the same way.
+    With `q_in` given and point-mass q_out / q_w (:210-236) the closure is fitted by a Gaussian at its mode (Laplace): see
+    `rule_in_laplace`."""
+    if q_in is not None:
+        return rule_in_laplace(q_out, q_in, q_v, q_w, q_theta, meta)
+    from .unisgp import LogPdfClosure
+    from .device import potrf
+    Xu = np.asarray(meta.Xu, dtype=np.float64)
+    M, D_in = Xu.shape
+    W = _mean_W(q_w)
+    s_vec, S = _second_moment_contraction(q_out, q_v, W, M)                             # :176-179
+    US = potrf(S, meta.device).T                                                        # upper factor: |US k|^2 = k' S k
+    trW = float(np.trace(W))
+    sigma2, ell = meta.kernel(np.atleast_1d(np.asarray(q_theta.mean(), dtype=np.float64)))
+
+    def log_backwardmess(x):
+        X = np.asarray(x, dtype=np.float64).reshape(-1, D_in)
+        eng = _aux_engine(meta, len(X))
+        eng.set_data(X, np.ones(len(X)), None)
+        eng.set_kernel(sigma2, ell, meta.jitter)
+        eng.sweep_local()
+        eng.set_posterior(s_vec, US)
+        I1, I2 = eng.w_stats()
+        val = -0.5 * trW * I1 - 0.5 * (I2 - 1.0)                                        # :181
+        return float(val[0]) if np.ndim(x) == 1 else val
+    return LogPdfClosure(log_backwardmess, multivariate=True)
+
+
+def rule_in_laplace(q_out, q_in, q_v, q_w, q_theta: PointMass, meta: MultiSGPMeta, iterations: int = 20):
+    """@rule MultiSGP(:in) with q_out::PointMass, q_in Gaussian, q_w::PointMass (GPnode/MultiSGPnode.jl:210-236): minimise the
+    negative closure from mean(q_in) with L-BFGS (20 iterations, :229) and return N(m_z, W_z^-1) in weighted-mean form, W_z
+    the Hessian at the minimiser (:231-233).  The reference differentiates with ForwardDiff / Zygote; here gradient and
+    Hessian are central differences of the device-evaluated closure, every stencil one device pass."""
+    from scipy.optimize import minimize
+    closure = rule_in(q_out, q_v, q_w, q_theta, meta)
+    x0 = np.asarray(q_in.mean(), dtype=np.float64).ravel()
+    D_in = len(x0)
+    h = 1e-5
+
+    def neg_and_grad(x):
+        pts = np.vstack([x] + [x + h * e for e in np.eye(D_in)] + [x - h * e for e in np.eye(D_in)])
+        f = -np.asarray(closure.logpdf(pts))
+        return float(f[0]), (f[1:1 + D_in] - f[1 + D_in:]) / (2 * h)
+    res = minimize(neg_and_grad, x0, jac=True, method="L-BFGS-B", options={"maxiter": iterations})
+    m_z = res.x
+    hh = 1e-4
+    E = np.eye(D_in)
+    pts, idx = [m_z], {}
+    for a in range(D_in):
+        for b in range(a, D_in):
+            idx[(a, b)] = len(pts)
+            pts += [m_z + hh * (E[a] + E[b]), m_z + hh * (E[a] - E[b]), m_z - hh * (E[a] - E[b]), m_z - hh * (E[a] + E[b])]
+    f = -np.asarray(closure.logpdf(np.vstack(pts)))
+    W_z = np.zeros((D_in, D_in))
+    for (a, b), k in idx.items():
+        W_z[a, b] = W_z[b, a] = (f[k] - f[k + 1] - f[k + 2] + f[k + 3]) / (4 * hh * hh)
+    return MvNormalWeightedMeanPrecision(W_z @ m_z, W_z)                                # :235
+
+
+def _second_moment_contraction(q_out, q_v, W, M):
+    """s = sum_d mu_v^(d) (mu_y' W)_d and S = sum_ij W_ij Rv_blk[i][j] -- what the :in and :theta closures keep of q(v)."""
+    mu_y = np.asarray(q_out.mean(), dtype=np.float64).ravel()
+    d_out = len(mu_y)
+    mu_v, Sigma_v = q_v.mean_cov()
+    mu_v = np.asarray(mu_v, dtype=np.float64).ravel()
+    Rv = np.asarray(Sigma_v, dtype=np.float64) + np.outer(mu_v, mu_v)
+    row = mu_y @ W
+    s_vec = sum(mu_v[d * M:(d + 1) * M] * row[d] for d in range(d_out))
+    S = sum(Rv[i * M:(i + 1) * M, j * M:(j + 1) * M] * W[i, j] for i in range(d_out) for j in range(d_out))
+    return s_vec, 0.5 * (S + S.T)
+
+
+def rule_theta(q_out, q_in, q_v, q_w, meta: MultiSGPMeta):
+    """@rule MultiSGP(:theta) (GPnode/MultiSGPnode.jl:447-466): theta -> -1/2 tr(W) (Psi0 - tr(Kuu^-1 Psi2')) + Psi1 . s
+    - 1/2 tr(Psi2' S), Psi2' = Psi2 + 1e-7 I (:458), Kuu(theta) without jitter (:455), Psi by meta.method's cubature over q_in.
+    Per cubature point this is the :in closure, so one device pass per theta (K_uu chain at theta, K_uf for the points, the
+    two per-point quadratic forms); the 1e-7 I term adds 1e-7 (tr(W) tr(Kuu^-1) - tr(S)) / 2, tr(Kuu^-1) from the device's
+    factor."""
+    from scipy.linalg import solve_triangular
+    from .unisgp import LogPdfClosure
+    from .device import potrf
+    if meta.method is None:
+        raise ValueError("MultiSGP(:theta) needs meta.method (a cubature rule)")
+    Xu = np.asarray(meta.Xu, dtype=np.float64)
+    M = Xu.shape[0]
+    W = _mean_W(q_w)
+    s_vec, S = _second_moment_contraction(q_out, q_v, W, M)
+    US = potrf(S, meta.device).T
+    trW, trS = float(np.trace(W)), float(np.trace(S))
+    m_in, P_in = q_in.mean_cov()
+    pts, wts = meta.method.points_weights(m_in, P_in)
+    pts, wts = np.atleast_2d(np.asarray(pts, dtype=np.float64)), np.asarray(wts, dtype=np.float64)
+
+    def log_backwardmess(theta):
+        sigma2, ell = meta.kernel(np.atleast_1d(np.asarray(theta, dtype=np.float64)))
+        eng = _aux_engine(meta, len(pts))
+        eng.set_data(pts, np.ones(len(pts)), None)
+        eng.set_kernel(sigma2, ell, 0.0)
+        eng.sweep_local()
+        eng.set_posterior(s_vec, US)
+        I1, I2 = eng.w_stats()
+        Linv = solve_triangular(eng.kuu_chol(), np.eye(M), lower=True)
+        return float(wts @ (-0.5 * trW * I1 - 0.5 * (I2 - 1.0)) + 0.5e-7 * (trW * np.sum(Linv * Linv) - trS))
+    return LogPdfClosure(log_backwardmess, multivariate=True)

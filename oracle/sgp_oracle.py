@@ -382,6 +382,57 @@ def multi_rule_v(Psi1, Psi2, mu_y, W):
     return xi, np.kron(W, Psi2)                                     # :306
 
 
+def multi_rule_in_logpdf(Xu, sigma2, ell, mu_y, mu_v, Sigma_v, W, Kuu_inv):
+    """@rule MultiSGP(:in) with a Gaussian or point-mass output (GPnode/MultiSGPnode.jl:162-184, :186-208): the log-pdf closure
+    x -> -1/2 tr(W) (k(x,x) - sum(Kuu^-1 .* k k')) + sumdiagV . k - 1/2 sum(k k' .* sumRvblk_W),  k = K(Xu, x),
+    sumdiagV = sum_d V[dM:(d+1)M, d] with V = mu_v mu_y' W (sum_diagonal_M, helper_functions/derivative_helper.jl:117-120),
+    sumRvblk_W = sum_ij Rv_blk[i][j] W[i][j] (create_blockmatrix, helper_functions/gp_helperfunction.jl:133-135)."""
+    Xu = np.atleast_2d(np.asarray(Xu, dtype=np.float64))
+    M = Xu.shape[0]
+    mu_y = np.asarray(mu_y, dtype=np.float64).ravel()
+    D = len(mu_y)
+    W = np.atleast_2d(np.asarray(W, dtype=np.float64))
+    mu_v = np.asarray(mu_v, dtype=np.float64).ravel()
+    Rv = np.asarray(Sigma_v, dtype=np.float64) + np.outer(mu_v, mu_v)                   # :176
+    V = np.outer(mu_v, mu_y) @ W                                                        # :177
+    sumdiagV = sum(V[d * M:(d + 1) * M, d] for d in range(D))                           # :178
+    sumRvblk_W = sum(Rv[i * M:(i + 1) * M, j * M:(j + 1) * M] * W[i, j] for i in range(D) for j in range(D))   # :179
+    trW = float(np.trace(W))
+
+    def log_backwardmess(x):
+        x = np.asarray(x, dtype=np.float64).reshape(1, -1)
+        k = kernelmatrix(sigma2, ell, Xu, x)[:, 0]
+        Psi0 = float(kernelmatrix(sigma2, ell, x)[0, 0])
+        Psi2 = np.outer(k, k)
+        return float(-0.5 * trW * (Psi0 - np.sum(Kuu_inv * Psi2)) + sumdiagV @ k - 0.5 * np.sum(Psi2 * sumRvblk_W))   # :181
+    return log_backwardmess
+
+
+def multi_rule_theta_logpdf(Xu, kernel, pts, wts, mu_y, mu_v, Sigma_v, W):
+    """@rule MultiSGP(:theta) (GPnode/MultiSGPnode.jl:447-466): theta -> -1/2 tr(W I1(theta)) + mu_y' W kron(C, Psi1(theta)) mu_v
+    - 1/2 tr(kron(W, Psi2(theta)) Rv), I1 = kron(C, Psi0 - tr(Kuu^-1(theta) Psi2(theta))), Psi2 carries + 1e-7 I (:458), Kuu no
+    jitter (:455).  `kernel`: theta -> (sigma2, lengthscales); (pts, wts): the cubature rule of q_in."""
+    Xu = np.atleast_2d(np.asarray(Xu, dtype=np.float64))
+    M = Xu.shape[0]
+    mu_y = np.asarray(mu_y, dtype=np.float64).ravel()
+    D = len(mu_y)
+    W = np.atleast_2d(np.asarray(W, dtype=np.float64))
+    mu_v = np.asarray(mu_v, dtype=np.float64).ravel()
+    Rv = np.asarray(Sigma_v, dtype=np.float64) + np.outer(mu_v, mu_v)                   # :450
+    C = np.eye(D)
+
+    def log_backwardmess(theta):
+        sigma2, ell = kernel(theta)
+        Psi0, Psi1, Psi2 = psi_statistics(Xu, pts, wts, sigma2, ell)
+        Psi2 = Psi2 + 1e-7 * np.eye(M)                                                  # :458
+        Kinv = cholinv(kernelmatrix(sigma2, ell, Xu))                                   # :455
+        I1 = np.kron(C, np.atleast_2d(Psi0 - np.trace(Kinv @ Psi2)))                    # :460
+        Psi1_tilde = np.kron(C, np.asarray(Psi1)[None, :])                              # :461
+        Psi3 = np.kron(W, Psi2)                                                         # :462
+        return float(-0.5 * np.trace(W @ I1) + mu_y @ W @ Psi1_tilde @ mu_v - 0.5 * np.trace(Psi3 @ Rv))   # :463
+    return log_backwardmess
+
+
 def multi_rule_w(Psi0, Psi1, Psi2, mu_y, Sigma_y, mu_v, Sigma_v, Kuu_inv):
     """@rule MultiSGP(:w) (GPnode/MultiSGPnode.jl:367-405,407-444): inverse scale I1 + I2 of WishartFast(D+2, .)."""
     D = len(mu_y)

@@ -174,6 +174,70 @@ def test_multisgp_mirror_rules(graph):
     assert math.isclose(MS.average_energy_summed(meta), U_ref, rel_tol=1e-6)
 
 
+def test_multisgp_rule_in_closure_and_laplace(graph):
+    """GPtest.jl:406-429: MultiSGP(:in) -- the log-pdf closure at the reference's probe inputs (device-backed: one pass per
+    batch of inputs) and its Laplace fit (mode and Hessian within the reference's own atol = 0.01)."""
+    from scipy.optimize import minimize
+    from gaussianprocessnode_amd import multisgp as MS
+    from gaussianprocessnode_amd.cubature import srcubature
+    from gaussianprocessnode_amd.distributions import MvNormalMeanCovariance as MvN
+    from gaussianprocessnode_amd.unisgp import LogPdfClosure
+    rng = np.random.default_rng(5)
+    Xu2 = np.array([[i, j] for j in range(1, 6) for i in range(1, 6)], dtype=np.float64)        # GPtest.jl:20
+    M = 25
+    q_theta = PointMass(THETA)
+    meta = Mt.MultiSGPMeta(srcubature(), Xu2, None, None, None, None, Mt.SEARDKernel(), Mt.GPCache(), jitter=1e-12)
+    q_v = MvN(np.sin(rng.random(2 * M)), np.eye(2 * M))                                          # GPtest.jl:355
+    Kinv = O.cholinv(O.kernelmatrix(1.0, np.array([1.0]), Xu2) + 1e-12 * np.eye(M))
+    for W, q_out in ((10 * 50.0 * np.eye(2), MvN(np.array([0.5, 1.4]), np.eye(2))),              # GPtest.jl:353,356
+                     (np.array([[3.0, 0.7], [0.7, 1.5]]), PointMass(np.array([1.5, 2.0])))):     # GPtest.jl:416
+        nu = MS.rule_in(q_out, q_v, PointMass(W), q_theta, meta)
+        assert isinstance(nu, LogPdfClosure) and nu.multivariate
+        ref = O.multi_rule_in_logpdf(Xu2, 1.0, np.array([1.0]), q_out.mean(), q_v.m, q_v.S, W, Kinv)
+        probes = np.array([[1.0, 1.5], [-1.5, 2.0], [2.2, 3.1], [4.0, 0.5]])
+        got = nu.logpdf(probes)                                                                  # one device pass
+        want = np.array([ref(x) for x in probes])
+        np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-7)
+        assert math.isclose(nu.logpdf(probes[1]), want[1], rel_tol=1e-8, abs_tol=1e-7)           # single input -> scalar
+    # Laplace fit (GPtest.jl:415-428): point-mass output and precision, q_in gives the start
+    W = 10 * 50.0 * np.eye(2)
+    q_out_pm, q_in = PointMass(np.array([1.5, 2.0])), MvN(np.array([1.0, 2.7]), np.eye(2))
+    nu_z = MS.rule_in(q_out_pm, q_v, PointMass(W), q_theta, meta, q_in=q_in)
+    ref = O.multi_rule_in_logpdf(Xu2, 1.0, np.array([1.0]), q_out_pm.mean(), q_v.m, q_v.S, W, Kinv)
+    res = minimize(lambda x: -ref(x), q_in.mean(), method="L-BFGS-B", options={"maxiter": 20})
+    h, E = 1e-4, np.eye(2)
+    Hz = np.array([[(-ref(res.x + h * (E[a] + E[b])) + ref(res.x + h * (E[a] - E[b])) + ref(res.x - h * (E[a] - E[b]))
+                     - ref(res.x - h * (E[a] + E[b]))) / (4 * h * h) for b in range(2)] for a in range(2)])
+    np.testing.assert_allclose(nu_z.mean(), res.x, atol=0.01)                                    # GPtest.jl:426
+    np.testing.assert_allclose(nu_z.cov(), np.linalg.inv(Hz), atol=0.01)                         # GPtest.jl:427
+
+
+def test_multisgp_rule_theta_closure(graph):
+    """GPtest.jl:473-506: MultiSGP(:theta) at the reference's probes theta = [1.2, 2.3], [0.5, 1.4] (Gaussian and point-mass
+    output).  K_uu(theta) carries no jitter here (GPnode/MultiSGPnode.jl:455) and the 5 x 5 unit grid with lengthscale 2.3 has
+    cond(K_uu) ~ 1e13: the closure's tr(K_uu^-1 Psi2) is only defined to ~cond * eps of its terms, hence the tolerance."""
+    from gaussianprocessnode_amd import multisgp as MS
+    from gaussianprocessnode_amd.cubature import srcubature
+    from gaussianprocessnode_amd.distributions import MvNormalMeanCovariance as MvN
+    rng = np.random.default_rng(6)
+    Xu2 = np.array([[i, j] for j in range(1, 6) for i in range(1, 6)], dtype=np.float64)
+    M = 25
+    meta = Mt.MultiSGPMeta(srcubature(), Xu2, None, None, None, None, Mt.SEARDKernel(), Mt.GPCache(), jitter=1e-12)
+    q_in = MvN(np.array([1.0, 2.7]), np.eye(2))
+    q_v = MvN(np.sin(rng.random(2 * M)), np.eye(2 * M))
+    W = 10 * 50.0 * np.eye(2)
+    pts, wts = O.srcubature(q_in.m, q_in.S)
+    for q_out in (MvN(np.array([0.5, 1.4]), np.eye(2)), PointMass(np.array([1.5, 2.0]))):
+        nu = MS.rule_theta(q_out, q_in, q_v, PointMass(W), meta)
+        ref = O.multi_rule_theta_logpdf(Xu2, Mt.SEARDKernel(), pts, wts, q_out.mean(), q_v.m, q_v.S, W)
+        for th in ([1.2, 2.3], [0.5, 1.4], [1.0, 0.8]):
+            s2, ell = Mt.SEARDKernel()(np.array(th))
+            K = O.kernelmatrix(s2, ell, Xu2)
+            scale = 0.5 * np.trace(W) * np.trace(np.linalg.solve(K + 1e-300 * np.eye(M), O.psi_statistics(Xu2, pts, wts, s2, ell)[2]))
+            tol = 1e-7 * abs(ref(np.array(th))) + 50 * np.finfo(float).eps * np.linalg.cond(K) * abs(scale)
+            assert abs(nu.logpdf(np.array(th)) - ref(np.array(th))) <= tol, (th, nu.logpdf(np.array(th)), ref(np.array(th)), tol)
+
+
 def test_streaming_driver_matches_oracle_loop():
     """PerformInference (experiments/regression_kin40k.ipynb:196-230) -- posterior carry over ragged
     minibatches and AdaMax steps on theta, against the same loop written with the oracle."""

@@ -215,6 +215,40 @@ def test_multi_rule_v(multi):
     np.testing.assert_allclose(xi, Psi1_tilde.T @ multi["W"] @ multi["mu_y"], rtol=1e-13)
 
 
+def test_multi_rule_in_closure(multi):
+    """GPtest.jl:406-413: logpdf(nu_in, x) == -1/2 tr(W kron(C, A_x)) + mu_y' W kron(C, B_x) mu_v
+    - 1/2 tr(Rv kron(C, B_x)' W kron(C, B_x)) at the reference's two probe inputs (and a third with a full W)."""
+    C = np.eye(2)
+    for W in (multi["W"], np.array([[3.0, 0.7], [0.7, 1.5]])):
+        f = O.multi_rule_in_logpdf(XU2, S2, ELL, multi["mu_y"], multi["mu_v"], multi["Sigma_v"], W, multi["Kinv"])
+        for x in ([1.0, 1.5], [-1.5, 2.0], [2.2, 3.1]):
+            xx = np.array([x])
+            B = O.kernelmatrix(S2, ELL, xx, XU2)                                            # B_x (1 x M), GPtest.jl:48
+            A = O.kernelmatrix(S2, ELL, xx, xx) - B @ multi["Kinv"] @ B.T                   # A_x, GPtest.jl:47
+            kB = np.kron(C, B)
+            gt = (-0.5 * np.trace(W @ np.kron(C, A)) + multi["mu_y"] @ W @ kB @ multi["mu_v"]
+                  - 0.5 * np.trace(multi["Rv"] @ kB.T @ W @ kB))
+            assert np.isclose(f(x), gt, rtol=1e-10, atol=1e-9), (x, f(x), gt)
+
+
+def test_multi_rule_theta_closure(multi):
+    """GPtest.jl:473-488: the :theta closure at the reference's probes, against its trace form
+    -1/2 tr(W) (Psi0 - tr(Kuu^-1 Psi2')) + Psi1 . s - 1/2 sum(Psi2' .* S)  (what the device evaluates point by point)."""
+    W, M = multi["W"], multi["M"]
+    kern = lambda th: (float(th[0]), np.asarray(th[1:], dtype=np.float64))                      # GPtest.jl:21
+    f = O.multi_rule_theta_logpdf(XU2, kern, multi["pts"], multi["w"], multi["mu_y"], multi["mu_v"], multi["Sigma_v"], W)
+    row = multi["mu_y"] @ W
+    s_vec = sum(multi["mu_v"][d * M:(d + 1) * M] * row[d] for d in range(2))
+    S = sum(multi["Rv"][i * M:(i + 1) * M, j * M:(j + 1) * M] * W[i, j] for i in range(2) for j in range(2))
+    for th in ([1.2, 2.3], [0.5, 1.4]):
+        s2, ell = kern(np.array(th))
+        P0, P1, P2 = O.psi_statistics(XU2, multi["pts"], multi["w"], s2, ell)
+        P2 = P2 + 1e-7 * np.eye(M)
+        Kinv = O.cholinv(O.kernelmatrix(s2, ell, XU2))
+        want = -0.5 * np.trace(W) * (P0 - np.trace(Kinv @ P2)) + P1 @ s_vec - 0.5 * np.sum(P2 * S)
+        assert np.isclose(f(np.array(th)), want, rtol=1e-9, atol=1e-6), (th, f(np.array(th)), want)
+
+
 def test_multi_rule_w(multi):
     """GPtest.jl:459-471: Wishart(D+2, inv(I1 + I2)) with Psi4 = E[kron(C,k') Rv kron(C,k)]."""
     S = O.multi_rule_w(multi["Psi0"], multi["Psi1"], multi["Psi2"], multi["mu_y"], multi["Sigma_y"],
