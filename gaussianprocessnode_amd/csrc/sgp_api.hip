@@ -66,6 +66,8 @@ struct sgp_handle {
     int64_t* dStamps = nullptr;
     int64_t* dStampTotals = nullptr;
     Params* hParams = nullptr;     // pinned
+    uint64_t params_gen = 1;       // bumped by every setter that changes hParams or Xu
+    uint64_t main_prep_gen = 0;    // the generation k_prep_xu last mirrored onto the main stream's copies (dXus, dParams)
     Params* dParams = nullptr;
     Params* dParamsK = nullptr;    // the K_uu chain's own copy (it runs on the side stream)
     double* dXusK = nullptr;
@@ -297,7 +299,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dTrace, (size_t)TRACE_BLOCKS + std::max((size_t)TRACE_BLOCKS * MAXO * MAXO, (size_t)h->TQ * (h->TQ + 1) * 4));
     ALLOC(h->dInfo, 4);
     ALLOC(h->dStamps, STAMP_STRIDE * SGP_T_COUNT);
-    ALLOC(h->dStampTotals, SGP_T_COUNT + 1);
+    ALLOC(h->dStampTotals, SGP_T_COUNT + 1 + 2 * SGP_T_COUNT);      // totals, count, then the last sweep's (begin, end) pairs
     ALLOC(h->dParams, 1);
     ALLOC(h->dParamsK, 1);
     ALLOC(h->dXusK, Mp * h->D);
@@ -328,7 +330,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     hipMemset(h->dInfo, 0, 4 * sizeof(int));
     hipMemset(h->dOut, 0, SGP_R_COUNT * sizeof(double));
     hipMemset(h->dStamps, 0, STAMP_STRIDE * SGP_T_COUNT * sizeof(int64_t));
-    hipMemset(h->dStampTotals, 0, (SGP_T_COUNT + 1) * sizeof(int64_t));
+    hipMemset(h->dStampTotals, 0, (SGP_T_COUNT + 1 + 2 * SGP_T_COUNT) * sizeof(int64_t));
     hipMemset(h->dMu, 0, Qp * sizeof(double));
     hipMemset(h->dXi0, 0, Qp * sizeof(double));
     *out = h;
@@ -365,6 +367,7 @@ extern "C" int sgp_set_inducing(sgp_handle* h, const double* Xu) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpy(h->dXu, Xu, sizeof(double) * h->M * h->D, hipMemcpyHostToDevice));
     h->have_inducing = true;
+    h->params_gen++;
     h->swept = h->swept_local = false;
     return 0;
 }
@@ -456,6 +459,7 @@ extern "C" int sgp_set_kernel(sgp_handle* h, double sigma2, const double* ell, i
     }
     h->hParams->sigma2 = sigma2;
     h->hParams->jitter = jitter;
+    h->params_gen++;
     h->n_ell = n_ell;
     h->have_kernel = true;
     return 0;
@@ -466,6 +470,7 @@ extern "C" int sgp_set_noise(sgp_handle* h, const double* W, double E_log_w) {
     if (int qrc = quiesce(h)) return qrc;
     for (int i = 0; i < h->dout * h->dout; ++i) h->hParams->W[i] = W[i];
     h->hParams->E_logw = E_log_w;
+    h->params_gen++;
     return 0;
 }
 
@@ -489,6 +494,7 @@ extern "C" int sgp_set_prior(sgp_handle* h, const double* vec, const double* mat
     if (form == 2) {
         if (!(mat[0] > 0.0)) return fail(h, SGP_ERR_ARG, "sgp_set_prior: isotropic variance must be > 0");
         h->hParams->prior_iso = 1.0 / mat[0];
+        h->params_gen++;
         h->prior_form = 2;
         return 0;
     }
@@ -581,15 +587,22 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
 
 static void enqueue_local(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
-    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, (const Params*)h->hParams,
-                       h->dParams, (int*)nullptr, M, Mp, D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP);
+    // The scaled inducing inputs and the parameter mirror only change when a setter ran: a sweep at unchanged parameters
+    // (VMP iterations at fixed theta) starts with the Gram kernel.  (Always in graph mode -- the captured sequence is fixed
+    // -- and without data, where no Gram kernel exists to open the sweep's stamps.)
+    const bool prep = h->main_prep_gen != h->params_gen || (h->cfg.flags & SGP_FLAG_GRAPH) || h->n <= 0;
+    if (prep) {
+        hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, (const Params*)h->hParams,
+                           h->dParams, (int*)nullptr, M, Mp, D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP);
+        h->main_prep_gen = h->params_gen;
+    }
     if (h->n > 0) {
         if (D <= 8)
             hipLaunchKernelGGL(k_gram_uf<8>, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
-                               h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM);
+                               h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, h->dStamps);
         else
             hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
-                               h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM);
+                               h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, h->dStamps);
         hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                            h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, h->ntiles, h->nchunks,
                            h->dStamps + STAMP_STRIDE * SGP_T_SYRK);
@@ -847,8 +860,8 @@ extern "C" int sgp_get_timestamps(sgp_handle* h, int64_t* out) {
     if (!h || !out) return SGP_ERR_ARG;
     int rc = sync_all(h);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpy2D(out, 2 * sizeof(int64_t), h->dStamps, STAMP_STRIDE * sizeof(int64_t), 2 * sizeof(int64_t), SGP_T_COUNT,
-                          hipMemcpyDeviceToHost));
+    // the last sweep's (begin, end) pairs, kept by the sweep's closing kernel behind the totals (the live records are reset there)
+    HIPCHK(h, hipMemcpy(out, h->dStampTotals + SGP_T_COUNT + 1, 2 * SGP_T_COUNT * sizeof(int64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -879,10 +892,10 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
     auto launch = [&]() {
         if (which == SGP_T_GRAM && h->D <= 8)
             hipLaunchKernelGGL(k_gram_uf<8>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
-                               h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr);
+                               h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr, (int64_t*)nullptr);
         else if (which == SGP_T_GRAM)
             hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
-                               h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr);
+                               h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr, (int64_t*)nullptr);
         else
             hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                                h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->chunk, h->ntiles, h->nchunks,
@@ -960,6 +973,7 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
     }
     hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, (const Params*)h->hParams,
                        h->dParams, (int*)nullptr, h->M, h->Mp, h->D, (int64_t*)nullptr, 0, 0);
+    h->main_prep_gen = h->params_gen;                        // (this call synchronises before it returns)
     switch (h->D) {
         case 1: launch_predict<1>(h, dXs, dMu, dMean, ns, s); break;
         case 2: launch_predict<2>(h, dXs, dMu, dMean, ns, s); break;
@@ -982,6 +996,7 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
 static int theta_objective_eval(sgp_handle* h, hipStream_t s, double* value) {
     enqueue_kuu(h, s);
     enqueue_local(h, s);
+    h->main_prep_gen = 0;       // this evaluation opens phase stamps that no closing kernel folds: let the next sweep's k_prep_xu reset them
     const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
     hipLaunchKernelGGL(k_trace_kinv, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dTrace, M, Mp);
     hipLaunchKernelGGL(k_trace_R, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dR, h->dTrace + TRACE_BLOCKS, M, Mp, h->dout,

@@ -116,9 +116,14 @@ __device__ __forceinline__ void stamp_fold_finish(StampFold f, int64_t* stamps, 
     const long long local_end = __shfl(e, LOCAL), finish1_begin = __shfl(b, FINISH1);
     if (slot == GAP) { b = local_end; e = (finish1_begin != UNSET) ? finish1_begin : local_end; }
     if (lane < NSLOTS) {
-        stamps[slot * STAMP_STRIDE] = b;
-        stamps[slot * STAMP_STRIDE + 1] = e;
+        int64_t* last = totals + NSLOTS + 1;                  // this sweep's (begin, end) pairs, for sgp_get_timestamps
+        last[2 * slot] = b;
+        last[2 * slot + 1] = e;
         if (e > b && b != UNSET) totals[slot] = f.tot + (e - b);
+        // ready for the next sweep: the begins are taken with atomicMin, so they start from "unset"; the exits are folded
+        // with max and time only grows, so they need no reset
+        stamps[slot * STAMP_STRIDE] = UNSET;
+        stamps[slot * STAMP_STRIDE + 1] = 0;
     }
     if (lane == 0) totals[NSLOTS] += 1;
 }
@@ -195,9 +200,14 @@ template <int DCAP>
 __global__ void __launch_bounds__(256) k_gram_uf(const double* __restrict__ Xus, const double* __restrict__ X,
                                                  const double* __restrict__ Yw, double* __restrict__ Kuf,
                                                  double* __restrict__ bpart, const Params* __restrict__ P,
-                                                 int M, int Mp, int D, int64_t N, int d_out, int64_t* stamps) {
+                                                 int M, int Mp, int D, int64_t N, int d_out, int64_t* stamps,
+                                                 int64_t* sweep_begin) {
     __shared__ double us[DCAP * TB];
     stamp_enter(stamps);
+    if (sweep_begin) {            // first kernel of a sweep whose parameters were already resident (no k_prep_xu in front)
+        stamp_enter(sweep_begin + 0 * STAMP_STRIDE);          // SGP_T_SWEEP
+        stamp_enter(sweep_begin + 7 * STAMP_STRIDE);          // SGP_T_LOCAL
+    }
     __shared__ double xs[DCAP * TB];
     __shared__ double ys[MAXO * TB];
     __shared__ double red[16 * TB];
