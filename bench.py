@@ -139,7 +139,7 @@ def main():
     achieved = syrk_flops / (syrk_us * 1e-6) / 1e12
     # HBM traffic of the same kernel: separate rocprofv3 --pmc passes (profiles/r01_pmc_*_T.txt), FETCH_SIZE doubled as
     # MI355X_MICROARCH.md prescribes for 16-B-per-lane streaming reads; only valid for the workload it was measured on
-    PMC_TRAFFIC = {("T", 1): 2 * 20.564e6 + 28.330e6}
+    PMC_TRAFFIC = {("T", 1): 2 * 24.008e6 + 30.691e6}
 
     out = {
         "metric": "VMP iterations/sec (sparse-GP node sweep, kin40k-shaped synthetic)",
