@@ -250,6 +250,46 @@ def test_graph_replay_equals_eager_and_tracks_parameters(G):
     assert not np.array_equal(outs[0][0][0], outs[0][1][0])
 
 
+def test_resident_parameters_are_refreshed_by_every_setter(G):
+    """Sweeps at unchanged parameters skip the parameter/inducing-input mirror kernel: every setter (kernel, noise, prior,
+    inducing inputs), a prediction and a theta-objective evaluation at other parameters in between must still leave the next
+    sweep bitwise equal to the same sweep on a fresh handle."""
+    N, M, D = 600, 70, 3
+    X, Xu, y, _ = synth(N, M, D, seed=8)
+    Xu2 = Xu + 0.05
+    ell_a, ell_b = np.array([1.0, 1.5, 2.0]), np.array([0.8, 1.1, 2.5])
+
+    def fresh(Xu_, s2, ell, w, pv):
+        with G.SGPDevice(N, M, D) as d:
+            d.set_inducing(Xu_); d.set_data(X, y); d.set_kernel(s2, ell, 1e-8); d.set_prior_isotropic(pv); d.set_noise([[w]])
+            d.sweep()
+            return d.posterior() + (d.scalars().energy,)
+
+    def same(a, b):
+        return all(np.array_equal(u, v) for u, v in zip(a[:3], b[:3])) and a[3] == b[3]
+
+    with G.SGPDevice(N, M, D) as dev:
+        dev.set_inducing(Xu); dev.set_data(X, y); dev.set_kernel(1.0, ell_a, 1e-8); dev.set_prior_isotropic(50.0); dev.set_noise([[10.0]])
+        dev.sweep(); dev.sweep(); dev.sweep()                                    # the 2nd and 3rd start with the Gram kernel
+        assert same(dev.posterior() + (dev.scalars().energy,), fresh(Xu, 1.0, ell_a, 10.0, 50.0))
+        dev.set_kernel(0.7, ell_b, 1e-8); dev.sweep(); dev.sweep()
+        assert same(dev.posterior() + (dev.scalars().energy,), fresh(Xu, 0.7, ell_b, 10.0, 50.0))
+        dev.set_noise([[33.0]]); dev.sweep()
+        assert same(dev.posterior() + (dev.scalars().energy,), fresh(Xu, 0.7, ell_b, 33.0, 50.0))
+        dev.set_prior_isotropic(5.0); dev.sweep()
+        assert same(dev.posterior() + (dev.scalars().energy,), fresh(Xu, 0.7, ell_b, 33.0, 5.0))
+        dev.set_inducing(Xu2); dev.sweep(); dev.sweep()
+        assert same(dev.posterior() + (dev.scalars().energy,), fresh(Xu2, 0.7, ell_b, 33.0, 5.0))
+        mu = dev.posterior()[0]
+        dev.predict(X[:50], mu)                                                  # mirrors the parameters itself
+        dev.set_kernel(1.3, ell_a, 1e-8)
+        dev.theta_objective(want_grad=True)                                      # evaluated at the new theta, q(v) of the old sweep
+        dev.set_kernel(0.7, ell_b, 1e-8); dev.sweep()
+        assert same(dev.posterior() + (dev.scalars().energy,), fresh(Xu2, 0.7, ell_b, 33.0, 5.0))
+        tot, cnt = dev.phase_totals()
+        assert cnt >= 9 and all(t >= 0 for t in tot)                             # the phase stamps survived the skipped kernels
+
+
 def test_two_phase_with_bound_statistics_buffer(G):
     """The multi-GPU hand-off on one GPU: two shards' statistics summed in a caller-owned buffer
     (what the RCCL all-reduce does), then the replicated finish."""
