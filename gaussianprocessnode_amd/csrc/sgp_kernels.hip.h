@@ -579,13 +579,15 @@ __global__ void __launch_bounds__(256) k_form_lambda(const double* __restrict__ 
 // Blocked right-looking Cholesky (lower), tile 64, ONE launch per block step (look-ahead by redundancy):
 //   k_potrf_step(j): block (a, b) of the trailing matrix first applies the rank-64 update of step j-1
 //   (A_ik -= L_i,j-1 L_k,j-1^T on the matrix cores).  Blocks of the first trailing column (b = 0) then
-//   continue with step j without leaving the kernel: each of them ALSO updates and factors the diagonal
-//   tile A_jj itself in LDS (redundant compute instead of an inter-block hand-off) and solves
-//   X L_jj^T = A_ij for its own tile; the block on the diagonal writes L_jj.
-// Thread layout of the sequential parts: 4 adjacent lanes (q = tid & 3) share one row r = tid >> 2 and lane q
-// keeps the row's entries c = q (mod 4) in registers (right-looking, no reductions; the quad exchanges the
-// pivot-column entry with a DPP quad broadcast).  The factorisation needs one barrier per column (the pivot
-// column travels through a double-buffered LDS vector), the triangular solve none.
+//   continue with step j without leaving the kernel: each of them ALSO factors the diagonal tile A_jj itself in
+//   LDS (redundant compute instead of an inter-block hand-off; its rank-64 update arrives as a tile formed by
+//   the previous launch, see trsm_tile_next) and solves X L_jj^T = A_ij for its own tile; the block on the
+//   diagonal writes L_jj.
+// Thread layout of the sequential parts: the triangular solves give 4 adjacent lanes (q = tid & 3) one row
+// r = tid >> 2, lane q keeping the row's entries c = q (mod 4) in registers (no reductions; the quad exchanges
+// the pivot entry with a DPP quad broadcast); the pivot runs of the factorisation use lane = 16 q + r over the
+// full symmetric 16 x 16 block (DPP row broadcast + one ds_bpermute per pivot, see potf2_tile).  Two workgroup
+// barriers per 16 pivots in the factorisation, none in the triangular solve.
 // `info` receives (global column + 1) of the first non-positive pivot (LAPACK convention).
 // ------------------------------------------------------------------------------------------------
 
