@@ -1663,6 +1663,19 @@ __global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__
                                                       double* __restrict__ uvpart, int Qp) {
     __shared__ double ts[CU_MAXQ];
     const int lane = threadIdx.x & 63;
+    // mat-vec workgroups: the first eight entries of the wave's column of W' are requested before the LDS copy of t is
+    // waited for -- one memory round trip for both instead of two (this launch sits alone on the critical path)
+    const bool matvec = (int)blockIdx.x < Qp / 4;
+    const int kcol = blockIdx.x * 4 + (threadIdx.x >> 6);
+    double wv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (matvec) {
+        const double* col = W + (size_t)kcol * Qp;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = kcol + lane + 64 * u;
+            wv[u] = col[min(i, Qp - 1)] * ((i < Qp) ? 1.0 : 0.0);
+        }
+    }
     for (int i = threadIdx.x; i < Qp; i += 256) ts[i] = tpart[i];     // t = W' (P xi), advanced block by block by tvec_role
     __syncthreads();
     if ((int)blockIdx.x > Qp / 4) {
@@ -1701,10 +1714,12 @@ __global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__
         }
         return;
     }
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int k = kcol;
     const double* col = W + (size_t)k * Qp;
     double s = 0.0;
-    for (int i = k + lane; i < Qp; i += 64) s = fma(col[i], ts[i], s);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s = fma(wv[u], ts[min(k + lane + 64 * u, Qp - 1)], s);
+    for (int i = k + lane + 512; i < Qp; i += 64) s = fma(col[i], ts[i], s);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) mu[Qp - 1 - k] = s;
 }
@@ -1776,6 +1791,9 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
         // the sweep's phase stamps now, so that closing them at the end is stores only.
         StampFold fold = {0, 0, 0};
         if (all_stamps && tid >= 192) fold = stamp_fold_load(all_stamps, totals, tid - 192);
+        // what the closing thread needs besides the five sums, fetched with everything else (not after the reduction)
+        const double c_syy = sc[0], c_skk = sc[1], c_n = sc[2], c_w = P->W[0], c_sigma2 = P->sigma2, c_elogw = P->E_logw;
+        const int c_i0 = info[0], c_i1 = info[1], c_i2 = info[2];
         double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};         // tr(Kuu^-1 Psi2), tr(R Psi2), log|L_K|, log|L_Lambda|, b' mu
         for (int b = tid; b < nK; b += 256) v[0] += partK[b];
         for (int b = tid; b < nR; b += 256) v[1] += partR[b];
@@ -1796,15 +1814,15 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
 #pragma unroll
             for (int i = 0; i < 5; ++i) t[i] = (redn[i] + redn[5 + i]) + (redn[10 + i] + redn[15 + i]);
             const double LOG2PI = 1.8378770664093454835606594728112;
-            const double n = sc[2], w = P->W[0];
-            const double sum_I1 = P->sigma2 * sc[1] - t[0];
-            const double sum_I2 = sc[0] - 2.0 * t[4] + t[1];
+            const double n = c_n, w = c_w;
+            const double sum_I1 = c_sigma2 * c_skk - t[0];
+            const double sum_I2 = c_syy - 2.0 * t[4] + t[1];
             out[0] = sum_I1;
             out[1] = sum_I2;
-            out[2] = 0.5 * (w * (sum_I1 + sum_I2) - n * P->E_logw + n * LOG2PI);
-            out[3] = (double)info[0];
-            out[4] = (double)info[1];
-            out[5] = (double)info[2];
+            out[2] = 0.5 * (w * (sum_I1 + sum_I2) - n * c_elogw + n * LOG2PI);
+            out[3] = (double)c_i0;
+            out[4] = (double)c_i1;
+            out[5] = (double)c_i2;
             out[6] = 2.0 * t[2];
             out[7] = 2.0 * t[3];
         }
