@@ -203,11 +203,11 @@ __global__ void __launch_bounds__(256) k_gram_uf(const double* __restrict__ Xus,
                                                  int M, int Mp, int D, int64_t N, int d_out, int64_t* stamps,
                                                  int64_t* sweep_begin) {
     __shared__ double us[DCAP * TB];
-    stamp_enter(stamps);
     if (sweep_begin) {            // first kernel of a sweep whose parameters were already resident (no k_prep_xu in front)
         stamp_enter(sweep_begin + 0 * STAMP_STRIDE);          // SGP_T_SWEEP
         stamp_enter(sweep_begin + 7 * STAMP_STRIDE);          // SGP_T_LOCAL
     }
+    stamp_enter(stamps);
     __shared__ double xs[DCAP * TB];
     __shared__ double ys[MAXO * TB];
     __shared__ double red[16 * TB];

@@ -290,6 +290,30 @@ def test_resident_parameters_are_refreshed_by_every_setter(G):
         assert cnt >= 9 and all(t >= 0 for t in tot)                             # the phase stamps survived the skipped kernels
 
 
+def test_phase_stamps_of_the_last_sweep(G):
+    """sgp_get_timestamps: (begin, end) of every phase of the LAST sweep on the 100 MHz clock, kept by the sweep's closing
+    kernel; the sweep record spans the phases and agrees with the accumulated totals."""
+    N, M, D = 3000, 256, 4
+    X, Xu, y, _ = synth(N, M, D, seed=12)
+    with G.SGPDevice(N, M, D) as dev:
+        dev.set_inducing(Xu); dev.set_data(X, y); dev.set_kernel(1.0, np.full(D, 1.5), 1e-8); dev.set_prior_isotropic(50.0)
+        dev.set_noise([[10.0]])
+        for _ in range(3):
+            dev.sweep()
+        dev.phase_totals(reset=True)
+        dev.sweep()                                                     # a sweep that starts with the Gram kernel
+        ts = np.asarray(dev.timestamps(), dtype=np.int64).reshape(-1, 2)
+        tot, cnt = dev.phase_totals()
+    assert cnt == 1
+    SWEEP, GRAM, SYRK, FINISH1, FINISH2, LOCAL = 0, 1, 2, 3, 4, 7
+    for slot in (SWEEP, GRAM, SYRK, FINISH1, FINISH2, LOCAL):
+        b, e = ts[slot]
+        assert 0 < b < e < b + 100 * 1_000_000, (slot, b, e)            # set, ordered, shorter than a second
+    assert ts[SWEEP][0] <= ts[GRAM][0] and ts[LOCAL][1] <= ts[FINISH1][1] <= ts[SWEEP][1]
+    assert ts[GRAM][1] <= ts[SYRK][1] <= ts[LOCAL][1]
+    assert abs((ts[SWEEP][1] - ts[SWEEP][0]) / 100.0 - tot[SWEEP]) < 0.02   # the same sweep, in microseconds
+
+
 def test_two_phase_with_bound_statistics_buffer(G):
     """The multi-GPU hand-off on one GPU: two shards' statistics summed in a caller-owned buffer
     (what the RCCL all-reduce does), then the replicated finish."""
