@@ -619,14 +619,12 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// 1/sqrt(d): v_rsq_f64 seed (measured ~2^-25 relative on gfx950) + two Newton steps (rounding-limited).  One step
-// (-DSGP_RSQRT_ONE_STEP: ~1e-15 relative) was measured to buy < 0.5 % of the sweep, so the exact form stays.
+// 1/sqrt(d): v_rsq_f64 seed (measured ~2^-25 relative on gfx950) + two Newton steps (rounding-limited).  Off the pivot
+// chain: potf2_tile evaluates it once per 16 pivots, for all of them in parallel.
 __device__ __forceinline__ double rsqrt_nr(double d) {
     double y = __builtin_amdgcn_rsq(d);
     const double h = 0.5 * d;
-#ifndef SGP_RSQRT_ONE_STEP
     y = y * fma(-h * y, y, 1.5);
-#endif
     y = y * fma(-h * y, y, 1.5);
     return y;
 }
