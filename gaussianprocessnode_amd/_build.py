@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsgp_hip.so")
 SOURCES = [os.path.join(CSRC, "sgp_api.hip")]
-HEADERS = [os.path.join(CSRC, "sgp_kernels.hip.h"), os.path.join(os.path.dirname(HERE), "include", "sgp_hip.h")]
+HEADERS = [os.path.join(CSRC, "sgp_kernels.hip.h"), os.path.join(CSRC, "sgp_chain.hip.h"), os.path.join(os.path.dirname(HERE), "include", "sgp_hip.h")]
 
 
 def _hipcc() -> str:

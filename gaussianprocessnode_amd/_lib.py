@@ -15,6 +15,7 @@ from . import _build
 SGP_FLAG_NO_GRAPH = 1
 SGP_FLAG_KEEP_KUF = 2
 SGP_FLAG_GRAPH = 4
+SGP_FLAG_STEP_CHAIN = 8
 SGP_S_YY, SGP_S_W, SGP_S_N, SGP_S_COUNT = 0, 1, 2, 8
 (SGP_R_SUM_I1, SGP_R_SUM_I2, SGP_R_ENERGY, SGP_R_INFO_KUU, SGP_R_INFO_LAMBDA, SGP_R_INFO_PRIOR,
  SGP_R_LOGDET_KUU, SGP_R_LOGDET_LAMBDA, SGP_R_COUNT) = range(9)
@@ -26,7 +27,7 @@ EXPORTS = [
     "sgp_set_kernel", "sgp_set_output_cov_sum", "sgp_set_prior", "sgp_set_noise", "sgp_sweep_local", "sgp_sweep_finish", "sgp_sweep",
     "sgp_stats_layout", "sgp_bind_stats", "sgp_get_posterior", "sgp_get_scalars", "sgp_get_stats",
     "sgp_get_kuu_chol", "sgp_get_wishart_invscale", "sgp_w_stats", "sgp_predict", "sgp_theta_objective", "sgp_carry_posterior", "sgp_set_posterior",
-    "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_get_phase_totals", "sgp_time_kernel",
+    "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_get_phase_totals", "sgp_time_kernel", "sgp_get_chain_trace",
 ]
 
 
@@ -106,6 +107,7 @@ def load(build_if_missing: bool = True):
     lib.sgp_get_timestamps.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.sgp_get_phase_totals.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]
     lib.sgp_time_kernel.argtypes = [vp, C.c_int32, C.c_int32, vp, dp]
+    lib.sgp_get_chain_trace.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "sgp_last_error":

@@ -8,10 +8,12 @@
 // Per-sweep scalars travel through a pinned Params block that each sequence's first kernel mirrors on the device.
 #include "../../include/sgp_hip.h"
 #include "sgp_kernels.hip.h"
+#include "sgp_chain.hip.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -22,6 +24,11 @@ using namespace sgp;
 namespace {
 
 thread_local std::string g_create_error;
+
+// The persistent factorisation launches need ALL their workgroups resident at once (they wait for each other).  Two handles
+// sweeping at the same time could each hold part of the chip: a handle that starts a sweep while another one's may still
+// be running waits for the device first.
+sgp_handle* g_chain_owner = nullptr;
 
 struct Graph {
     hipGraph_t graph = nullptr;
@@ -60,6 +67,15 @@ struct sgp_handle {
     double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr, *dOut2 = nullptr, *dUvWork = nullptr;
     double *dGradM = nullptr, *dGradPart = nullptr, *dGrad = nullptr;   // theta-gradient scratch (allocated on first use)
     double* dSaccK = nullptr;      // K_uu chain: Sigma-style accumulator of K_uu^-1 = W_K^T W_K (see sigma_row_tile)
+    // persistent factorisation launch (sgp_chain.hip.h), one set per chain: [0] K_uu, [1] Lambda
+    bool use_chain = false;
+    long long* dChainFlags[2] = {nullptr, nullptr};
+    long long chain_epoch[2] = {0, 0};
+    long long gate_epoch = 0;      // value the sweep's SYRK stores into the gate word (see k_chain_gate)
+    bool gate_kuu = false;         // the K_uu chain of the sweep being enqueued waits behind the gate
+    double* dChainFar[2] = {nullptr, nullptr};
+    double* dChainRinv[2] = {nullptr, nullptr};
+    long long* dChainTrace[2] = {nullptr, nullptr};   // diagnostics, allocated when SGP_CHAIN_TRACE is set
     double* dCall = nullptr;       // scratch of the per-call outputs (sgp_predict, sgp_w_stats): grows, never shrinks
     size_t call_capacity = 0;
     int* dInfo = nullptr;
@@ -203,6 +219,33 @@ static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s
                        Kinv, trace_part, uv ? *uv : UvArgs{}, Sacc);
 }
 
+// The same factorisation (and ride-along roles) as launch_potrf, with the Cholesky itself as ONE persistent launch
+// (sgp_chain.hip.h).  `which`: 0 = K_uu chain (the matrix is evaluated from the scaled inducing inputs), 1 = Lambda chain
+// (evaluated from the statistics through `form`).  A receives L; Winv / Sacc / tv_* as in launch_potrf.
+static void launch_chain(sgp_handle* h, int which, double* A, int ld, int Tn, int* info, int n_valid, hipStream_t s, double* Winv,
+                         const LamForm* form, double* Sacc, const double* tv_xi, double* tv_t, const double* Xus,
+                         const Params* P, int M, int D) {
+    ChainArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = A; g.Ain = nullptr; g.ld = ld; g.Tn = Tn; g.info = info; g.n_valid = n_valid;
+    g.Winv = Winv; g.Far = h->dChainFar[which]; g.rinv_all = h->dChainRinv[which];
+    g.flags = h->dChainFlags[which]; g.epoch = ++h->chain_epoch[which];
+    g.trace = h->dChainTrace[which];
+    if (form) g.form = *form;
+    g.Xus = Xus; g.P = P; g.M = M; g.D = D;
+    hipLaunchKernelGGL(k_chol_chain, dim3(chain_blocks(Tn, Winv != nullptr)), dim3(CH_THREADS), 0, s, g);
+    if (!Winv) return;
+    for (int j = 1; j <= Tn; ++j) {
+        int e = 0;
+        if (j >= 2) {
+            e += 2 * (j - 1) * (j < Tn ? 2 : 1);
+            if (Sacc) e += (j - 1) * j / 2;
+        }
+        if (tv_t) e += 1;
+        if (e > 0) hipLaunchKernelGGL(k_chain_extras, dim3(e), dim3(256), 0, s, A, ld, j, Tn, Winv, Sacc, tv_xi, tv_t);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" int sgp_abi_version(void) { return SGP_ABI_VERSION; }
 
@@ -303,6 +346,29 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dParams, 1);
     ALLOC(h->dParamsK, 1);
     ALLOC(h->dXusK, Mp * h->D);
+    {
+        // one persistent launch per factorisation unless SGP_CHAIN=steps asks for the launch-per-step path (the fallback for
+        // matrices of more than CH_TMAX tile rows, for hipGraph mode and for the stand-alone building blocks)
+        const char* env = getenv("SGP_CHAIN");
+        const bool steps = env && strcmp(env, "steps") == 0;
+        h->use_chain = !steps && !(cfg->flags & (SGP_FLAG_GRAPH | SGP_FLAG_STEP_CHAIN)) && h->TQ <= CH_TMAX && h->T <= CH_TMAX;
+        if (h->use_chain) {
+            ALLOC(h->dChainFlags[0], CH_F_COUNT);
+            ALLOC(h->dChainFlags[1], CH_F_COUNT);
+            ALLOC(h->dChainFar[0], Mp * Mp);
+            ALLOC(h->dChainFar[1], Qp * Qp);
+            ALLOC(h->dChainRinv[0], Mp);
+            ALLOC(h->dChainRinv[1], Qp);
+            if (getenv("SGP_CHAIN_TRACE")) {
+                ALLOC(h->dChainTrace[0], CH_TMAX * 8);
+                ALLOC(h->dChainTrace[1], CH_TMAX * 8);
+                hipMemset(h->dChainTrace[0], 0, sizeof(long long) * CH_TMAX * 8);
+                hipMemset(h->dChainTrace[1], 0, sizeof(long long) * CH_TMAX * 8);
+            }
+            hipMemset(h->dChainFlags[0], 0, sizeof(long long) * CH_F_COUNT);
+            hipMemset(h->dChainFlags[1], 0, sizeof(long long) * CH_F_COUNT);
+        }
+    }
     if (cfg->flags & SGP_FLAG_KEEP_KUF) {
         ALLOC(h->dPa, (size_t)h->T * nmax);
         ALLOC(h->dPb, (size_t)h->T * nmax);
@@ -341,6 +407,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
     if (!h) return 0;
     hipSetDevice(h->cfg.device);
     hipDeviceSynchronize();
+    if (g_chain_owner == h) g_chain_owner = nullptr;
     h->gLocal.reset();
     h->gFinish.reset();
     h->gFinish2.reset();
@@ -349,7 +416,8 @@ extern "C" int sgp_destroy(sgp_handle* h) {
                     h->dDataScal, h->dKuu, h->dWk, h->dKinv, h->dLam, h->dWl, h->dSigma, h->dR, h->dTmp, h->dLambda0,
                     h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
                     h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals, h->dUvWork,
-                    h->dGradM, h->dGradPart, h->dGrad, h->dCall, h->dSaccK};
+                    h->dGradM, h->dGradPart, h->dGrad, h->dCall, h->dSaccK, h->dChainFlags[0], h->dChainFlags[1],
+                    h->dChainFar[0], h->dChainFar[1], h->dChainRinv[0], h->dChainRinv[1], h->dChainTrace[0], h->dChainTrace[1]};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evSide) hipEventDestroy(h->evSide);
@@ -580,8 +648,15 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, (const Params*)h->hParams,
                        h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0);
-    hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
-    launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk, nullptr, h->dSaccK);
+    if (h->use_chain) {
+        if (h->gate_kuu)
+            hipLaunchKernelGGL(k_chain_gate, dim3(1), dim3(64), 0, s, (const long long*)(h->dChainFlags[0] + CH_F_GATE), h->gate_epoch);
+        launch_chain(h, 0, h->dKuu, Mp, T, h->dInfo + 0, M, s, h->dWk, nullptr, h->dSaccK, nullptr, nullptr, h->dXusK,
+                     h->dParamsK, M, D);
+    } else {
+        hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
+        launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk, nullptr, h->dSaccK);
+    }
     launch_ata(h->dWk, h->dKinv, Mp, T, s, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->dSaccK);
 }
 
@@ -605,7 +680,8 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
                                h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, h->dStamps);
         hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                            h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, h->ntiles, h->nchunks,
-                           h->dStamps + STAMP_STRIDE * SGP_T_SYRK);
+                           h->dStamps + STAMP_STRIDE * SGP_T_SYRK, h->use_chain ? h->dChainFlags[0] + CH_F_GATE : nullptr,
+                           h->gate_epoch);
     }
     hipLaunchKernelGGL(k_assemble, dim3(T, T, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
                        h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
@@ -623,7 +699,10 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     form.M = M; form.Mp = Mp; form.d_out = h->dout; form.Q = Q; form.prior_form = h->prior_form;
     form.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
     double* uvt0 = h->dUvWork + 2 * (size_t)Qp;     // t = W' P xi, advanced block by block during the factorisation
-    launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + 3 * TB * TB, s, h->dWl, &form, h->dTmp, h->dXi, uvt0);
+    if (h->use_chain)
+        launch_chain(h, 1, h->dLam, Qp, TQ, h->dInfo + 1, Qp, s, h->dWl, &form, h->dTmp, h->dXi, uvt0, nullptr, nullptr, 0, 0);
+    else
+        launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + 3 * TB * TB, s, h->dWl, &form, h->dTmp, h->dXi, uvt0);
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
     // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
     double* uvp = h->dXi;                    // xi is consumed by the forward solve; p lands in the same vector afterwards
@@ -701,13 +780,20 @@ extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) {
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
+    if (h->use_chain) {
+        if (g_chain_owner && g_chain_owner != h) HIPCHK(h, hipDeviceSynchronize());
+        g_chain_owner = h;
+    }
     h->in_flight = true;
     // The K_uu chain depends on theta and Xu only: it starts on the (low-priority) side stream as soon as the previous
     // sweep has finished with its outputs, runs beside the data-sized kernels, the all-reduce and the Lambda chain, and is
     // joined just before the Sigma launch.  The main stream itself only ever WAITS on the side stream's event and records
     // one event at the very end of a sweep: an event record between two of its kernels was measured at ~6 us of idle time.
     HIPCHK(h, hipStreamWaitEvent(h->side, h->evDone, 0));
+    ++h->gate_epoch;
+    h->gate_kuu = h->use_chain && h->n > 0;                    // (a SYRK launch follows on the main stream and opens the gate)
     rc = run_sequence(h, h->gKuu, enqueue_kuu, h->side);
+    h->gate_kuu = false;
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->evSide, h->side));
     rc = run_sequence(h, h->gLocal, enqueue_local, s);
@@ -783,6 +869,8 @@ extern "C" int sgp_get_scalars(sgp_handle* h, double* out) {
     int rc = sync_all(h);
     if (rc) return rc;
     HIPCHK(h, hipMemcpy(out, h->dOut, SGP_R_COUNT * sizeof(double), hipMemcpyDeviceToHost));
+    if (out[SGP_R_INFO_KUU] < 0 || out[SGP_R_INFO_LAMBDA] < 0)
+        return fail(h, SGP_ERR_HIP, "the persistent factorisation launch gave up waiting (deadlock guard): its workgroups were not all resident; set SGP_CHAIN=steps");
     if (out[SGP_R_INFO_KUU] > 0) { h->err = "K_uu is not positive definite"; return (int)out[SGP_R_INFO_KUU]; }
     if (out[SGP_R_INFO_LAMBDA] > 0) {
         // Lambda is factored from its last row upwards: report the natural index of the failing pivot
@@ -800,6 +888,8 @@ extern "C" int sgp_get_posterior(sgp_handle* h, double* mu_v, double* Sigma_v, d
     if (rc) return rc;
     int info[4];
     HIPCHK(h, hipMemcpy(info, h->dInfo, sizeof info, hipMemcpyDeviceToHost));
+    if (info[0] < 0 || info[1] < 0)
+        return fail(h, SGP_ERR_HIP, "the persistent factorisation launch gave up waiting (deadlock guard): its workgroups were not all resident; set SGP_CHAIN=steps");
     if (info[0] > 0) { h->err = "K_uu is not positive definite"; return info[0]; }
     if (info[1] > 0) { h->err = "Lambda is not positive definite"; return std::max(1, h->Qp - info[1] + 1); }
     const int Q = h->Q, Qp = h->Qp;
@@ -865,6 +955,15 @@ extern "C" int sgp_get_timestamps(sgp_handle* h, int64_t* out) {
     return 0;
 }
 
+extern "C" int sgp_get_chain_trace(sgp_handle* h, int32_t which, int64_t* out) {
+    if (!h || !out || which < 0 || which > 1) return SGP_ERR_ARG;
+    if (!h->dChainTrace[which]) return fail(h, SGP_ERR_ARG, "sgp_get_chain_trace: create the handle with SGP_CHAIN_TRACE set in the environment");
+    int rc = sync_all(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(out, h->dChainTrace[which], sizeof(long long) * CH_TMAX * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int sgp_get_phase_totals(sgp_handle* h, int64_t* totals, int64_t* count, int32_t reset) {
     if (!h || !totals || !count) return SGP_ERR_ARG;
     int rc = sync_all(h);
@@ -899,7 +998,7 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
         else
             hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                                h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->chunk, h->ntiles, h->nchunks,
-                               (int64_t*)nullptr);
+                               (int64_t*)nullptr, (long long*)nullptr, 0LL);
     };
     if (which != SGP_T_GRAM && which != SGP_T_SYRK) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: which must be SGP_T_GRAM or SGP_T_SYRK");
     launch();
@@ -1094,6 +1193,16 @@ static int set_device_checked(int device) {
     return 0;
 }
 
+// device temporaries of the stand-alone building blocks: freed on every exit path
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+}  // namespace
+
 extern "C" int sgp_kernelmatrix(int32_t device, const double* A, int64_t na, const double* B, int64_t nb, int32_t d,
                                 double sigma2, const double* ell, int32_t n_ell, double* K) {
     if (!A || !B || !K || !ell || d < 1 || d > MAXD || (n_ell != 1 && n_ell != d) || na < 0 || nb < 0)
@@ -1106,20 +1215,19 @@ extern "C" int sgp_kernelmatrix(int32_t device, const double* A, int64_t na, con
     memset(&P, 0, sizeof P);
     P.sigma2 = sigma2;
     for (int i = 0; i < d; ++i) P.inv_ell[i] = 1.0 / ell[n_ell == 1 ? 0 : i];
-    double *dA = nullptr, *dB = nullptr, *dK = nullptr;
-    Params* dP = nullptr;
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dA), sizeof(double) * na * d));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dB), sizeof(double) * nb * d));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dK), sizeof(double) * na * nb));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dP), sizeof(Params)));
-    HIPCHK(h, hipMemcpy(dA, A, sizeof(double) * na * d, hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(dB, B, sizeof(double) * nb * d, hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(dP, &P, sizeof(Params), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kernelmatrix, dim3((unsigned)((na * nb + 255) / 256)), dim3(256), 0, 0, dA, dB, dK, dP, na, nb, d);
+    DevBuf bA, bB, bK, bP;
+    HIPCHK(h, bA.alloc(sizeof(double) * na * d));
+    HIPCHK(h, bB.alloc(sizeof(double) * nb * d));
+    HIPCHK(h, bK.alloc(sizeof(double) * na * nb));
+    HIPCHK(h, bP.alloc(sizeof(Params)));
+    HIPCHK(h, hipMemcpy(bA.p, A, sizeof(double) * na * d, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(bB.p, B, sizeof(double) * nb * d, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(bP.p, &P, sizeof(Params), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kernelmatrix, dim3((unsigned)((na * nb + 255) / 256)), dim3(256), 0, 0, bA.as<double>(), bB.as<double>(),
+                       bK.as<double>(), bP.as<Params>(), na, nb, d);
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpy(K, dK, sizeof(double) * na * nb, hipMemcpyDeviceToHost));
-    hipFree(dA); hipFree(dB); hipFree(dK); hipFree(dP);
+    HIPCHK(h, hipMemcpy(K, bK.p, sizeof(double) * na * nb, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1134,36 +1242,58 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
         if (j < n) memcpy(&tmp[(size_t)j * np], &A[(size_t)j * n], sizeof(double) * n);
         else tmp[(size_t)j * np + j] = 1.0;
     }
-    double *dA = nullptr, *dW = nullptr, *dC = nullptr;
-    int* dInfo = nullptr;
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dA), sizeof(double) * np * np));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dInfo), sizeof(int)));
-    HIPCHK(h, hipMemset(dInfo, 0, sizeof(int)));
-    HIPCHK(h, hipMemcpy(dA, tmp.data(), sizeof(double) * np * np, hipMemcpyHostToDevice));
-    double* dScr = nullptr;
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dScr), sizeof(double) * 3 * TB * TB));
-    HIPCHK(h, hipMemset(dScr, 0, sizeof(double) * 3 * TB * TB));
+    const size_t mat = sizeof(double) * np * np;
+    DevBuf bA, bInfo, bScr, bW, bC, bL, bFar, bRinv, bFlags;
+    HIPCHK(h, bA.alloc(mat));
+    HIPCHK(h, bInfo.alloc(sizeof(int)));
+    HIPCHK(h, hipMemset(bInfo.p, 0, sizeof(int)));
+    HIPCHK(h, hipMemcpy(bA.p, tmp.data(), mat, hipMemcpyHostToDevice));
     if (inverse) {
-        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dW), sizeof(double) * np * np));
-        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dC), sizeof(double) * np * np));
+        HIPCHK(h, bW.alloc(mat));
+        HIPCHK(h, bC.alloc(mat));
     }
-    launch_potrf(dA, np, Tn, dInfo, n, dScr, 0, dW);
-    const double* result = dA;
+    const char* env = getenv("SGP_CHAIN");
+    const bool chain = !(env && strcmp(env, "steps") == 0) && Tn <= CH_TMAX;
+    const double* factor = bA.as<double>();
+    if (chain) {
+        // one persistent launch (sgp_chain.hip.h); the factor goes to a buffer of its own (see ChainArgs::Ain)
+        if (g_chain_owner) HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, bL.alloc(mat));
+        HIPCHK(h, bFar.alloc(mat));
+        HIPCHK(h, bRinv.alloc(sizeof(double) * np));
+        HIPCHK(h, bFlags.alloc(sizeof(long long) * CH_F_COUNT));
+        HIPCHK(h, hipMemset(bL.p, 0, mat));
+        HIPCHK(h, hipMemset(bFlags.p, 0, sizeof(long long) * CH_F_COUNT));
+        ChainArgs g;
+        memset(&g, 0, sizeof g);
+        g.A = bL.as<double>(); g.Ain = bA.as<double>(); g.ld = np; g.Tn = Tn; g.info = bInfo.as<int>(); g.n_valid = n;
+        g.Winv = inverse ? bW.as<double>() : nullptr; g.Far = bFar.as<double>(); g.rinv_all = bRinv.as<double>();
+        g.flags = bFlags.as<long long>(); g.epoch = 1;
+        hipLaunchKernelGGL(k_chol_chain, dim3(chain_blocks(Tn, inverse)), dim3(CH_THREADS), 0, 0, g);
+        if (inverse)
+            for (int j = 2; j <= Tn; ++j)
+                hipLaunchKernelGGL(k_chain_extras, dim3(2 * (j - 1) * (j < Tn ? 2 : 1)), dim3(256), 0, 0, bL.as<double>(), np, j, Tn,
+                                   bW.as<double>(), (double*)nullptr, (const double*)nullptr, (double*)nullptr);
+        factor = bL.as<double>();
+    } else {
+        HIPCHK(h, bScr.alloc(sizeof(double) * 3 * TB * TB));
+        HIPCHK(h, hipMemset(bScr.p, 0, sizeof(double) * 3 * TB * TB));
+        launch_potrf(bA.as<double>(), np, Tn, bInfo.as<int>(), n, bScr.as<double>(), 0, bW.as<double>());
+    }
+    const double* result = factor;
     if (inverse) {
-        launch_ata(dW, dC, np, Tn, 0);
-        result = dC;
+        launch_ata(bW.as<double>(), bC.as<double>(), np, Tn, 0);
+        result = bC.as<double>();
     }
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipGetLastError());
     int info = 0;
-    HIPCHK(h, hipMemcpy(&info, dInfo, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&info, bInfo.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (info < 0) return fail(nullptr, SGP_ERR_HIP, "the persistent factorisation launch gave up waiting (deadlock guard)");
     HIPCHK(h, hipMemcpy2D(out, sizeof(double) * n, result, sizeof(double) * np, sizeof(double) * n, n, hipMemcpyDeviceToHost));
     if (!inverse)
         for (int j = 0; j < n; ++j)
             for (int i = 0; i < j; ++i) out[(size_t)j * n + i] = 0.0;
-    hipFree(dA); hipFree(dInfo); hipFree(dScr);
-    if (dW) hipFree(dW);
-    if (dC) hipFree(dC);
     if (info > 0) { g_create_error = "matrix is not positive definite"; return info; }
     return 0;
 }

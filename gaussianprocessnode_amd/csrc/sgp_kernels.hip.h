@@ -375,9 +375,14 @@ __device__ __forceinline__ void tile_from_index(int t, int& I, int& J) {
 
 __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
                                                      double* __restrict__ slabs, int Mp, int64_t N, int chunk,
-                                                     int ntiles, int nchunks, int64_t* stamps) {
+                                                     int ntiles, int nchunks, int64_t* stamps, long long* gate,
+                                                     long long gate_value) {
     __shared__ double lds[2 * 2 * KB * PS];           // [buf][panel A|B][KB][PS]
     stamp_enter(stamps);
+    // the last workgroup of this launch's single resident round is on a CU: whoever waited for that (k_chain_gate in front of
+    // the K_uu chain's persistent launch) may take the CUs that are left
+    if (gate && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        __hip_atomic_store(gate, gate_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     // XCD-aware block -> (tile, chunk) map: workgroups are dealt round-robin over the 8 XCDs, so ids congruent mod 8
     // share an L2.  All tiles of one point-chunk read the same K_uf columns: the work items, ordered chunk-major, are cut

@@ -31,10 +31,11 @@ class SGPDevice:
     """Owns the device buffers for (n_max points, M inducing points, D dims, d_out outputs)."""
 
     def __init__(self, n_max: int, m: int, d: int, d_out: int = 1, device: int = 0, use_graph: bool = False,
-                 keep_kuf: bool = False):
+                 keep_kuf: bool = False, step_chain: bool = False):
         self._lib = _lib.load()
         self._h = C.c_void_p()
-        flags = (_lib.SGP_FLAG_GRAPH if use_graph else 0) | (_lib.SGP_FLAG_KEEP_KUF if keep_kuf else 0)
+        flags = ((_lib.SGP_FLAG_GRAPH if use_graph else 0) | (_lib.SGP_FLAG_KEEP_KUF if keep_kuf else 0)
+                 | (_lib.SGP_FLAG_STEP_CHAIN if step_chain else 0))
         cfg = _lib.Config(n_max=int(n_max), m=int(m), d=int(d), d_out=int(d_out), device=int(device), flags=flags)
         check(self._lib.sgp_create(C.byref(cfg), C.byref(self._h)), None, "sgp_create")
         self.n_max, self.M, self.D, self.d_out, self.device = int(n_max), int(m), int(d), int(d_out), int(device)

@@ -37,7 +37,11 @@ extern "C" {
 #define SGP_FLAG_NO_GRAPH   1   /* launch kernels eagerly -- the default since eager launches measured ~20 us per sweep faster
                                  * than hipGraph replay at every size (tools/graph_vs_eager.py); kept as a no-op */
 #define SGP_FLAG_KEEP_KUF   2   /* keep K_uf resident for the per-point outputs (sgp_w_stats per_point) */
-#define SGP_FLAG_GRAPH      4   /* replay the launch sequences as captured hipGraphs (opt-in; bitwise the same results) */
+#define SGP_FLAG_GRAPH      4   /* replay the launch sequences as captured hipGraphs (opt-in; implies SGP_FLAG_STEP_CHAIN) */
+#define SGP_FLAG_STEP_CHAIN 8   /* factor K_uu and Lambda with one launch per 64-column step (the round-1 path) instead of one
+                                 * persistent launch per factorisation.  Also selected by the environment variable
+                                 * SGP_CHAIN=steps and, automatically, for matrices of more than 12 tile rows (d_out * M > 768).
+                                 * Both paths are deterministic; they differ from each other by rounding (left- vs right-looking). */
 
 typedef struct sgp_handle sgp_handle;
 
@@ -182,6 +186,11 @@ int sgp_get_timestamps(sgp_handle* h, int64_t* out /* 2*SGP_T_COUNT */);
 /* Running totals of the per-sweep phase durations (same slots, 100 MHz ticks) over all sweeps since the last reset, and
  * the number of sweeps counted: the per-launch averages of the kernels INSIDE the timed sweeps. */
 int sgp_get_phase_totals(sgp_handle* h, int64_t* totals /* SGP_T_COUNT */, int64_t* count, int32_t reset);
+/* Diagnostics of the persistent factorisation launch (csrc/sgp_chain.hip.h), recorded when the handle was created with the
+ * environment variable SGP_CHAIN_TRACE set: 12 steps x 8 ticks (100 MHz) of the critical workgroup during the last sweep --
+ * [0] step begins, [1] last pivot run of the diagonal tile done, [5] lower tile awaited, [2] lower tile arrived, [3] its
+ * last block solved, [4] its share of the next diagonal tile's update applied.  which: 0 = K_uu chain, 1 = Lambda chain. */
+int sgp_get_chain_trace(sgp_handle* h, int32_t which, int64_t* out /* 96 */);
 /* HIP-event timing of one data-sized kernel (which = SGP_T_GRAM or SGP_T_SYRK) launched eagerly `iters` times on
  * `stream` with the resident data of the last sweep; returns the average launch duration in microseconds. */
 int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void* stream, double* avg_us);

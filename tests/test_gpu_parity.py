@@ -229,8 +229,10 @@ def test_graph_replay_equals_eager_and_tracks_parameters(G):
     N, M, D = 700, 96, 3
     X, Xu, y, _ = synth(N, M, D, seed=3)
     outs = []
-    for use_graph in (True, False):
-        with G.SGPDevice(N, M, D, use_graph=use_graph) as dev:
+    # graph replay uses the launch-per-step factorisation (SGP_FLAG_STEP_CHAIN): compare it with eager launches of the same
+    # kernels bitwise, and with the default path (one persistent launch per factorisation) to rounding
+    for use_graph, step_chain in ((True, True), (False, True), (False, False)):
+        with G.SGPDevice(N, M, D, use_graph=use_graph, step_chain=step_chain) as dev:
             dev.set_inducing(Xu)
             dev.set_data(X, y)
             dev.set_prior_isotropic(50.0)
@@ -242,10 +244,12 @@ def test_graph_replay_equals_eager_and_tracks_parameters(G):
                 mu, Sig, Uv = dev.posterior()
                 res.append((mu, Sig, Uv, dev.scalars().energy))
             outs.append(res)
-    for a, b in zip(*outs):
-        for u, v in zip(a[:3], b[:3]):
+    for a, b, c in zip(*outs):
+        for u, v, x in zip(a[:3], b[:3], c[:3]):
             assert np.array_equal(u, v)          # same kernels, same order: bitwise equal
+            assert relF(x, v) < 1e-11            # the persistent launch factors right-looking: equal to rounding
         assert a[3] == b[3]
+        assert math.isclose(c[3], b[3], rel_tol=1e-10)
     assert np.array_equal(outs[0][0][0], outs[0][2][0])      # same parameters again -> same result
     assert not np.array_equal(outs[0][0][0], outs[0][1][0])
 
