@@ -15,7 +15,7 @@ from . import _build
 SGP_FLAG_NO_GRAPH = 1
 SGP_FLAG_KEEP_KUF = 2
 SGP_FLAG_GRAPH = 4
-SGP_FLAG_STEP_CHAIN = 8
+SGP_FLAG_PERSISTENT_CHAIN = 8
 SGP_S_YY, SGP_S_W, SGP_S_N, SGP_S_COUNT = 0, 1, 2, 8
 (SGP_R_SUM_I1, SGP_R_SUM_I2, SGP_R_ENERGY, SGP_R_INFO_KUU, SGP_R_INFO_LAMBDA, SGP_R_INFO_PRIOR,
  SGP_R_LOGDET_KUU, SGP_R_LOGDET_LAMBDA, SGP_R_COUNT) = range(9)
@@ -27,7 +27,7 @@ EXPORTS = [
     "sgp_set_kernel", "sgp_set_output_cov_sum", "sgp_set_prior", "sgp_set_noise", "sgp_sweep_local", "sgp_sweep_finish", "sgp_sweep",
     "sgp_stats_layout", "sgp_bind_stats", "sgp_get_posterior", "sgp_get_scalars", "sgp_get_stats",
     "sgp_get_kuu_chol", "sgp_get_wishart_invscale", "sgp_w_stats", "sgp_predict", "sgp_theta_objective", "sgp_carry_posterior", "sgp_set_posterior",
-    "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_get_phase_totals", "sgp_time_kernel", "sgp_get_chain_trace",
+    "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_get_phase_totals", "sgp_time_kernel", "sgp_get_chain_trace", "sgp_set_allreduce", "sgp_use_rccl", "sgp_measure_sclk_mhz",
 ]
 
 
@@ -47,6 +47,9 @@ class Config(C.Structure):
     _fields_ = [("n_max", C.c_int64), ("m", C.c_int32), ("d", C.c_int32), ("d_out", C.c_int32),
                 ("device", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
 
+
+# int hook(void* ctx, void* stats_dev, int64_t count, void* stream): the all-reduce step of sgp_sweep (include/sgp_hip.h)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 _lib = None
 
@@ -108,6 +111,9 @@ def load(build_if_missing: bool = True):
     lib.sgp_get_phase_totals.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]
     lib.sgp_time_kernel.argtypes = [vp, C.c_int32, C.c_int32, vp, dp]
     lib.sgp_get_chain_trace.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
+    lib.sgp_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    lib.sgp_use_rccl.argtypes = [vp, vp]
+    lib.sgp_measure_sclk_mhz.argtypes = [C.c_int32, dp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "sgp_last_error":

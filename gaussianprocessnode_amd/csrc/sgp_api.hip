@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -35,6 +36,7 @@ struct Graph {
     hipGraphExec_t exec = nullptr;
     int64_t key_n = -1;
     int key_prior = -1;
+    int key_omega = -1;
     void* key_stats = nullptr;
     bool valid = false;
     void reset() {
@@ -73,9 +75,15 @@ struct sgp_handle {
     long long chain_epoch[2] = {0, 0};
     long long gate_epoch = 0;      // value the sweep's SYRK stores into the gate word (see k_chain_gate)
     bool gate_kuu = false;         // the K_uu chain of the sweep being enqueued waits behind the gate
-    double* dChainFar[2] = {nullptr, nullptr};
-    double* dChainRinv[2] = {nullptr, nullptr};
+    double* dKuuAlt = nullptr;     // the other parity of dKuu / dLam: the launches alternate (see sgp_chain.hip.h, hand-offs)
+    double* dLamAlt = nullptr;
+    double* dChainFar[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};     // [chain][parity] mailbox matrices
+    double* dChainShip[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    double* dChainRinv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     long long* dChainTrace[2] = {nullptr, nullptr};   // diagnostics, allocated when SGP_CHAIN_TRACE is set
+    ChainArgs* dChainArgs[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [chain][parity]: the launches' argument structs
+    ChainArgs chain_args_shadow[2][2];                // what the device copies hold (rewritten only when something changes)
+    bool chain_args_valid[2][2] = {{false, false}, {false, false}};
     double* dCall = nullptr;       // scratch of the per-call outputs (sgp_predict, sgp_w_stats): grows, never shrinks
     size_t call_capacity = 0;
     int* dInfo = nullptr;
@@ -93,6 +101,9 @@ struct sgp_handle {
     int64_t stats_count = 0;
     size_t slab_capacity = 0;
     Graph gLocal, gFinish, gFinish2, gKuu;
+    sgp_allreduce_fn allreduce = nullptr;   // the multi-GPU exchange step of sgp_sweep (see include/sgp_hip.h)
+    void* allreduce_ctx = nullptr;
+    void* rccl_comm = nullptr;
     double ryy_data[MAXO * MAXO] = {0};   // sum omega y y' of the current data (without the output-covariance term)
     std::string err;
 };
@@ -222,18 +233,32 @@ static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s
 // The same factorisation (and ride-along roles) as launch_potrf, with the Cholesky itself as ONE persistent launch
 // (sgp_chain.hip.h).  `which`: 0 = K_uu chain (the matrix is evaluated from the scaled inducing inputs), 1 = Lambda chain
 // (evaluated from the statistics through `form`).  A receives L; Winv / Sacc / tv_* as in launch_potrf.
-static void launch_chain(sgp_handle* h, int which, double* A, int ld, int Tn, int* info, int n_valid, hipStream_t s, double* Winv,
-                         const LamForm* form, double* Sacc, const double* tv_xi, double* tv_t, const double* Xus,
+static void launch_chain(sgp_handle* h, int which, double* A, double* A_next, int ld, int Tn, int* info, int n_valid, hipStream_t s,
+                         double* Winv, const LamForm* form, double* Sacc, const double* tv_xi, double* tv_t, const double* Xus,
                          const Params* P, int M, int D) {
     ChainArgs g;
     memset(&g, 0, sizeof g);
-    g.A = A; g.Ain = nullptr; g.ld = ld; g.Tn = Tn; g.info = info; g.n_valid = n_valid;
-    g.Winv = Winv; g.Far = h->dChainFar[which]; g.rinv_all = h->dChainRinv[which];
-    g.flags = h->dChainFlags[which]; g.epoch = ++h->chain_epoch[which];
+    const int par = (int)(++h->chain_epoch[which] & 1);
+    g.A = A; g.A_next = A_next; g.ld = ld; g.Tn = Tn; g.info = info; g.n_valid = n_valid;
+    g.Far = h->dChainFar[which][par]; g.Far_next = h->dChainFar[which][par ^ 1];
+    g.Ship = h->dChainShip[which][par]; g.Ship_next = h->dChainShip[which][par ^ 1];
+    g.rinv_all = h->dChainRinv[which][par]; g.rinv_next = h->dChainRinv[which][par ^ 1];
+    g.Winv = Winv;
+    g.abortw = h->dChainFlags[which] + CH_F_ABORT + par;
+    g.abortw_next = h->dChainFlags[which] + CH_F_ABORT + (par ^ 1);
     g.trace = h->dChainTrace[which];
     if (form) g.form = *form;
     g.Xus = Xus; g.P = P; g.M = M; g.D = D;
-    hipLaunchKernelGGL(k_chol_chain, dim3(chain_blocks(Tn, Winv != nullptr)), dim3(CH_THREADS), 0, s, g);
+    // the device copy of the arguments changes rarely (statistics buffer rebound, prior form): rewritten only then, after
+    // waiting for whatever may still be reading it
+    if (!h->chain_args_valid[which][par] || memcmp(&g, &h->chain_args_shadow[which][par], sizeof g) != 0) {
+        hipDeviceSynchronize();
+        hipMemcpy(h->dChainArgs[which][par], &g, sizeof g, hipMemcpyHostToDevice);
+        h->chain_args_shadow[which][par] = g;
+        h->chain_args_valid[which][par] = true;
+    }
+    hipLaunchKernelGGL(k_chol_chain, dim3(chain_blocks(Tn, Winv != nullptr)), dim3(CH_THREADS), 0, s,
+                       (const ChainArgs*)h->dChainArgs[which][par]);
     if (!Winv) return;
     for (int j = 1; j <= Tn; ++j) {
         int e = 0;
@@ -347,26 +372,44 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dParamsK, 1);
     ALLOC(h->dXusK, Mp * h->D);
     {
-        // one persistent launch per factorisation unless SGP_CHAIN=steps asks for the launch-per-step path (the fallback for
-        // matrices of more than CH_TMAX tile rows, for hipGraph mode and for the stand-alone building blocks)
+        // opt-in: one persistent launch per factorisation (sgp_chain.hip.h) instead of one launch per 64-column step
         const char* env = getenv("SGP_CHAIN");
-        const bool steps = env && strcmp(env, "steps") == 0;
-        h->use_chain = !steps && !(cfg->flags & (SGP_FLAG_GRAPH | SGP_FLAG_STEP_CHAIN)) && h->TQ <= CH_TMAX && h->T <= CH_TMAX;
+        const bool persistent = (env && strcmp(env, "persistent") == 0) || (cfg->flags & SGP_FLAG_PERSISTENT_CHAIN);
+        h->use_chain = persistent && !(cfg->flags & SGP_FLAG_GRAPH) && h->TQ <= CH_TMAX && h->T <= CH_TMAX;
         if (h->use_chain) {
             ALLOC(h->dChainFlags[0], CH_F_COUNT);
             ALLOC(h->dChainFlags[1], CH_F_COUNT);
-            ALLOC(h->dChainFar[0], Mp * Mp);
-            ALLOC(h->dChainFar[1], Qp * Qp);
-            ALLOC(h->dChainRinv[0], Mp);
-            ALLOC(h->dChainRinv[1], Qp);
+            ALLOC(h->dKuuAlt, Mp * Mp);
+            ALLOC(h->dLamAlt, Qp * Qp);
+            for (int par = 0; par < 2; ++par) {
+                ALLOC(h->dChainFar[0][par], Mp * Mp);
+                ALLOC(h->dChainFar[1][par], Qp * Qp);
+                ALLOC(h->dChainShip[0][par], Mp * Mp);
+                ALLOC(h->dChainShip[1][par], Qp * Qp);
+                ALLOC(h->dChainRinv[0][par], Mp);
+                ALLOC(h->dChainRinv[1][par], Qp);
+                ALLOC(h->dChainArgs[0][par], 1);
+                ALLOC(h->dChainArgs[1][par], 1);
+            }
             if (getenv("SGP_CHAIN_TRACE")) {
-                ALLOC(h->dChainTrace[0], CH_TMAX * 8);
-                ALLOC(h->dChainTrace[1], CH_TMAX * 8);
-                hipMemset(h->dChainTrace[0], 0, sizeof(long long) * CH_TMAX * 8);
-                hipMemset(h->dChainTrace[1], 0, sizeof(long long) * CH_TMAX * 8);
+                ALLOC(h->dChainTrace[0], CH_TMAX * 32);
+                ALLOC(h->dChainTrace[1], CH_TMAX * 32);
+                hipMemset(h->dChainTrace[0], 0, sizeof(long long) * CH_TMAX * 32);
+                hipMemset(h->dChainTrace[1], 0, sizeof(long long) * CH_TMAX * 32);
             }
             hipMemset(h->dChainFlags[0], 0, sizeof(long long) * CH_F_COUNT);
             hipMemset(h->dChainFlags[1], 0, sizeof(long long) * CH_F_COUNT);
+            // every mailbox starts out full of sentinels; from then on each launch refills the other parity's
+            auto fill = [&](double* p, size_t n) {
+                hipLaunchKernelGGL(k_chain_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, p, n);
+            };
+            fill(h->dKuu, Mp * Mp); fill(h->dKuuAlt, Mp * Mp); fill(h->dLam, Qp * Qp); fill(h->dLamAlt, Qp * Qp);
+            for (int par = 0; par < 2; ++par) {
+                fill(h->dChainFar[0][par], Mp * Mp); fill(h->dChainFar[1][par], Qp * Qp);
+                fill(h->dChainShip[0][par], Mp * Mp); fill(h->dChainShip[1][par], Qp * Qp);
+                fill(h->dChainRinv[0][par], Mp); fill(h->dChainRinv[1][par], Qp);
+            }
+            hipDeviceSynchronize();
         }
     }
     if (cfg->flags & SGP_FLAG_KEEP_KUF) {
@@ -417,7 +460,11 @@ extern "C" int sgp_destroy(sgp_handle* h) {
                     h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
                     h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals, h->dUvWork,
                     h->dGradM, h->dGradPart, h->dGrad, h->dCall, h->dSaccK, h->dChainFlags[0], h->dChainFlags[1],
-                    h->dChainFar[0], h->dChainFar[1], h->dChainRinv[0], h->dChainRinv[1], h->dChainTrace[0], h->dChainTrace[1]};
+                    h->dChainFar[0][0], h->dChainFar[0][1], h->dChainFar[1][0], h->dChainFar[1][1],
+                    h->dChainShip[0][0], h->dChainShip[0][1], h->dChainShip[1][0], h->dChainShip[1][1],
+                    h->dChainRinv[0][0], h->dChainRinv[0][1], h->dChainRinv[1][0], h->dChainRinv[1][1],
+                    h->dChainTrace[0], h->dChainTrace[1], h->dKuuAlt, h->dLamAlt,
+                    h->dChainArgs[0][0], h->dChainArgs[0][1], h->dChainArgs[1][0], h->dChainArgs[1][1]};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evSide) hipEventDestroy(h->evSide);
@@ -585,8 +632,10 @@ extern "C" int sgp_set_prior(sgp_handle* h, const double* vec, const double* mat
     HIPCHK(h, hipMemsetAsync(h->dInfo + 2, 0, sizeof(int), s));
     launch_potrf(h->dTmp, h->Qp, h->TQ, h->dInfo + 2, h->Q, h->dScratch + 6 * TB * TB, s, h->dWl);
     launch_ata(h->dWl, h->dLambda0, h->Qp, h->TQ, s);
-    HIPCHK(h, hipMemcpyAsync(h->dMu, v.data(), Qp * sizeof(double), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_symv, dim3((h->Qp + 3) / 4), dim3(256), 0, s, h->dLambda0, h->dMu, h->dXi0, h->Qp, h->Qp);
+    // (the mean is staged in dXi and the factor in dTmp / dWl -- buffers every sweep rewrites before it reads them -- not in dMu:
+    // sgp_get_posterior, sgp_predict(mu_v = NULL) and the theta gradient read the last sweep's mean from there)
+    HIPCHK(h, hipMemcpyAsync(h->dXi, v.data(), Qp * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_symv, dim3((h->Qp + 3) / 4), dim3(256), 0, s, h->dLambda0, h->dXi, h->dXi0, h->Qp, h->Qp);
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     int info = 0;
@@ -612,6 +661,7 @@ extern "C" int sgp_carry_posterior(sgp_handle* h, void* stream) {
     HIPCHK(h, hipMemcpyAsync(h->dXi0, h->dXi, sizeof(double) * Qp, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipGetLastError());
     h->prior_form = 1;
+    h->in_flight = true;                       // (asynchronous: a following setter must wait for it before it touches the prior)
     return 0;
 }
 
@@ -651,7 +701,8 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     if (h->use_chain) {
         if (h->gate_kuu)
             hipLaunchKernelGGL(k_chain_gate, dim3(1), dim3(64), 0, s, (const long long*)(h->dChainFlags[0] + CH_F_GATE), h->gate_epoch);
-        launch_chain(h, 0, h->dKuu, Mp, T, h->dInfo + 0, M, s, h->dWk, nullptr, h->dSaccK, nullptr, nullptr, h->dXusK,
+        std::swap(h->dKuu, h->dKuuAlt);         // this launch's factor goes to the buffer the last one refilled with sentinels
+        launch_chain(h, 0, h->dKuu, h->dKuuAlt, Mp, T, h->dInfo + 0, M, s, h->dWk, nullptr, h->dSaccK, nullptr, nullptr, h->dXusK,
                      h->dParamsK, M, D);
     } else {
         hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
@@ -699,9 +750,10 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     form.M = M; form.Mp = Mp; form.d_out = h->dout; form.Q = Q; form.prior_form = h->prior_form;
     form.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
     double* uvt0 = h->dUvWork + 2 * (size_t)Qp;     // t = W' P xi, advanced block by block during the factorisation
-    if (h->use_chain)
-        launch_chain(h, 1, h->dLam, Qp, TQ, h->dInfo + 1, Qp, s, h->dWl, &form, h->dTmp, h->dXi, uvt0, nullptr, nullptr, 0, 0);
-    else
+    if (h->use_chain) {
+        std::swap(h->dLam, h->dLamAlt);
+        launch_chain(h, 1, h->dLam, h->dLamAlt, Qp, TQ, h->dInfo + 1, Qp, s, h->dWl, &form, h->dTmp, h->dXi, uvt0, nullptr, nullptr, 0, 0);
+    } else
         launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + 3 * TB * TB, s, h->dWl, &form, h->dTmp, h->dXi, uvt0);
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
     // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
@@ -746,6 +798,25 @@ static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
                        h->dStamps + STAMP_STRIDE * SGP_T_FINISH2, h->dStamps, h->dStampTotals);
 }
 
+static int set_device_checked(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, SGP_ERR_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(nullptr, SGP_ERR_ARG, "bad device ordinal");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, SGP_ERR_HIP, "hipSetDevice failed");
+    return 0;
+}
+
+// device temporaries of the stand-alone building blocks: freed on every exit path
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+}  // namespace
+
+
 typedef void (*enqueue_fn)(sgp_handle*, hipStream_t);
 
 static int run_sequence(sgp_handle* h, Graph& g, enqueue_fn fn, hipStream_t s) {
@@ -754,7 +825,8 @@ static int run_sequence(sgp_handle* h, Graph& g, enqueue_fn fn, hipStream_t s) {
         HIPCHK(h, hipGetLastError());
         return 0;
     }
-    if (!g.valid || g.key_n != h->n || g.key_prior != h->prior_form || g.key_stats != (void*)h->dStats) {
+    if (!g.valid || g.key_n != h->n || g.key_prior != h->prior_form || g.key_stats != (void*)h->dStats ||
+        g.key_omega != (int)h->has_omega) {
         g.reset();
         // capture on the library's own stream (the caller's stream may be the legacy default stream)
         HIPCHK(h, hipStreamBeginCapture(h->own, hipStreamCaptureModeThreadLocal));
@@ -762,7 +834,7 @@ static int run_sequence(sgp_handle* h, Graph& g, enqueue_fn fn, hipStream_t s) {
         hipError_t e = hipStreamEndCapture(h->own, &g.graph);
         if (e != hipSuccess) { h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return SGP_ERR_HIP; }
         HIPCHK(h, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-        g.key_n = h->n; g.key_prior = h->prior_form; g.key_stats = h->dStats; g.valid = true;
+        g.key_n = h->n; g.key_prior = h->prior_form; g.key_stats = h->dStats; g.key_omega = (int)h->has_omega; g.valid = true;
     }
     HIPCHK(h, hipGraphLaunch(g.exec, s));
     return 0;
@@ -824,7 +896,63 @@ extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
 extern "C" int sgp_sweep(sgp_handle* h, void* stream) {
     int rc = sgp_sweep_local(h, stream);
     if (rc) return rc;
+    if (h->allreduce) {
+        // the one exchange step: sum the packed statistics over the ranks, on the sweep's stream (the K_uu chain keeps
+        // running on the side stream meanwhile)
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
+        rc = h->allreduce(h->allreduce_ctx, h->dStats, h->stats_count, s);
+        if (rc) return fail(h, SGP_ERR_HIP, "sgp_sweep: the all-reduce hook failed");
+    }
     return sgp_sweep_finish(h, stream);
+}
+
+extern "C" int sgp_set_allreduce(sgp_handle* h, sgp_allreduce_fn fn, void* ctx) {
+    if (!h) return SGP_ERR_ARG;
+    if (int qrc = quiesce(h)) return qrc;
+    h->allreduce = fn;
+    h->allreduce_ctx = ctx;
+    return 0;
+}
+
+// ncclAllReduce(sendbuff, recvbuff, count, ncclDouble = 8, ncclSum = 0, comm, stream), looked up in the running process
+typedef int (*nccl_allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static nccl_allreduce_t g_nccl_allreduce = nullptr;
+static int rccl_hook(void* ctx, void* buf, int64_t count, void* stream) {
+    sgp_handle* h = static_cast<sgp_handle*>(ctx);
+    return g_nccl_allreduce(buf, buf, (size_t)count, /*ncclDouble*/ 8, /*ncclSum*/ 0, h->rccl_comm, static_cast<hipStream_t>(stream));
+}
+extern "C" int sgp_use_rccl(sgp_handle* h, void* nccl_comm) {
+    if (!h || !nccl_comm) return fail(h, SGP_ERR_ARG, "sgp_use_rccl: null argument");
+    if (!g_nccl_allreduce) g_nccl_allreduce = reinterpret_cast<nccl_allreduce_t>(dlsym(RTLD_DEFAULT, "ncclAllReduce"));
+    if (!g_nccl_allreduce) return fail(h, SGP_ERR_ARG, "sgp_use_rccl: no ncclAllReduce in this process (load librccl first)");
+    if (int qrc = quiesce(h)) return qrc;
+    h->rccl_comm = nccl_comm;
+    h->allreduce = rccl_hook;
+    h->allreduce_ctx = h;
+    return 0;
+}
+
+__global__ void k_clock_probe(long long* out, int iters) {
+    double a = 1.0 + threadIdx.x * 1e-9, b = 0.999999;
+    const long long c0 = (long long)__builtin_amdgcn_s_memtime(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) { a = fma(a, b, 1e-9); a = fma(a, b, 1e-9); a = fma(a, b, 1e-9); a = fma(a, b, 1e-9); }
+    const long long c1 = (long long)__builtin_amdgcn_s_memtime(), r1 = (long long)__builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = (long long)a; }
+}
+extern "C" int sgp_measure_sclk_mhz(int32_t device, double* mhz) {
+    if (!mhz) return SGP_ERR_ARG;
+    int rc = set_device_checked(device);
+    if (rc) return rc;
+    sgp_handle* h = nullptr;
+    DevBuf b;
+    HIPCHK(h, b.alloc(3 * sizeof(long long)));
+    hipLaunchKernelGGL(k_clock_probe, dim3(1024), dim3(256), 0, 0, b.as<long long>(), 20000);     // ~1 ms on every CU
+    hipLaunchKernelGGL(k_clock_probe, dim3(1024), dim3(256), 0, 0, b.as<long long>(), 20000);
+    HIPCHK(h, hipDeviceSynchronize());
+    long long v[3];
+    HIPCHK(h, hipMemcpy(v, b.p, sizeof v, hipMemcpyDeviceToHost));
+    *mhz = v[1] > 0 ? 100.0 * (double)v[0] / (double)v[1] : 0.0;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -870,7 +998,7 @@ extern "C" int sgp_get_scalars(sgp_handle* h, double* out) {
     if (rc) return rc;
     HIPCHK(h, hipMemcpy(out, h->dOut, SGP_R_COUNT * sizeof(double), hipMemcpyDeviceToHost));
     if (out[SGP_R_INFO_KUU] < 0 || out[SGP_R_INFO_LAMBDA] < 0)
-        return fail(h, SGP_ERR_HIP, "the persistent factorisation launch gave up waiting (deadlock guard): its workgroups were not all resident; set SGP_CHAIN=steps");
+        return fail(h, SGP_ERR_HIP, "the persistent factorisation launch gave up waiting (deadlock guard): its workgroups were not all resident");
     if (out[SGP_R_INFO_KUU] > 0) { h->err = "K_uu is not positive definite"; return (int)out[SGP_R_INFO_KUU]; }
     if (out[SGP_R_INFO_LAMBDA] > 0) {
         // Lambda is factored from its last row upwards: report the natural index of the failing pivot
@@ -889,7 +1017,7 @@ extern "C" int sgp_get_posterior(sgp_handle* h, double* mu_v, double* Sigma_v, d
     int info[4];
     HIPCHK(h, hipMemcpy(info, h->dInfo, sizeof info, hipMemcpyDeviceToHost));
     if (info[0] < 0 || info[1] < 0)
-        return fail(h, SGP_ERR_HIP, "the persistent factorisation launch gave up waiting (deadlock guard): its workgroups were not all resident; set SGP_CHAIN=steps");
+        return fail(h, SGP_ERR_HIP, "the persistent factorisation launch gave up waiting (deadlock guard): its workgroups were not all resident");
     if (info[0] > 0) { h->err = "K_uu is not positive definite"; return info[0]; }
     if (info[1] > 0) { h->err = "Lambda is not positive definite"; return std::max(1, h->Qp - info[1] + 1); }
     const int Q = h->Q, Qp = h->Qp;
@@ -960,7 +1088,7 @@ extern "C" int sgp_get_chain_trace(sgp_handle* h, int32_t which, int64_t* out) {
     if (!h->dChainTrace[which]) return fail(h, SGP_ERR_ARG, "sgp_get_chain_trace: create the handle with SGP_CHAIN_TRACE set in the environment");
     int rc = sync_all(h);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpy(out, h->dChainTrace[which], sizeof(long long) * CH_TMAX * 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out, h->dChainTrace[which], sizeof(long long) * CH_TMAX * 32, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1047,8 +1175,8 @@ extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) 
 // ------------------------------------------------------------------------------------------------
 template <int DT>
 static void launch_predict(sgp_handle* h, const double* dXs, const double* dMu, double* dMean, int64_t ns, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_predict<DT>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, h->dXus, dXs, dMu,
-                       dMean, h->dParams, h->M, h->Mp, h->D, ns, h->dout);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_predict<DT>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, h->dXusK, dXs, dMu,
+                       dMean, h->dParamsK, h->M, h->Mp, h->D, ns, h->dout);
 }
 
 extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const double* mu_v, double* mean) {
@@ -1070,9 +1198,12 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
         HIPCHK(h, hipMemcpy(dMuTmp, mu_v, sizeof(double) * h->Q, hipMemcpyHostToDevice));
         dMu = dMuTmp;
     }
-    hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, (const Params*)h->hParams,
-                       h->dParams, (int*)nullptr, h->M, h->Mp, h->D, (int64_t*)nullptr, 0, 0);
-    h->main_prep_gen = h->params_gen;                        // (this call synchronises before it returns)
+    // The CURRENT kernel parameters go into the K_uu chain's mirror (dParamsK / dXusK: every sweep rewrites it first thing), not
+    // into dParams / dXus: those must keep the values of the last sweep, which sgp_carry_posterior and the gradient of
+    // sgp_theta_objective at unchanged theta still read (a predict between set_noise and theta_objective scaled
+    // the gradient by w_new / w_old twice).
+    hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, (const Params*)h->hParams,
+                       h->dParamsK, (int*)nullptr, h->M, h->Mp, h->D, (int64_t*)nullptr, 0, 0);
     switch (h->D) {
         case 1: launch_predict<1>(h, dXs, dMu, dMean, ns, s); break;
         case 2: launch_predict<2>(h, dXs, dMu, dMean, ns, s); break;
@@ -1185,24 +1316,6 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
 // ------------------------------------------------------------------------------------------------
 // stand-alone building blocks (host in / host out, blocking)
 // ------------------------------------------------------------------------------------------------
-static int set_device_checked(int device) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, SGP_ERR_NODEVICE, "no HIP device visible");
-    if (device < 0 || device >= ndev) return fail(nullptr, SGP_ERR_ARG, "bad device ordinal");
-    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, SGP_ERR_HIP, "hipSetDevice failed");
-    return 0;
-}
-
-// device temporaries of the stand-alone building blocks: freed on every exit path
-namespace {
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-    template <typename T> T* as() const { return static_cast<T*>(p); }
-};
-}  // namespace
-
 extern "C" int sgp_kernelmatrix(int32_t device, const double* A, int64_t na, const double* B, int64_t nb, int32_t d,
                                 double sigma2, const double* ell, int32_t n_ell, double* K) {
     if (!A || !B || !K || !ell || d < 1 || d > MAXD || (n_ell != 1 && n_ell != d) || na < 0 || nb < 0)
@@ -1243,7 +1356,7 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
         else tmp[(size_t)j * np + j] = 1.0;
     }
     const size_t mat = sizeof(double) * np * np;
-    DevBuf bA, bInfo, bScr, bW, bC, bL, bFar, bRinv, bFlags;
+    DevBuf bA, bInfo, bScr, bW, bC, bL, bFar, bShip, bRinv, bFlags, bArgs;
     HIPCHK(h, bA.alloc(mat));
     HIPCHK(h, bInfo.alloc(sizeof(int)));
     HIPCHK(h, hipMemset(bInfo.p, 0, sizeof(int)));
@@ -1253,23 +1366,31 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
         HIPCHK(h, bC.alloc(mat));
     }
     const char* env = getenv("SGP_CHAIN");
-    const bool chain = !(env && strcmp(env, "steps") == 0) && Tn <= CH_TMAX;
+    const bool chain = env && strcmp(env, "persistent") == 0 && Tn <= CH_TMAX;
     const double* factor = bA.as<double>();
     if (chain) {
         // one persistent launch (sgp_chain.hip.h); the factor goes to a buffer of its own (see ChainArgs::Ain)
         if (g_chain_owner) HIPCHK(h, hipDeviceSynchronize());
         HIPCHK(h, bL.alloc(mat));
         HIPCHK(h, bFar.alloc(mat));
+        HIPCHK(h, bShip.alloc(mat));
         HIPCHK(h, bRinv.alloc(sizeof(double) * np));
         HIPCHK(h, bFlags.alloc(sizeof(long long) * CH_F_COUNT));
-        HIPCHK(h, hipMemset(bL.p, 0, mat));
         HIPCHK(h, hipMemset(bFlags.p, 0, sizeof(long long) * CH_F_COUNT));
+        const unsigned nb = (unsigned)(((size_t)np * np + 255) / 256);
+        hipLaunchKernelGGL(k_chain_fill, dim3(nb), dim3(256), 0, 0, bL.as<double>(), (size_t)np * np);
+        hipLaunchKernelGGL(k_chain_fill, dim3(nb), dim3(256), 0, 0, bFar.as<double>(), (size_t)np * np);
+        hipLaunchKernelGGL(k_chain_fill, dim3(nb), dim3(256), 0, 0, bShip.as<double>(), (size_t)np * np);
+        hipLaunchKernelGGL(k_chain_fill, dim3((np + 255) / 256), dim3(256), 0, 0, bRinv.as<double>(), (size_t)np);
         ChainArgs g;
         memset(&g, 0, sizeof g);
         g.A = bL.as<double>(); g.Ain = bA.as<double>(); g.ld = np; g.Tn = Tn; g.info = bInfo.as<int>(); g.n_valid = n;
-        g.Winv = inverse ? bW.as<double>() : nullptr; g.Far = bFar.as<double>(); g.rinv_all = bRinv.as<double>();
-        g.flags = bFlags.as<long long>(); g.epoch = 1;
-        hipLaunchKernelGGL(k_chol_chain, dim3(chain_blocks(Tn, inverse)), dim3(CH_THREADS), 0, 0, g);
+        g.Winv = inverse ? bW.as<double>() : nullptr; g.Far = bFar.as<double>(); g.Ship = bShip.as<double>();
+        g.rinv_all = bRinv.as<double>();
+        g.abortw = bFlags.as<long long>() + CH_F_ABORT;
+        HIPCHK(h, bArgs.alloc(sizeof(ChainArgs)));
+        HIPCHK(h, hipMemcpy(bArgs.p, &g, sizeof g, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_chol_chain, dim3(chain_blocks(Tn, inverse)), dim3(CH_THREADS), 0, 0, (const ChainArgs*)bArgs.as<ChainArgs>());
         if (inverse)
             for (int j = 2; j <= Tn; ++j)
                 hipLaunchKernelGGL(k_chain_extras, dim3(2 * (j - 1) * (j < Tn ? 2 : 1)), dim3(256), 0, 0, bL.as<double>(), np, j, Tn,
@@ -1289,6 +1410,19 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
     HIPCHK(h, hipGetLastError());
     int info = 0;
     HIPCHK(h, hipMemcpy(&info, bInfo.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (chain && getenv("SGP_CHAIN_DUMP")) {              // debugging aid: the mailbox matrices of this call, raw
+        std::vector<double> hb((size_t)np * np);
+        FILE* f = fopen(getenv("SGP_CHAIN_DUMP"), "wb");
+        if (f) {
+            int hdr[2] = {np, Tn};
+            fwrite(hdr, sizeof(int), 2, f);
+            for (void* src : {bL.p, bShip.p, bFar.p}) {
+                hipMemcpy(hb.data(), src, mat, hipMemcpyDeviceToHost);
+                fwrite(hb.data(), sizeof(double), hb.size(), f);
+            }
+            fclose(f);
+        }
+    }
     if (info < 0) return fail(nullptr, SGP_ERR_HIP, "the persistent factorisation launch gave up waiting (deadlock guard)");
     HIPCHK(h, hipMemcpy2D(out, sizeof(double) * n, result, sizeof(double) * np, sizeof(double) * n, n, hipMemcpyDeviceToHost));
     if (!inverse)

@@ -31,11 +31,11 @@ class SGPDevice:
     """Owns the device buffers for (n_max points, M inducing points, D dims, d_out outputs)."""
 
     def __init__(self, n_max: int, m: int, d: int, d_out: int = 1, device: int = 0, use_graph: bool = False,
-                 keep_kuf: bool = False, step_chain: bool = False):
+                 keep_kuf: bool = False, persistent_chain: bool = False):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         flags = ((_lib.SGP_FLAG_GRAPH if use_graph else 0) | (_lib.SGP_FLAG_KEEP_KUF if keep_kuf else 0)
-                 | (_lib.SGP_FLAG_STEP_CHAIN if step_chain else 0))
+                 | (_lib.SGP_FLAG_PERSISTENT_CHAIN if persistent_chain else 0))
         cfg = _lib.Config(n_max=int(n_max), m=int(m), d=int(d), d_out=int(d_out), device=int(device), flags=flags)
         check(self._lib.sgp_create(C.byref(cfg), C.byref(self._h)), None, "sgp_create")
         self.n_max, self.M, self.D, self.d_out, self.device = int(n_max), int(m), int(d), int(d_out), int(device)
@@ -85,6 +85,7 @@ class SGPDevice:
         ell = as_f64(np.atleast_1d(ell))
         check(self._lib.sgp_set_kernel(self._h, float(sigma2), ptr(ell), int(ell.size), float(jitter)), self._h,
               "sgp_set_kernel")
+        self._n_ell = int(ell.size)          # the C side writes 1 + n_ell gradient entries (sgp_theta_objective)
 
     def set_prior_meancov(self, mu0, Sigma0):
         mu0 = as_f64(np.reshape(mu0, (self.Q,)))
@@ -182,7 +183,12 @@ class SGPDevice:
         """neg_log_backwardmess_fast at the current kernel with q(v) fixed at the last sweep; optionally its gradient
         w.r.t. (sigma2, ell...)."""
         v = C.c_double()
-        g = np.empty(1 + (self.D if n_ell is None else n_ell)) if want_grad else None
+        have = getattr(self, "_n_ell", None)
+        if want_grad and have is None:
+            raise ValueError("theta_objective: call set_kernel first")
+        if n_ell is not None and have is not None and int(n_ell) != have:
+            raise ValueError(f"theta_objective: n_ell={n_ell} but the kernel was set with {have} lengthscale(s)")
+        g = np.empty(1 + have) if want_grad else None
         check(self._lib.sgp_theta_objective(self._h, C.cast(C.byref(v), C.POINTER(C.c_double)), ptr(g)), self._h,
               "sgp_theta_objective")
         return (v.value, g) if want_grad else v.value

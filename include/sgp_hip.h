@@ -37,19 +37,22 @@ extern "C" {
 #define SGP_FLAG_NO_GRAPH   1   /* launch kernels eagerly -- the default since eager launches measured ~20 us per sweep faster
                                  * than hipGraph replay at every size (tools/graph_vs_eager.py); kept as a no-op */
 #define SGP_FLAG_KEEP_KUF   2   /* keep K_uf resident for the per-point outputs (sgp_w_stats per_point) */
-#define SGP_FLAG_GRAPH      4   /* replay the launch sequences as captured hipGraphs (opt-in; implies SGP_FLAG_STEP_CHAIN) */
-#define SGP_FLAG_STEP_CHAIN 8   /* factor K_uu and Lambda with one launch per 64-column step (the round-1 path) instead of one
-                                 * persistent launch per factorisation.  Also selected by the environment variable
-                                 * SGP_CHAIN=steps and, automatically, for matrices of more than 12 tile rows (d_out * M > 768).
-                                 * Both paths are deterministic; they differ from each other by rounding (left- vs right-looking). */
+#define SGP_FLAG_GRAPH      4   /* replay the launch sequences as captured hipGraphs (opt-in; bitwise the same results) */
+#define SGP_FLAG_PERSISTENT_CHAIN 8   /* EXPERIMENTAL, opt-in (also: environment variable SGP_CHAIN=persistent): factor K_uu and
+                                 * Lambda with one persistent launch per factorisation (csrc/sgp_chain.hip.h) instead of one launch
+                                 * per 64-column step.  Correct and deterministic (it differs from the default by rounding: right- vs
+                                 * left-looking) but measured SLOWER on MI355X (24 vs 19.5 us per step at M = 512);
+                                 * ignored with SGP_FLAG_GRAPH and for matrices of more than 12 tile rows (d_out * M > 768). */
 
 typedef struct sgp_handle sgp_handle;
 
+/* Limits of this build (sgp_create returns SGP_ERR_ARG beyond them): 1 <= d <= 32 (LDS coordinate panels),
+ * 1 <= d_out <= 4 (register tiles of the MultiSGP reductions), d_out * m <= 4032 (LDS copy of the forward-solve vector). */
 typedef struct sgp_config {
     int64_t n_max;    /* capacity in points of this handle (this rank's shard) */
     int32_t m;        /* inducing points M                 */
     int32_t d;        /* input dimension D (1..32)         */
-    int32_t d_out;    /* outputs: 1 = UniSGP, >1 = MultiSGP (shared kernel) */
+    int32_t d_out;    /* outputs: 1 = UniSGP, 2..4 = MultiSGP (shared kernel) */
     int32_t device;   /* HIP device ordinal                */
     int32_t flags;    /* SGP_FLAG_*                        */
     int32_t reserved;
@@ -117,7 +120,27 @@ int sgp_set_noise(sgp_handle* h, const double* W, double E_log_w);
  * All calls are asynchronous on `stream`; results are fetched with sgp_get_*.  */
 int sgp_sweep_local(sgp_handle* h, void* stream);
 int sgp_sweep_finish(sgp_handle* h, void* stream);
-int sgp_sweep(sgp_handle* h, void* stream);                 /* local + finish (single GPU) */
+int sgp_sweep(sgp_handle* h, void* stream);                 /* local + [all-reduce hook] + finish */
+
+/* ---- multi-GPU: the one exchange step of a sweep --------------------------------------------
+ * Points are sharded over the ranks (one process = one GPU = one handle); Xu, theta and the prior are replicated.  The
+ * statistics are sums over points (the N-fold message product of GPnode/UniSGPnode.jl:62-63 and the sequential minibatch
+ * carry of experiments/regression_kin40k.ipynb:205-212 rely on the same additivity), so a sweep needs ONE sum-all-reduce of
+ * the packed statistics buffer (sgp_stats_layout) between its two halves.  With a hook installed, sgp_sweep does
+ *     local statistics  ->  hook(ctx, stats_dev, count, stream)  ->  replicated M^3 tail
+ * inside the library, on `stream`; the K_uu chain runs beside all three on the library's side stream.
+ * The hook must enqueue an in-place sum-all-reduce of `count` doubles at `stats_dev` on `stream` and return 0; it may be
+ * RCCL's ncclAllReduce (sgp_use_rccl), MPI on device buffers, torch.distributed through a ctypes callback, or a test double.
+ * fn = NULL removes the hook (single GPU). */
+typedef int (*sgp_allreduce_fn)(void* ctx, void* stats_dev, int64_t count, void* stream);
+int sgp_set_allreduce(sgp_handle* h, sgp_allreduce_fn fn, void* ctx);
+/* Convenience: all-reduce with RCCL on the communicator `nccl_comm` (an ncclComm_t created by the host program, e.g. with
+ * ncclCommInitRank over xGMI).  The library does not link RCCL: it looks ncclAllReduce up in the process (dlsym), so the
+ * RCCL the host program already loaded is the one that is used.  Returns SGP_ERR_ARG if no RCCL is loaded. */
+int sgp_use_rccl(sgp_handle* h, void* nccl_comm);
+/* shader clock the chip holds under a short FP64 load (MHz): Delta s_memtime / Delta s_memrealtime x 100 MHz (bench.py reports it
+ * next to the roofline fractions) */
+int sgp_measure_sclk_mhz(int32_t device, double* mhz);
 
 /* packed statistics buffer (device): [Psi2: Mp*Mp | B: Mp*d_out | scalars: SGP_S_COUNT (+ d_out*d_out Ryy)]
  * Mp = M rounded up to the tile size; count = total doubles to all-reduce. */
@@ -187,10 +210,14 @@ int sgp_get_timestamps(sgp_handle* h, int64_t* out /* 2*SGP_T_COUNT */);
  * the number of sweeps counted: the per-launch averages of the kernels INSIDE the timed sweeps. */
 int sgp_get_phase_totals(sgp_handle* h, int64_t* totals /* SGP_T_COUNT */, int64_t* count, int32_t reset);
 /* Diagnostics of the persistent factorisation launch (csrc/sgp_chain.hip.h), recorded when the handle was created with the
- * environment variable SGP_CHAIN_TRACE set: 12 steps x 8 ticks (100 MHz) of the critical workgroup during the last sweep --
- * [0] step begins, [1] last pivot run of the diagonal tile done, [5] lower tile awaited, [2] lower tile arrived, [3] its
- * last block solved, [4] its share of the next diagonal tile's update applied.  which: 0 = K_uu chain, 1 = Lambda chain. */
-int sgp_get_chain_trace(sgp_handle* h, int32_t which, int64_t* out /* 96 */);
+ * environment variable SGP_CHAIN_TRACE set: 12 steps x 32 ticks (100 MHz) during the last sweep.  Critical workgroup: [0] step
+ * begins, [1] last pivot run of the diagonal tile done, [5] lower tile awaited, [2] lower tile arrived, [3] its last block
+ * solved, [4] its share of the next diagonal tile's update applied, [6] / [7] waves 0 / 1 done with theirs, [8] far part of
+ * the next diagonal tile received.  Feeder whose shipment this step consumes: [13] accumulation done, [9] last block solved,
+ * [14] last product slice awaited, [10] ... done, [11] / [12] shipment stored by waves 0 / 4.
+ * [16 + 4 cb ..]: that feeder's wave 0 at column block cb: block in registers, solved, published, updates applied.
+ * which: 0 = K_uu chain, 1 = Lambda chain. */
+int sgp_get_chain_trace(sgp_handle* h, int32_t which, int64_t* out /* 384 */);
 /* HIP-event timing of one data-sized kernel (which = SGP_T_GRAM or SGP_T_SYRK) launched eagerly `iters` times on
  * `stream` with the resident data of the last sweep; returns the average launch duration in microseconds. */
 int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void* stream, double* avg_us);

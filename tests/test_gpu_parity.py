@@ -229,10 +229,10 @@ def test_graph_replay_equals_eager_and_tracks_parameters(G):
     N, M, D = 700, 96, 3
     X, Xu, y, _ = synth(N, M, D, seed=3)
     outs = []
-    # graph replay uses the launch-per-step factorisation (SGP_FLAG_STEP_CHAIN): compare it with eager launches of the same
-    # kernels bitwise, and with the default path (one persistent launch per factorisation) to rounding
-    for use_graph, step_chain in ((True, True), (False, True), (False, False)):
-        with G.SGPDevice(N, M, D, use_graph=use_graph, step_chain=step_chain) as dev:
+    # graph replay against eager launches of the same kernels: bitwise; against the opt-in persistent factorisation launch
+    # (SGP_FLAG_PERSISTENT_CHAIN, right-looking): to rounding
+    for use_graph, persistent in ((True, False), (False, False), (False, True)):
+        with G.SGPDevice(N, M, D, use_graph=use_graph, persistent_chain=persistent) as dev:
             dev.set_inducing(Xu)
             dev.set_data(X, y)
             dev.set_prior_isotropic(50.0)
@@ -247,9 +247,9 @@ def test_graph_replay_equals_eager_and_tracks_parameters(G):
     for a, b, c in zip(*outs):
         for u, v, x in zip(a[:3], b[:3], c[:3]):
             assert np.array_equal(u, v)          # same kernels, same order: bitwise equal
-            assert relF(x, v) < 1e-11            # the persistent launch factors right-looking: equal to rounding
+            assert relF(x, v) < 1e-9             # the persistent launch factors right-looking: equal to ~cond * eps
         assert a[3] == b[3]
-        assert math.isclose(c[3], b[3], rel_tol=1e-10)
+        assert math.isclose(c[3], b[3], rel_tol=1e-6)      # (the energy cancels against s_kk: cond(K_uu) * eps)
     assert np.array_equal(outs[0][0][0], outs[0][2][0])      # same parameters again -> same result
     assert not np.array_equal(outs[0][0][0], outs[0][1][0])
 
@@ -644,3 +644,114 @@ def test_large_m_and_empty_data(G):
     assert np.all(mu == 0.0) and np.abs(Sig - 50.0 * np.eye(M)).max() < 1e-12
     assert np.abs(Uv - math.sqrt(50.0) * np.eye(M)).max() < 1e-12
     assert sc.sum_I1 == 0.0 and sc.sum_I2 == 0.0 and sc.energy == 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+# The opt-in persistent factorisation launch (csrc/sgp_chain.hip.h, SGP_FLAG_PERSISTENT_CHAIN / SGP_CHAIN=persistent):
+# one critical workgroup keeps the diagonal and sub-diagonal tiles in LDS across the steps, helper workgroups feed it through
+# sentinel-tagged mailboxes.  Slower than the launch-per-step default on MI355X but it must stay right.
+@pytest.mark.parametrize("n", [1, 64, 100, 192, 300, 512, 700])
+def test_persistent_chain_potrf_potri(G, n, monkeypatch):
+    monkeypatch.setenv("SGP_CHAIN", "persistent")
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n))
+    A = A @ A.T / n + np.eye(n)
+    for _ in range(3):                               # (hand-off races show up as run-to-run differences)
+        L = G.potrf(A)
+        np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-10, atol=1e-12)
+        Ai = G.potri(A)
+        assert relF(Ai, np.linalg.inv(A)) < 1e-11
+
+
+def test_persistent_chain_sweep_matches_oracle_and_is_deterministic(G):
+    N, M, D, w = 1500, 512, 8, 1e4
+    X, Xu, y, _ = synth(N, M, D, seed=11)
+    s2, ell = 0.9, np.linspace(1.5, 3.0, D)
+    with G.SGPDevice(N, M, D, persistent_chain=True) as dev:
+        dev.set_inducing(Xu)
+        dev.set_data(X, y)
+        dev.set_kernel(s2, ell, 0.0)
+        dev.set_prior_isotropic(50.0)
+        dev.set_noise([[w]])
+        dev.sweep()
+        first = dev.posterior()
+        KuuL = dev.kuu_chol()
+        for _ in range(20):
+            dev.sweep()
+        again = dev.posterior()
+        sc = dev.scalars()
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+    ref = O.vmp_sweep(Xu, X, y, None, s2, ell, w, jitter=0.0, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
+    cond_L = np.linalg.cond(np.eye(M) / 50.0 + w * ref.stats.Psi2)
+    tol = min(1e-5, max(1e-9, 20 * np.finfo(float).eps * cond_L))
+    assert relF(KuuL, ref.KuuL) < 1e-9
+    assert relF(again[0], ref.mu_v) < tol and relF(again[1], ref.Sigma_v) < tol and relF(again[2], ref.Uv) < tol
+    assert abs(sc.energy - ref.energy) <= max(1e-7, tol) * abs(ref.energy) + 1e-6
+    assert sc.info_kuu == 0 and sc.info_lambda == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# Regression tests for state the C ABI exposes freely (round-1 advisor findings)
+def test_set_prior_meancov_after_a_sweep_leaves_the_posterior_alone(G):
+    N, M, D = 400, 70, 2
+    X, Xu, y, _ = synth(N, M, D, seed=5)
+    rng = np.random.default_rng(5)
+    B = rng.normal(size=(M, M))
+    S0 = B @ B.T / M + np.eye(M)
+    with G.SGPDevice(N, M, D) as dev:
+        dev.set_inducing(Xu); dev.set_data(X, y); dev.set_kernel(0.9, np.array([1.5, 2.0]), 1e-8)
+        dev.set_prior_isotropic(50.0); dev.set_noise([[20.0]])
+        dev.sweep()
+        before = dev.posterior()
+        pred_before = dev.predict(X[:50])
+        dev.set_prior_meancov(rng.normal(size=M), S0)        # factors S0 on the device: must not use the results as scratch
+        after = dev.posterior()
+        pred_after = dev.predict(X[:50])
+    for a, b in zip(before, after):
+        assert np.array_equal(a, b)
+    assert np.array_equal(pred_before, pred_after)
+
+
+def test_predict_between_set_noise_and_theta_objective_does_not_change_the_gradient(G):
+    N, M, D = 600, 96, 3
+    X, Xu, y, _ = synth(N, M, D, seed=8)
+    ell = np.array([1.2, 1.7, 2.2])
+    res = []
+    for with_predict in (False, True):
+        with G.SGPDevice(N, M, D) as dev:
+            dev.set_inducing(Xu); dev.set_data(X, y); dev.set_kernel(0.8, ell, 1e-8)
+            dev.set_prior_isotropic(50.0); dev.set_noise([[10.0]])
+            dev.sweep()
+            dev.set_noise([[35.0]])                          # the notebooks pass the UPDATED q(w) to the objective
+            if with_predict:
+                dev.predict(X[:20])
+            res.append(dev.theta_objective(want_grad=True))
+    (v0, g0), (v1, g1) = res
+    assert v0 == v1 and np.array_equal(g0, g1)
+    # and it is the gradient at w = 35 of the oracle objective (central differences)
+    ref = O.vmp_sweep(Xu, X, y, None, 0.8, ell, 10.0, jitter=1e-8, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
+    f = lambda s2, l: O.theta_objective(Xu, X, y, s2, l, ref.mu_v, ref.Uv, 35.0, jitter=1e-8)
+    h = 1e-5
+    num = [(f(0.8 + h, ell) - f(0.8 - h, ell)) / (2 * h)]
+    for d in range(D):
+        e = np.zeros(D); e[d] = h
+        num.append((f(0.8, ell + e) - f(0.8, ell - e)) / (2 * h))
+    np.testing.assert_allclose(g1, num, rtol=2e-5, atol=1e-6 * abs(v1))
+
+
+def test_theta_objective_gradient_length_follows_the_kernel(G):
+    N, M, D = 200, 40, 3
+    X, Xu, y, _ = synth(N, M, D, seed=2)
+    with G.SGPDevice(N, M, D) as dev:
+        dev.set_inducing(Xu); dev.set_data(X, y); dev.set_prior_isotropic(50.0); dev.set_noise([[10.0]])
+        dev.set_kernel(0.8, np.array([1.5]), 1e-8)           # isotropic: 1 + 1 entries
+        dev.sweep()
+        _, g = dev.theta_objective(want_grad=True)
+        assert g.shape == (2,) and np.all(np.isfinite(g))
+        with pytest.raises(ValueError):
+            dev.theta_objective(want_grad=True, n_ell=3)
+        dev.set_kernel(0.8, np.array([1.5, 1.6, 1.7]), 1e-8)  # ARD: 1 + D
+        dev.sweep()
+        _, g = dev.theta_objective(want_grad=True)
+        assert g.shape == (4,) and np.all(np.isfinite(g))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Quick check of the persistent factorisation launch through the stand-alone building blocks (sgp_potrf / sgp_potri)
 against NumPy, for every tile count it supports, then one sweep against the oracle."""
-import os, sys, time
+import os, sys
+os.environ.setdefault("SGP_CHAIN", "persistent"), time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
