@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- VMP iterations/sec of the sparse-GP node's sweep on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload T|C2|C3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload T|C2|C3|N1M]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -31,6 +31,9 @@ WORKLOADS = {
     "T": (10000, 512, 8),
     "C2": (10000, 256, 8),
     "C3": (40000, 512, 8),
+    # scaling workload: at T the replicated M^3 tail caps strong scaling at ~1.35x on 8 GPUs; the >= 6x
+    # regime of the north star needs the data-sized kernels to dominate
+    "N1M": (1000000, 512, 8),
 }
 # trained kin40k hyper-parameters (softplus(theta_opt), experiments/regression_kin40k.ipynb:255-263)
 SIGMA2 = 0.17636613718898136
@@ -39,6 +42,20 @@ ELL = np.array([2.994391934274809, 2.905302600576806, 1.7401945529137626, 2.2697
 W_BAR = 1e4            # experiments/regression_kin40k.ipynb:118
 PRIOR_VAR = 50.0       # :203-204
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (AMD spec; tools/mfma_f64_probe.hip saturates at ~49)
+PIVOT_CYCLES = 127             # dependent cycles per pivot of the factorisation's inner loop: the chains' floor
+
+
+def pmc_traffic(workload, world):
+    """HBM/fabric bytes per SYRK launch from this round's rocprofv3 --pmc passes (tools/measure_round.sh writes the file next to
+    the raw summaries it was computed from; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane reads)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None, None
+    if rec.get("workload") != workload or rec.get("n_gpus") != world:
+        return None, None
+    return rec.get("traffic_bytes_per_launch"), {k: rec.get(k) for k in ("fetch_size_bytes", "write_size_bytes", "commit", "source")}
 
 
 def synthetic(N, M, D, seed=1, n_test=2000):
@@ -59,8 +76,8 @@ def synthetic(N, M, D, seed=1, n_test=2000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="T", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -91,6 +108,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     N, M, D = WORKLOADS[args.workload]
+    if args.steps is None:
+        args.steps = 300 if N <= 100000 else 20
+    if args.warmup is None:
+        args.warmup = 30 if N <= 100000 else 3
     X, Xu, y, Xt, yt = synthetic(N, M, D)
     lo, hi = shard_bounds(N, world, rank)
 
@@ -136,10 +157,16 @@ def main():
     syrk_us = tick_us(_lib.SGP_T_SYRK)
     n_loc = hi - lo
     syrk_flops = float(n_loc) * M * (M + 1)                     # SYRK lower half n M (M+1)
-    achieved = syrk_flops / (syrk_us * 1e-6) / 1e12
-    # HBM traffic of the same kernel: separate rocprofv3 --pmc passes (profiles/r01_pmc_*_T.txt), FETCH_SIZE doubled as
-    # MI355X_MICROARCH.md prescribes for 16-B-per-lane streaming reads; only valid for the workload it was measured on
-    PMC_TRAFFIC = {("T", 1): 2 * 24.008e6 + 30.691e6}
+    # `achieved` is priced at the HIP-event duration of the kernel launched alone (the clock rocprofv3 --kernel-trace --stats
+    # shows for it too: profiles/r02_bench_T_kernel_stats.csv); the in-sweep figure, with the K_uu chain beside it, rides along
+    achieved = syrk_flops / (syrk_us_alone * 1e-6) / 1e12
+    traffic, traffic_src = pmc_traffic(args.workload, world)
+    import ctypes as C
+    sclk = C.c_double()
+    _lib.check(dev._lib.sgp_measure_sclk_mhz(local_rank, C.byref(sclk)), None, "sgp_measure_sclk_mhz")
+    f1_us = tick_us(_lib.SGP_T_FINISH1)
+    Qp = (M + 63) // 64 * 64
+    chain_floor_us = Qp * PIVOT_CYCLES / sclk.value              # the pivots of one factorisation, nothing else
 
     out = {
         "metric": "VMP iterations/sec (sparse-GP node sweep, kin40k-shaped synthetic)",
@@ -156,15 +183,28 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: N={N} M={M} D={D} UniSGP regression, ARD-SE kernel at the trained kin40k "
                                f"hyper-parameters, w=1e4, prior N(0,50I), jitter 0",
-                   "points_per_gpu": n_loc, "parallelism": f"data-sharded x{world}, 1 all-reduce of {eng.stats.numel()} f64"},
+                   "points_per_gpu": n_loc, "parallelism": f"data-sharded x{world}, 1 all-reduce of {eng.stats.numel()} f64",
+                   "variant": "W' trace form (SURVEY.md Appendix A): sum I1 / sum I2 from the reduced statistics, no per-point "
+                              "TRSM / TRMM (their 2 n M^2 flop are not part of the timed sweep)",
+                   "collective": {"backend": sweep.backend, "world_size_seen": sweep.world,
+                                  "where": "inside sgp_sweep (C ABI all-reduce hook) on the sweep's stream" if sweep.hooked
+                                           else "none (single rank)"}},
+        "sclk_mhz": sclk.value,
         "roofline": {"kernel": "k_syrk_stream (Psi2 = K_uf K_uf^T, v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": PMC_TRAFFIC.get((args.workload, world)),
-                     "launch_us_in_timed_region": syrk_us, "launches_averaged": int(n_counted),
-                     "launch_us_alone_hip_events": syrk_us_alone,
-                     "achieved_alone": syrk_flops / (syrk_us_alone * 1e-6) / 1e12,
+                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "clock": "HIP events around 10 eager launches of the kernel alone on the sweep's stream (the duration "
+                              "rocprofv3 --kernel-trace --stats reports for it)",
+                     "launch_us": syrk_us_alone, "launch_us_in_timed_region": syrk_us, "launches_averaged": int(n_counted),
+                     "achieved_in_timed_region": syrk_flops / (syrk_us * 1e-6) / 1e12 if syrk_us > 0 else None,
                      "algorithmic_flops_per_launch": syrk_flops,
-                     "peak_note": "78.6 = MI355X FP64 matrix spec; a back-to-back MFMA loop (tools/mfma_f64_probe.hip) saturates at 49, v_fma_f64 at 63-67"},
+                     "peak_note": "78.6 = MI355X FP64 matrix spec; a back-to-back MFMA loop (tools/mfma_f64_probe.hip) saturates at "
+                                  "49 at the sclk above, v_fma_f64 at 63-67"},
+        # the sweep's critical path is the Lambda factorisation chain: latency-bound, priced against its pivot floor
+        "roofline_chain": {"kernel": "k_potrf_step x (M/64 + 1) + k_trmv_mu_scan (Lambda = L L^T, inverse factor, Sigma rows, t, mu)",
+                           "bound": "latency (dependent pivot chain)", "achieved_us": f1_us, "floor_us": chain_floor_us,
+                           "frac": chain_floor_us / f1_us if f1_us > 0 else None,
+                           "model": f"{Qp} pivots x {PIVOT_CYCLES} dependent cycles at sclk"},
         # second data-sized kernel (SURVEY.md §8d asks for HBM GB/s on K_uf): k_gram_uf writes 8 n Mp bytes of K_uf once
         "roofline_k_uf": {"kernel": "k_gram_uf (K_uf assembly, coalesced 32-B stores)", "bound": "hbm",
                           "achieved": 8.0 * n_loc * dev.stats_layout()[2] / (tick_us(_lib.SGP_T_GRAM) * 1e-6) / 1e9,
@@ -204,7 +244,9 @@ def main():
         ctx = threadpool_limits(limits=cores) if threadpool_limits else None
         if ctx:
             ctx.__enter__()
+        t_ref0 = time.perf_counter()
         ref = cpu_sweep()
+        t_ref = time.perf_counter() - t_ref0
         out["parity"] = {
             "mu_v_rel_frobenius": float(np.linalg.norm(mu - ref.mu_v) / np.linalg.norm(ref.mu_v)),
             "Sigma_v_rel_frobenius": float(np.linalg.norm(Sig - ref.Sigma_v) / np.linalg.norm(ref.Sigma_v)),
@@ -214,7 +256,7 @@ def main():
             "tolerance": 1e-5,
         }
         if world == 1 and not args.no_cpu_baseline:
-            reps, t_cpu = 0, 0.0
+            reps, t_cpu = (1, t_ref) if t_ref > 5.0 else (0, 0.0)   # (one sweep at N = 1e6 is the whole bounded sample)
             while t_cpu < 10.0 and reps < 100:                   # bounded sample: ~10 s of CPU work
                 t1 = time.perf_counter()
                 cpu_sweep()
@@ -226,6 +268,8 @@ def main():
             # the reference's algorithmic shape (one rank-1 M x M message + fold + TRSV per point, one thread):
             # oracle/sgp_oracle.c on two bounded samples, extrapolated linearly in N to the full workload
             try:
+                if N > 100000:
+                    raise RuntimeError("skipped at this size")
                 from oracle import c_oracle
                 ts = []
                 for ns in (100, 250):
@@ -243,6 +287,8 @@ def main():
                 out["cpu_baseline_per_point"] = {"error": repr(e)}
             # SMSE on the real kin40k data (tests/golden): one sweep with the reference's Xu / theta_opt, first M inducing points
             try:
+                if N > 100000:
+                    raise RuntimeError("skipped at this size")
                 gold = os.path.join(ROOT, "tests", "golden")
                 fx, kd = np.load(os.path.join(gold, "kin40k_fixture.npz")), np.load(os.path.join(gold, "kin40k_data.npz"))
                 s2k, ellk = O.kernel_from_theta(fx["theta_opt"], softplus_params=True)

@@ -114,6 +114,29 @@ class SGPDevice:
     def sweep_finish(self, stream: int = 0):
         check(self._lib.sgp_sweep_finish(self._h, C.c_void_p(stream)), self._h, "sgp_sweep_finish")
 
+    def set_allreduce(self, fn):
+        """Install (fn = None: remove) the multi-GPU exchange step of `sweep`: fn(stats_dev_ptr, count, stream) must enqueue an
+        in-place sum-all-reduce of `count` doubles on `stream` (include/sgp_hip.h, sgp_set_allreduce)."""
+        if fn is None:
+            self._allreduce_cb = None
+            check(self._lib.sgp_set_allreduce(self._h, _lib.ALLREDUCE_FN(0), None), self._h, "sgp_set_allreduce")
+            return
+
+        def hook(ctx, buf, count, stream):
+            try:
+                fn(int(buf), int(count), int(stream or 0))
+                return 0
+            except Exception:                              # pragma: no cover  (reported through the status code)
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._allreduce_cb = _lib.ALLREDUCE_FN(hook)        # keep the trampoline alive as long as it is installed
+        check(self._lib.sgp_set_allreduce(self._h, self._allreduce_cb, None), self._h, "sgp_set_allreduce")
+
+    def use_rccl(self, comm_ptr: int):
+        """All-reduce with RCCL on an ncclComm_t the host program created (sgp_use_rccl)."""
+        check(self._lib.sgp_use_rccl(self._h, C.c_void_p(comm_ptr)), self._h, "sgp_use_rccl")
+
     def sweep(self, stream: int = 0):
         check(self._lib.sgp_sweep(self._h, C.c_void_p(stream)), self._h, "sgp_sweep")
 

@@ -97,6 +97,20 @@ class HipEngine:
     def sweep_finish(self):
         self.dev.sweep_finish(self.stream.cuda_stream)
 
+    def install_allreduce(self, reduce_fn):
+        """Make the exchange step part of the library's `sgp_sweep` (include/sgp_hip.h, sgp_set_allreduce): `reduce_fn()` must
+        all-reduce `self.stats` in place, ordered on `self.stream`."""
+        ptr = self.stats.data_ptr()
+
+        def hook(buf, count, stream):
+            assert buf == ptr and count == self.stats.numel(), "the library reduces the buffer bound with bind_stats"
+            reduce_fn()
+        self.dev.set_allreduce(hook)
+
+    def sweep(self):
+        """local statistics -> installed all-reduce hook -> replicated tail: ONE library call."""
+        self.dev.sweep(self.stream.cuda_stream)
+
     def synchronize(self):
         self.torch.cuda.synchronize()
 
@@ -117,21 +131,33 @@ class ShardedSweep:
         import torch.distributed as dist
         self.dist = dist
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.backend = dist.get_backend(group) if self.world > 1 else "none"
+        # Engines that run the exchange step inside their own sweep (HipEngine: the C ABI's all-reduce hook) get the
+        # collective installed once; the others are driven half by half.
+        self.hooked = self.world > 1 and hasattr(engine, "install_allreduce")
+        if self.hooked:
+            engine.install_allreduce(self._reduce)
 
-    def sweep(self):
+    def _reduce(self):
+        # issued inside the engine's stream context: the collective is ordered after the local kernels and before the
+        # replicated tail on that stream
         ctx = self.engine.stream_context() if hasattr(self.engine, "stream_context") else None
         if ctx is not None:
             ctx.__enter__()
         try:
-            self.engine.sweep_local()
-            if self.world > 1:
-                # issued inside the engine's stream context: the collective is ordered after the local kernels and before
-                # the replicated tail on that stream
-                self.dist.all_reduce(self.engine.stats, op=self.dist.ReduceOp.SUM, group=self.group)
-            self.engine.sweep_finish()
+            self.dist.all_reduce(self.engine.stats, op=self.dist.ReduceOp.SUM, group=self.group)
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
+
+    def sweep(self):
+        if self.hooked or (self.world == 1 and hasattr(self.engine, "sweep")):
+            self.engine.sweep()
+            return
+        self.engine.sweep_local()
+        if self.world > 1:
+            self._reduce()
+        self.engine.sweep_finish()
 
     def theta_objective(self, n_ell=None):
         """neg_log_backwardmess_fast and its gradient over ALL shards (helper_functions/derivative_helper.jl:23-39,55-63):

@@ -94,6 +94,18 @@ class OracleShardEngine:
         self.res = O.vmp_sweep(self.Xu, None, None, None, self.s2, self.ell, self.w, jitter=self.jitter,
                                Lambda0=np.eye(self.M) / self.prior_var, xi0=np.zeros(self.M), stats=st)
 
+    # the C ABI's form of the N > 1 path (include/sgp_hip.h, sgp_set_allreduce): the exchange step is a hook INSIDE the sweep
+    def install_allreduce(self, reduce_fn):
+        self._hook = reduce_fn
+        self.hook_calls = 0
+
+    def sweep(self):
+        self.sweep_local()
+        if getattr(self, "_hook", None) is not None:
+            self._hook()
+            self.hook_calls += 1
+        self.sweep_finish()
+
     def theta_objective_local(self, n_ell=None):
         """This shard's terms of neg_log_backwardmess_fast at the replicated q(v), gradient by central differences."""
         r = self.res

@@ -755,3 +755,62 @@ def test_theta_objective_gradient_length_follows_the_kernel(G):
         dev.sweep()
         _, g = dev.theta_objective(want_grad=True)
         assert g.shape == (4,) and np.all(np.isfinite(g))
+
+
+def test_sweep_with_the_allreduce_hook_inside_the_library(G):
+    """The C ABI's multi-GPU form (sgp_set_allreduce): ONE sgp_sweep call = local statistics -> hook -> replicated tail.  On one GPU
+    the hook adds the statistics of the other shard (computed beforehand by a second handle) -- what a sum-all-reduce over two
+    ranks leaves in the buffer -- on the sweep's own stream."""
+    torch = pytest.importorskip("torch")
+    N, M, D = 900, 80, 2
+    X, Xu, y, _ = synth(N, M, D, seed=22)
+    s2, ell, w = 1.0, np.array([1.3, 0.8]), 50.0
+    ref = O.vmp_sweep(Xu, X, y, None, s2, ell, w, jitter=1e-8, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
+    cut = 350
+
+    def make(sl):
+        d = G.SGPDevice(N, M, D)
+        d.set_inducing(Xu); d.set_data(X[sl], y[sl]); d.set_kernel(s2, ell, 1e-8)
+        d.set_prior_isotropic(50.0); d.set_noise([[w]])
+        return d
+    other, mine = make(slice(cut, N)), make(slice(0, cut))
+    _, count, _ = mine.stats_layout()
+    buf_other = torch.zeros(count, dtype=torch.float64, device="cuda")
+    buf_mine = torch.zeros(count, dtype=torch.float64, device="cuda")
+    tstream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    other.bind_stats(buf_other.data_ptr())
+    other.sweep_local(tstream.cuda_stream)
+    torch.cuda.synchronize()
+    mine.bind_stats(buf_mine.data_ptr())
+    calls = []
+
+    def hook(ptr, n, stream):
+        assert ptr == buf_mine.data_ptr() and n == count and stream == tstream.cuda_stream
+        calls.append(n)
+        with torch.cuda.stream(tstream):
+            buf_mine.add_(buf_other)             # ordered on the sweep's stream, like ncclAllReduce would be
+    mine.set_allreduce(hook)
+    for _ in range(3):                           # the buffer is rebuilt by every sweep: no accumulation across sweeps
+        mine.sweep(tstream.cuda_stream)
+    torch.cuda.synchronize()
+    assert calls == [count] * 3
+    mu, Sig, _ = mine.posterior(want_uv=False)
+    sc = mine.scalars()
+    assert relF(mu, ref.mu_v) < 1e-8 and relF(Sig, ref.Sigma_v) < 1e-8
+    assert math.isclose(sc.sum_I2, ref.sum_I2, rel_tol=1e-8)
+    mine.set_allreduce(None)                     # hook removed: the sweep is single-GPU again (this shard alone)
+    mine.sweep(tstream.cuda_stream)
+    torch.cuda.synchronize()
+    assert calls == [count] * 3
+    ref1 = O.vmp_sweep(Xu, X[:cut], y[:cut], None, s2, ell, w, jitter=1e-8, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
+    assert relF(mine.posterior(want_uv=False)[0], ref1.mu_v) < 1e-8
+    other.close(); mine.close()
+
+
+def test_shader_clock_probe(G):
+    import ctypes as C
+    from gaussianprocessnode_amd import _lib
+    v = C.c_double()
+    _lib.check(_lib.load().sgp_measure_sclk_mhz(0, C.byref(v)), None, "sgp_measure_sclk_mhz")
+    assert 500.0 < v.value < 3000.0

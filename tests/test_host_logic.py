@@ -154,8 +154,9 @@ s2, ell, w = 0.9, np.array([1.5, 2.0]), 40.0
 lo, hi = shard_bounds(N, world, rank)
 eng = OracleShardEngine(Xu, X[lo:hi], y[lo:hi], s2, ell, w, 50.0, 1e-8)
 sw = ShardedSweep(eng)
-assert sw.world == world
+assert sw.world == world and sw.hooked and sw.backend == "gloo"
 sw.sweep(); sw.sweep()                      # the buffer is rebuilt every sweep (no accumulation across sweeps)
+assert eng.hook_calls == 2                  # the exchange step ran INSIDE the engine's sweep (the C ABI's all-reduce hook)
 ref = O.vmp_sweep(Xu, X, y, None, s2, ell, w, jitter=1e-8, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
 assert np.linalg.norm(eng.res.mu_v - ref.mu_v) / np.linalg.norm(ref.mu_v) < 1e-10
 assert np.linalg.norm(eng.res.Sigma_v - ref.Sigma_v) / np.linalg.norm(ref.Sigma_v) < 1e-10

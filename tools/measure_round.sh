@@ -1,27 +1,29 @@
 #!/bin/bash
-# Every measurement behind profiles/r01_* and DESIGN.md section 6, in one GPU call:
+# Every measurement behind profiles/r02_* and DESIGN.md's measured-state section, in one GPU call:
 #   gpurun --timeout 1200 -- 'bash tools/measure_round.sh 2>&1 | tail -40'
 # Outputs land under gpurun_out/final/ (tests, bench line, rocprofv3 kernel trace + stats + one-sweep timeline, the three
-# PMC passes, BASELINE config rates, fuzz, accuracy sweep, the two training runs); copy what is judged into profiles/.
+# PMC passes, the traffic record bench.py reads, BASELINE config rates, accuracy sweep, the two training runs); copy what is
+# judged into profiles/.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 cd $R
 timeout -k 10 600 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
-timeout -k 10 300 python bench.py > $O/bench_T.json 2> $O/bench_T.err; tail -c 300 $O/bench_T.json; echo
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/kt && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline > $O/kt.json 2> $O/kt.err
-f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); g=$(find /tmp/kt -name "*kernel_stats.csv" | head -1)
-python3 $R/tools/timeline.py $f > $O/timeline.txt; cp $g $O/kernel_stats.csv; python3 $R/tools/kstats.py $g 60 > $O/kernel_stats_per_sweep.txt 2>&1 || python3 $R/tools/kstats.py $g > $O/kernel_stats_per_sweep.txt 2>&1
-echo "trace done"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c && timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/pmc_$c.err
-  h=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1); python3 $R/tools/pmc_summary.py $h $c > $O/pmc_$c.txt 2>&1; echo "pmc $c done"
+  h=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1); cp $h $O/pmc_$c.csv; python3 $R/tools/pmc_summary.py $h $c > $O/pmc_$c.txt 2>&1; echo "pmc $c done"
 done
+python3 $R/tools/pmc_traffic_json.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv T $O/pmc_traffic.json; cp $O/pmc_traffic.json $R/profiles/r02_pmc_traffic.json
 rm -rf /tmp/pmc_m && timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_m -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/pmc_mfma.err
-h=$(find /tmp/pmc_m -name "*counter_collection.csv" | head -1); cp $h $O/pmc_mfma_raw.csv; echo "pmc mfma done"
+h=$(find /tmp/pmc_m -name "*counter_collection.csv" | head -1); cp $h $O/pmc_mfma_raw.csv; python3 $R/tools/pmc_mfma_summary.py $h > $O/pmc_mfma.txt 2>&1; echo "pmc mfma done"
+rm -rf /tmp/kt && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline > $O/kt.json 2> $O/kt.err
+f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); g=$(find /tmp/kt -name "*kernel_stats.csv" | head -1)
+python3 $R/tools/timeline.py $f > $O/timeline.txt; cp $g $O/kernel_stats.csv; python3 $R/tools/kstats.py $g 60 > $O/kernel_stats_per_sweep.txt 2>&1
+echo "trace done"
 cd $R
+timeout -k 10 300 python bench.py > $O/bench_T.json 2> $O/bench_T.err; tail -c 400 $O/bench_T.json; echo
+timeout -k 10 300 python bench.py --workload N1M --no-cpu-baseline > $O/bench_N1M.json 2> $O/bench_N1M.err; tail -c 300 $O/bench_N1M.json; echo
 timeout -k 10 200 python tools/config_rates.py > $O/config_rates.txt 2>&1; tail -8 $O/config_rates.txt
-timeout -k 10 200 python tools/fuzz_parity.py 11 120 2>&1 | tail -1 > $O/fuzz.txt; cat $O/fuzz.txt
 timeout -k 10 300 python tools/accuracy_sweep.py 100 > $O/accuracy_sweep.txt 2>&1; grep "worst" $O/accuracy_sweep.txt
 timeout -k 10 120 python examples/train_kin40k.py > $O/train_kin40k.txt 2>&1; tail -2 $O/train_kin40k.txt
 timeout -k 10 120 python examples/train_banana.py > $O/train_banana.txt 2>&1; tail -2 $O/train_banana.txt
