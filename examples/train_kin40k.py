@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=500)
     ap.add_argument("--batch", type=int, default=500)
     ap.add_argument("--eta", type=float, default=1e-3)
+    ap.add_argument("--host-paced", action="store_true", help="setters + sgp_theta_objective + numpy AdaMax per minibatch")
     args = ap.parse_args()
 
     import gaussianprocessnode_amd as G
@@ -44,7 +45,7 @@ def main():
     with G.SGPDevice(args.batch, M, D, use_graph=os.environ.get("SGP_GRAPH") is not None) as eng:
         t0 = time.perf_counter()
         qv, theta = perform_inference(theta_init, xtrain, ytrain, Xu, eng, batch_size=args.batch, epochs=args.epochs,
-                                      w_val=w_val, optimizer=AdaMax(eta=args.eta))
+                                      w_val=w_val, optimizer=AdaMax(eta=args.eta), device_paced=not args.host_paced)
         t_train = time.perf_counter() - t0
         p = softplus(theta)
         eng.set_kernel(float(p[0]), p[1:], 1e-8)                         # :296 (jitter only at prediction time)
@@ -53,6 +54,7 @@ def main():
     nsweeps = args.epochs * ((len(ytrain) + args.batch - 1) // args.batch)
     print(json.dumps({
         "experiment": "kin40k PerformInference (experiments/regression_kin40k.ipynb)",
+        "pacing": "host (setters, sgp_theta_objective, numpy AdaMax)" if args.host_paced else "device (sgp_train_*)",
         "epochs": args.epochs, "minibatch": args.batch, "M": int(M), "sweeps_plus_theta_steps": nsweeps,
         "handle_create_seconds": t0 - t_create, "train_seconds": t_train, "total_seconds": t_total, "ms_per_minibatch": 1e3 * t_train / nsweeps,
         "smse_test": float(SMSE(ytest, pred)), "smse_train": float(SMSE(ytrain, _predict_train(G, xtrain, Xu, p, qv.m))),

@@ -94,6 +94,13 @@ struct sgp_handle {
     uint64_t main_prep_gen = 0;    // the generation k_prep_xu last mirrored onto the main stream's copies (dXus, dParams)
     Params* dParams = nullptr;
     Params* dParamsK = nullptr;    // the K_uu chain's own copy (it runs on the side stream)
+    const Params* params_src = nullptr;   // what k_prep_xu mirrors: hParams, or dTrainParams while a device-paced run is open
+    // device-paced training (sgp_train_*): the resident training set, the optimiser state and the parameter source
+    double *dTrainX = nullptr, *dTrainY = nullptr;
+    int64_t train_N = 0;
+    TrainState* dTrain = nullptr;
+    Params* dTrainParams = nullptr;
+    bool training = false;
     double* dXusK = nullptr;
     hipStream_t own = nullptr, side = nullptr;
     hipEvent_t evSide = nullptr, evDone = nullptr;
@@ -152,6 +159,7 @@ static int call_scratch(sgp_handle* h, size_t count, double** out) {
 }
 
 static int quiesce(sgp_handle* h) {
+    if (h->training) return fail(h, SGP_ERR_ARG, "a device-paced training run is open on this handle: call sgp_train_end first");
     if (h->in_flight) {
         HIPCHK(h, hipSetDevice(h->cfg.device));
         HIPCHK(h, hipDeviceSynchronize());
@@ -428,6 +436,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     for (int d = 0; d < MAXD; ++d) h->hParams->inv_ell[d] = 1.0;
     h->hParams->W[0] = 1.0;
     h->hParams->prior_iso = 1.0;
+    h->params_src = h->hParams;
     if (hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking) != hipSuccess ||
         create_low_priority_stream(&h->side) != hipSuccess ||
         hipEventCreateWithFlags(&h->evSide, hipEventDisableTiming) != hipSuccess ||
@@ -464,7 +473,8 @@ extern "C" int sgp_destroy(sgp_handle* h) {
                     h->dChainShip[0][0], h->dChainShip[0][1], h->dChainShip[1][0], h->dChainShip[1][1],
                     h->dChainRinv[0][0], h->dChainRinv[0][1], h->dChainRinv[1][0], h->dChainRinv[1][1],
                     h->dChainTrace[0], h->dChainTrace[1], h->dKuuAlt, h->dLamAlt,
-                    h->dChainArgs[0][0], h->dChainArgs[0][1], h->dChainArgs[1][0], h->dChainArgs[1][1]};
+                    h->dChainArgs[0][0], h->dChainArgs[0][1], h->dChainArgs[1][0], h->dChainArgs[1][1],
+                    h->dTrainX, h->dTrainY, h->dTrain, h->dTrainParams};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evSide) hipEventDestroy(h->evSide);
@@ -484,6 +494,23 @@ extern "C" int sgp_set_inducing(sgp_handle* h, const double* Xu) {
     h->have_inducing = true;
     h->params_gen++;
     h->swept = h->swept_local = false;
+    return 0;
+}
+
+// the launch geometry of the data-sized kernels for n points
+static int set_point_count(sgp_handle* h, int64_t n) {
+    h->n = n;
+    h->nblk = (int)((n + TB - 1) / TB);
+    // split the point axis into one resident round of workgroups (see syrk_chunking), chunk a multiple of the stage size
+    int want = 1, align = 1;
+    syrk_chunking(h->ntiles, h->num_cus, &want, &align);
+    int64_t per = (n + want - 1) / want;
+    per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);
+    h->chunk = (int)per;
+    h->nchunks = (int)std::max<int64_t>(1, (n + per - 1) / per);
+    if (h->nchunks > align) h->nchunks = (h->nchunks + align - 1) / align * align;   // trailing chunks may be empty (zero slabs)
+    if ((size_t)h->nchunks * h->ntiles * TB * TB > h->slab_capacity)
+        return fail(h, SGP_ERR_ARG, "sgp_set_data: internal slab capacity exceeded");
     return 0;
 }
 
@@ -530,17 +557,7 @@ extern "C" int sgp_set_data(sgp_handle* h, const double* X, const double* y_mean
     h->has_omega = pt_weight != nullptr;
     h->has_yv = y_var != nullptr;
     h->have_data = true;
-    h->nblk = (int)((n + TB - 1) / TB);
-    // split the point axis into one resident round of workgroups (see syrk_chunking), chunk a multiple of the stage size
-    int want = 1, align = 1;
-    syrk_chunking(h->ntiles, h->num_cus, &want, &align);
-    int64_t per = (n + want - 1) / want;
-    per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);
-    h->chunk = (int)per;
-    h->nchunks = (int)std::max<int64_t>(1, (n + per - 1) / per);
-    if (h->nchunks > align) h->nchunks = (h->nchunks + align - 1) / align * align;   // trailing chunks may be empty (zero slabs)
-    if ((size_t)h->nchunks * h->ntiles * TB * TB > h->slab_capacity)
-        return fail(h, SGP_ERR_ARG, "sgp_set_data: internal slab capacity exceeded");
+    if (int rc = set_point_count(h, n)) return rc;
     h->swept = h->swept_local = false;
     return 0;
 }
@@ -696,7 +713,7 @@ extern "C" int sgp_bind_stats(sgp_handle* h, void* stats_dev) {
 // different streams (parallel branches inside ONE captured graph were observed to execute back to back).
 static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
-    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, (const Params*)h->hParams,
+    hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->params_src,
                        h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0);
     if (h->use_chain) {
         if (h->gate_kuu)
@@ -718,7 +735,7 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     // -- and without data, where no Gram kernel exists to open the sweep's stamps.)
     const bool prep = h->main_prep_gen != h->params_gen || (h->cfg.flags & SGP_FLAG_GRAPH) || h->n <= 0;
     if (prep) {
-        hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, (const Params*)h->hParams,
+        hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->params_src,
                            h->dParams, (int*)nullptr, M, Mp, D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP);
         h->main_prep_gen = h->params_gen;
     }
@@ -1183,6 +1200,7 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
     if (!h || !Xstar || !mean || ns < 0) return fail(h, SGP_ERR_ARG, "sgp_predict: bad argument");
     if (!h->have_inducing || !h->have_kernel) return fail(h, SGP_ERR_ARG, "sgp_predict: set_inducing and set_kernel first");
     if (!mu_v && !h->swept) return fail(h, SGP_ERR_ARG, "sgp_predict: no posterior in the handle and mu_v is NULL");
+    if (h->training) return fail(h, SGP_ERR_ARG, "sgp_predict: a device-paced training run is open (sgp_train_end first)");
     if (ns == 0) return 0;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipDeviceSynchronize());
@@ -1223,60 +1241,10 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
 // evaluated at the CURRENT kernel parameters with q(v) (mu_v, R = Sigma_v + mu mu') held fixed at the last finished
 // sweep -- exactly how the notebooks call it (experiments/regression_kin40k.ipynb:212-221: q(v) from the sweep, then the
 // gradient step on theta).  Re-uses the sweep's kernels: K_uu chain + Gram/SYRK at theta, then the trace kernels.
-static int theta_objective_eval(sgp_handle* h, hipStream_t s, double* value) {
-    enqueue_kuu(h, s);
-    enqueue_local(h, s);
-    h->main_prep_gen = 0;       // this evaluation opens phase stamps that no closing kernel folds: let the next sweep's k_prep_xu reset them
-    const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
-    hipLaunchKernelGGL(k_trace_kinv, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dTrace, M, Mp);
-    hipLaunchKernelGGL(k_trace_R, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dR, h->dTrace + TRACE_BLOCKS, M, Mp, h->dout,
-                       Qp, (int64_t*)nullptr);
-    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, (const double*)h->dTrace, (int)TRACE_BLOCKS,
-                       (const double*)(h->dTrace + TRACE_BLOCKS), (int)TRACE_BLOCKS, h->dMu, h->dKuu, h->dLam, h->dInfo, h->dParams,
-                       h->dOut2, h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q, (int64_t*)nullptr, (int64_t*)nullptr,
-                       (int64_t*)nullptr);
-    HIPCHK(h, hipStreamSynchronize(s));
-    HIPCHK(h, hipGetLastError());
-    double out[SGP_R_COUNT], sc[SGP_S_COUNT];
-    HIPCHK(h, hipMemcpy(out, h->dOut2, sizeof out, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(sc, h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, sizeof sc, hipMemcpyDeviceToHost));
-    if (out[SGP_R_INFO_KUU] > 0) { h->err = "K_uu is not positive definite"; return (int)out[SGP_R_INFO_KUU]; }
-    *value = 0.5 * h->hParams->W[0] * (out[SGP_R_SUM_I1] + out[SGP_R_SUM_I2] - sc[SGP_S_YY]);
-    return 0;
-}
-
-extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
-    if (!h || !value) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: null argument");
-    if (!h->swept || h->dout != 1) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: needs a finished UniSGP sweep (q(v))");
-    if (!h->have_data || !h->have_kernel) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: data and kernel must be set");
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipDeviceSynchronize());
-    h->in_flight = false;
-    hipStream_t s = h->own;
-    // Same theta, data and noise as the sweep that produced q(v) -- the notebooks' call pattern
-    // (experiments/regression_kin40k.ipynb:205-221 evaluates the gradient at the theta the sweep just used): K_uf, Psi2, b,
-    // K_uu^-1 and the traces are still on the device, nothing is recomputed.  (Not with externally reduced statistics:
-    // the objective is additive over shards only with each rank's LOCAL Psi2.)
-    bool fresh = !h->stats_dirty && h->swept_data_gen == h->data_gen && h->dStats == h->dStatsOwn &&
-                 h->swept_params.sigma2 == h->hParams->sigma2 && h->swept_params.jitter == h->hParams->jitter;
-    // the objective is linear in w: a new mean(q_w) (classification_banana.ipynb passes the UPDATED q(w)) only rescales it
-    const double wscale = fresh ? h->hParams->W[0] / h->swept_params.W[0] : 1.0;
-    for (int d = 0; d < h->D && fresh; ++d) fresh = h->swept_params.inv_ell[d] == h->hParams->inv_ell[d];
-    int rc = 0;
-    if (fresh) {
-        double out[SGP_R_COUNT], sc[SGP_S_COUNT];
-        HIPCHK(h, hipMemcpy(out, h->dOut, sizeof out, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(sc, h->dStats + (size_t)h->Mp * h->Mp + (size_t)h->Mp * h->dout, sizeof sc, hipMemcpyDeviceToHost));
-        if (out[SGP_R_INFO_KUU] > 0) { h->err = "K_uu is not positive definite"; return (int)out[SGP_R_INFO_KUU]; }
-        *value = 0.5 * h->hParams->W[0] * (out[SGP_R_SUM_I1] + out[SGP_R_SUM_I2] - sc[SGP_S_YY]);
-        if (!grad) return 0;
-    } else {
-        h->stats_dirty = true;                   // the statistics now belong to the NEW theta, not to q(v)'s sweep
-        rc = theta_objective_eval(h, s, value);
-        if (rc || !grad) { h->swept_local = true; return rc; }
-    }
-    // analytic gradient w.r.t. (sigma2, ell_1 .. ell_n_ell): one G K_uf GEMM contracted with the kernel derivatives in its
-    // epilogue, plus the K_uu term through H = Kinv Psi2 Kinv (see k_theta_grad_* in sgp_kernels.hip.h)
+// analytic gradient w.r.t. (sigma2, ell_1 .. ell_n_ell) of the objective at the resident K_uf, Psi2, K_uu^-1, R and mu, into
+// h->dGrad: one G K_uf GEMM contracted with the kernel derivatives in its
+// epilogue, plus the K_uu term through H = Kinv Psi2 Kinv (see k_theta_grad_* in sgp_kernels.hip.h)
+static int enqueue_theta_grad(sgp_handle* h, hipStream_t s) {
     const int Mp = h->Mp, T = h->T;
     const int nblk_max = (int)((h->n_max + TB - 1) / TB);
     if (!h->dGradM) {
@@ -1305,11 +1273,190 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     hipLaunchKernelGGL(k_theta_grad_uu, dim3(T, T), dim3(256), 0, s, dH, h->dXus, h->dParams, part_uu, h->M, Mp, h->D);
     hipLaunchKernelGGL(k_theta_grad_finish, dim3(1), dim3(256), 0, s, part_uf, n_uf, part_uu, T * T,
                        h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, h->dParams, h->dGrad, h->D, h->n_ell);
+    return 0;
+}
+
+static int theta_objective_eval(sgp_handle* h, hipStream_t s, double* value) {
+    enqueue_kuu(h, s);
+    enqueue_local(h, s);
+    h->main_prep_gen = 0;       // this evaluation opens phase stamps that no closing kernel folds: let the next sweep's k_prep_xu reset them
+    const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
+    hipLaunchKernelGGL(k_trace_kinv, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dTrace, M, Mp);
+    hipLaunchKernelGGL(k_trace_R, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dR, h->dTrace + TRACE_BLOCKS, M, Mp, h->dout,
+                       Qp, (int64_t*)nullptr);
+    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, (const double*)h->dTrace, (int)TRACE_BLOCKS,
+                       (const double*)(h->dTrace + TRACE_BLOCKS), (int)TRACE_BLOCKS, h->dMu, h->dKuu, h->dLam, h->dInfo, h->dParams,
+                       h->dOut2, h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q, (int64_t*)nullptr, (int64_t*)nullptr,
+                       (int64_t*)nullptr);
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    double out[SGP_R_COUNT], sc[SGP_S_COUNT];
+    HIPCHK(h, hipMemcpy(out, h->dOut2, sizeof out, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(sc, h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, sizeof sc, hipMemcpyDeviceToHost));
+    if (out[SGP_R_INFO_KUU] > 0) { h->err = "K_uu is not positive definite"; return (int)out[SGP_R_INFO_KUU]; }
+    *value = 0.5 * h->hParams->W[0] * (out[SGP_R_SUM_I1] + out[SGP_R_SUM_I2] - sc[SGP_S_YY]);
+    return 0;
+}
+
+extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
+    if (!h || !value) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: null argument");
+    if (!h->swept || h->dout != 1) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: needs a finished UniSGP sweep (q(v))");
+    if (!h->have_data || !h->have_kernel) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: data and kernel must be set");
+    if (h->training) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: a device-paced training run is open (sgp_train_end first)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    h->in_flight = false;
+    hipStream_t s = h->own;
+    // Same theta, data and noise as the sweep that produced q(v) -- the notebooks' call pattern
+    // (experiments/regression_kin40k.ipynb:205-221 evaluates the gradient at the theta the sweep just used): K_uf, Psi2, b,
+    // K_uu^-1 and the traces are still on the device, nothing is recomputed.  (Not with externally reduced statistics:
+    // the objective is additive over shards only with each rank's LOCAL Psi2.)
+    bool fresh = !h->stats_dirty && h->swept_data_gen == h->data_gen && h->dStats == h->dStatsOwn &&
+                 h->swept_params.sigma2 == h->hParams->sigma2 && h->swept_params.jitter == h->hParams->jitter;
+    // the objective is linear in w: a new mean(q_w) (classification_banana.ipynb passes the UPDATED q(w)) only rescales it
+    const double wscale = fresh ? h->hParams->W[0] / h->swept_params.W[0] : 1.0;
+    for (int d = 0; d < h->D && fresh; ++d) fresh = h->swept_params.inv_ell[d] == h->hParams->inv_ell[d];
+    int rc = 0;
+    if (fresh) {
+        double out[SGP_R_COUNT], sc[SGP_S_COUNT];
+        HIPCHK(h, hipMemcpy(out, h->dOut, sizeof out, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(sc, h->dStats + (size_t)h->Mp * h->Mp + (size_t)h->Mp * h->dout, sizeof sc, hipMemcpyDeviceToHost));
+        if (out[SGP_R_INFO_KUU] > 0) { h->err = "K_uu is not positive definite"; return (int)out[SGP_R_INFO_KUU]; }
+        *value = 0.5 * h->hParams->W[0] * (out[SGP_R_SUM_I1] + out[SGP_R_SUM_I2] - sc[SGP_S_YY]);
+        if (!grad) return 0;
+    } else {
+        h->stats_dirty = true;                   // the statistics now belong to the NEW theta, not to q(v)'s sweep
+        rc = theta_objective_eval(h, s, value);
+        if (rc || !grad) { h->swept_local = true; return rc; }
+    }
+    if (int grc = enqueue_theta_grad(h, s)) return grc;
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpy(grad, h->dGrad, sizeof(double) * (1 + h->n_ell), hipMemcpyDeviceToHost));
     for (int i = 0; i <= h->n_ell; ++i) grad[i] *= wscale;
     if (!fresh) h->swept_local = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-paced minibatch training: the loop of `PerformInference` (experiments/regression_kin40k.ipynb:196-230) with
+// nothing but launches on the host side.  The training set is resident, a minibatch is a window of it, the optimiser
+// (Flux's AdaMax, :222) and the softplus map of `kernel_gp` (:108) run on the device, and the next sweep's parameters are
+// read from where the optimiser kernel wrote them.  The host never waits inside the loop; factorisation failures are
+// counted on the device (the step is then skipped) and reported by sgp_train_end.
+// ------------------------------------------------------------------------------------------------
+extern "C" int sgp_train_begin(sgp_handle* h, const double* X, const double* y, int64_t n_total, const double* theta_raw,
+                               int32_t n_ell, double jitter, double eta, double beta1, double beta2, double eps) {
+    if (!h || !X || !y || !theta_raw) return fail(h, SGP_ERR_ARG, "sgp_train_begin: null argument");
+    if (int qrc = quiesce(h)) return qrc;
+    if (h->dout != 1) return fail(h, SGP_ERR_ARG, "sgp_train_begin: the theta objective is defined for UniSGP (d_out = 1)");
+    if (h->cfg.flags & SGP_FLAG_GRAPH) return fail(h, SGP_ERR_ARG, "sgp_train_begin: not with SGP_FLAG_GRAPH (the window moves every step)");
+    if (h->allreduce || h->dStats != h->dStatsOwn)
+        return fail(h, SGP_ERR_ARG, "sgp_train_begin: the objective is additive over shards only with local statistics (no all-reduce hook, no bound buffer)");
+    if (!h->have_inducing) return fail(h, SGP_ERR_ARG, "sgp_train_begin: call sgp_set_inducing first");
+    if (n_total < 1) return fail(h, SGP_ERR_ARG, "sgp_train_begin: empty training set");
+    if (n_ell != 1 && n_ell != h->D) return fail(h, SGP_ERR_ARG, "sgp_train_begin: n_ell must be 1 or D");
+    if (!(jitter >= 0.0) || !(eta > 0.0)) return fail(h, SGP_ERR_ARG, "sgp_train_begin: jitter >= 0 and eta > 0 required");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->train_N != n_total) {
+        if (h->dTrainX) hipFree(h->dTrainX);
+        if (h->dTrainY) hipFree(h->dTrainY);
+        h->dTrainX = h->dTrainY = nullptr;
+        h->train_N = 0;
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dTrainX), sizeof(double) * (size_t)n_total * h->D));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dTrainY), sizeof(double) * (size_t)n_total));
+        h->train_N = n_total;
+    }
+    if (!h->dTrain) {
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dTrain), sizeof(TrainState)));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dTrainParams), sizeof(Params)));
+    }
+    HIPCHK(h, hipMemcpy(h->dTrainX, X, sizeof(double) * (size_t)n_total * h->D, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->dTrainY, y, sizeof(double) * (size_t)n_total, hipMemcpyHostToDevice));
+    TrainState st;
+    memset(&st, 0, sizeof st);
+    for (int i = 0; i <= n_ell; ++i) st.theta[i] = theta_raw[i];
+    st.bp[0] = beta1; st.bp[1] = beta2;
+    st.eta = eta; st.beta1 = beta1; st.beta2 = beta2; st.eps = eps;
+    HIPCHK(h, hipMemcpy(h->dTrain, &st, sizeof st, hipMemcpyHostToDevice));
+    // noise precision, E[log w], the isotropic prior and the jitter stay what the setters left; sigma2 and the lengthscales
+    // come from theta on the device
+    h->hParams->jitter = jitter;
+    HIPCHK(h, hipMemcpy(h->dTrainParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice));
+    h->n_ell = n_ell;
+    hipLaunchKernelGGL(k_train_adamax, dim3(1), dim3(64), 0, h->own, h->dTrain, (const double*)nullptr, (const double*)nullptr,
+                       h->dTrainParams, h->D, n_ell, 0);
+    HIPCHK(h, hipStreamSynchronize(h->own));
+    h->params_src = h->dTrainParams;
+    h->have_kernel = true;
+    h->training = true;
+    h->swept = h->swept_local = false;
+    return 0;
+}
+
+// one minibatch = the window [offset, offset + n) of the resident set: sweep (:205-211), posterior carry (:212), gradient of
+// the objective at that q(v) (:214-221) and the optimiser step (:222).  flags: SGP_TRAIN_LEARN takes the optimiser step,
+// SGP_TRAIN_RESET_PRIOR first puts the isotropic prior of sgp_set_prior(form 2) back (the per-epoch reset, :203-204 -- the
+// prior's form is a launch argument, so this costs nothing).  Asynchronous.
+extern "C" int sgp_train_step(sgp_handle* h, int64_t offset, int64_t n, int32_t flags) {
+    if (!h) return SGP_ERR_ARG;
+    if (!h->training) return fail(h, SGP_ERR_ARG, "sgp_train_step: call sgp_train_begin first");
+    if (offset < 0 || n < 1 || offset + n > h->train_N || n > h->n_max)
+        return fail(h, SGP_ERR_ARG, "sgp_train_step: window outside the resident set or larger than n_max");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = h->own;
+    const bool learn = (flags & SGP_TRAIN_LEARN) != 0;
+    if (flags & SGP_TRAIN_RESET_PRIOR) h->prior_form = 2;
+    double *ownX = h->dX, *ownYw = h->dYw, *ownY = h->dY;
+    h->dX = h->dTrainX + (size_t)offset * h->D;
+    h->dYw = h->dY = h->dTrainY + offset;
+    h->has_omega = h->has_yv = false;
+    h->have_data = true;
+    h->n_nodes = (double)n;
+    h->data_gen++;
+    h->params_gen++;                                           // theta moved: k_prep_xu mirrors the parameters again
+    int rc = set_point_count(h, n);
+    if (!rc) {
+        hipLaunchKernelGGL(k_train_window, dim3(1), dim3(256), 0, s, (const double*)h->dY, n, h->dDataScal, (int)SGP_S_COUNT + 1);
+        rc = sgp_sweep_local(h, nullptr);                      // (the sweep's own entry points: the product path here too)
+        if (!rc) rc = sgp_sweep_finish(h, nullptr);
+        if (!rc) rc = sgp_carry_posterior(h, nullptr);
+        if (!rc && learn) rc = enqueue_theta_grad(h, s);
+        if (!rc && learn)
+            hipLaunchKernelGGL(k_train_adamax, dim3(1), dim3(64), 0, s, h->dTrain, (const double*)h->dGrad, (const double*)h->dOut,
+                               h->dTrainParams, h->D, h->n_ell, 1);
+        // the next K_uu chain (side stream) reads the parameters this step wrote and overwrites the K_uu^-1 its gradient read
+        if (!rc && hipEventRecord(h->evDone, s) != hipSuccess) rc = fail(h, SGP_ERR_HIP, "sgp_train_step: hipEventRecord failed");
+    }
+    h->dX = ownX; h->dYw = ownYw; h->dY = ownY;
+    h->have_data = false;                                      // the window is not the handle's data: set_data again after the run
+    if (rc) return rc;
+    if (hipGetLastError() != hipSuccess) return fail(h, SGP_ERR_HIP, "sgp_train_step: launch failed");
+    return 0;
+}
+
+// waits for the queued steps; theta_raw[1 + n_ell] = the raw parameters after the last step; counts[2] = optimiser steps
+// taken, minibatches skipped because a factorisation failed.  The handle is an ordinary one again afterwards (kernel set
+// to softplus(theta), posterior getters valid, data must be set again before the next sweep).
+extern "C" int sgp_train_end(sgp_handle* h, double* theta_raw, int64_t* counts) {
+    if (!h) return SGP_ERR_ARG;
+    if (!h->training) return fail(h, SGP_ERR_ARG, "sgp_train_end: no run is open");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->training = false;
+    h->params_src = h->hParams;
+    HIPCHK(h, hipDeviceSynchronize());
+    h->in_flight = false;
+    TrainState st;
+    HIPCHK(h, hipMemcpy(&st, h->dTrain, sizeof st, hipMemcpyDeviceToHost));
+    Params P;
+    HIPCHK(h, hipMemcpy(&P, h->dTrainParams, sizeof P, hipMemcpyDeviceToHost));
+    h->hParams->sigma2 = P.sigma2;
+    for (int d = 0; d < h->D; ++d) h->hParams->inv_ell[d] = P.inv_ell[d];
+    h->params_gen++;
+    h->stats_dirty = true;                                     // the resident statistics belong to the previous theta
+    h->swept_local = false;
+    if (theta_raw) for (int i = 0; i <= h->n_ell; ++i) theta_raw[i] = st.theta[i];
+    if (counts) { counts[0] = (int64_t)st.steps; counts[1] = (int64_t)st.rejected; }
     return 0;
 }
 

@@ -2298,4 +2298,63 @@ __global__ void __launch_bounds__(256) k_theta_grad_finish(const double* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device-paced minibatch training (sgp_train_* in sgp_api.hip): the host only enqueues; the data window's scalars, the
+// softplus map theta -> kernel parameters and the optimiser step are tiny kernels between the sweep's own.
+// ------------------------------------------------------------------------------------------------
+// data scalars of the window y[0 .. n) (what sgp_set_data computes on the host): sum y^2 in S_YY and in the Ryy slot, n in
+// S_W and S_N.  One workgroup, fixed summation order.
+__global__ void __launch_bounds__(256) k_train_window(const double* __restrict__ y, int64_t n, double* __restrict__ scal,
+                                                      int count) {
+    __shared__ double red[4];
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) a += y[i] * y[i];
+    const double syy = block_sum(a, red);
+    for (int e = threadIdx.x; e < count; e += 256) {
+        double v = 0.0;
+        if (e == 0 /* SGP_S_YY */ || e == 8 /* Ryy[0] of d_out = 1 */) v = syy;
+        if (e == 1 /* SGP_S_W */ || e == 2 /* SGP_S_N */) v = (double)n;
+        scal[e] = v;
+    }
+}
+
+struct TrainState {
+    double theta[MAXD + 1];     // raw (pre-softplus) parameters: sigma2 first, then the lengthscale(s)
+    double m[MAXD + 1];         // AdaMax first moment
+    double u[MAXD + 1];         // AdaMax infinity-norm accumulator
+    double bp[2];               // running powers of beta
+    double eta, beta1, beta2, eps;
+    double steps, rejected;     // optimiser steps taken / minibatches whose factorisations failed (theta left alone)
+};
+
+__device__ __forceinline__ double softplus_dev(double x) { return fmax(x, 0.0) + log1p(exp(-fabs(x))); }
+
+// One thread: Flux's AdaMax (m = b1 m + (1 - b1) g; u = max(b2 u, |g|); theta -= eta / (1 - b1^t) m / (u + eps)) on the raw
+// parameters with the chain rule through softplus (d softplus = sigmoid), then the kernel parameters of the NEXT sweep
+// written where k_prep_xu reads them.  `update` = 0 only writes the parameters (first step of a run).
+__global__ void k_train_adamax(TrainState* __restrict__ st, const double* __restrict__ grad, const double* __restrict__ out,
+                               Params* __restrict__ src, int D, int n_ell, int update) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (update) {
+        const bool ok = out[3] == 0.0 && out[4] == 0.0;           // SGP_R_INFO_KUU, SGP_R_INFO_LAMBDA
+        if (ok) {
+            for (int i = 0; i <= n_ell; ++i) {
+                const double th = st->theta[i];
+                const double g = grad[i] / (1.0 + exp(-th));
+                const double m = st->beta1 * st->m[i] + (1.0 - st->beta1) * g;
+                const double u = fmax(st->beta2 * st->u[i], fabs(g));
+                st->m[i] = m;
+                st->u[i] = u;
+                st->theta[i] = th - (st->eta / (1.0 - st->bp[0])) * m / (u + st->eps);
+            }
+            st->bp[0] *= st->beta1;
+            st->bp[1] *= st->beta2;
+            st->steps += 1.0;
+        } else
+            st->rejected += 1.0;
+    }
+    src->sigma2 = softplus_dev(st->theta[0]);
+    for (int d = 0; d < D; ++d) src->inv_ell[d] = 1.0 / softplus_dev(st->theta[1 + (n_ell == 1 ? 0 : d)]);
+}
+
 }  // namespace sgp

@@ -216,6 +216,34 @@ class SGPDevice:
               "sgp_theta_objective")
         return (v.value, g) if want_grad else v.value
 
+    # -- device-paced minibatch training (sgp_train_*) -----------------------------------------------------------------
+    def train_begin(self, X, y, theta_raw, *, jitter: float = 0.0, eta: float = 1e-3, beta=(0.9, 0.999), eps: float = 1e-8):
+        """Upload the training set (X: N x D, one point per row; y: N) and the raw (pre-softplus) parameters, reset the
+        AdaMax state: the loop of `PerformInference` (experiments/regression_kin40k.ipynb:196-230) then runs as
+        `train_step` calls that only enqueue."""
+        X = np.ascontiguousarray(np.asarray(X, dtype=np.float64).reshape(-1, self.D))
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        if len(y) != X.shape[0]:
+            raise ValueError("train_begin: X and y disagree on the number of points")
+        th = np.ascontiguousarray(np.asarray(theta_raw, dtype=np.float64).reshape(-1))
+        n_ell = th.size - 1
+        check(self._lib.sgp_train_begin(self._h, ptr(X), ptr(y), len(y), ptr(th), n_ell, float(jitter), float(eta),
+                                        float(beta[0]), float(beta[1]), float(eps)), self._h, "sgp_train_begin")
+        self._n_ell = n_ell
+
+    def train_step(self, offset: int, n: int, learn: bool = True, reset_prior: bool = False):
+        """One minibatch [offset, offset + n): sweep, carry, gradient, optimiser step.  Asynchronous.  reset_prior puts
+        the isotropic prior of `set_prior_isotropic` back first (the per-epoch reset of the notebooks)."""
+        check(self._lib.sgp_train_step(self._h, int(offset), int(n), (1 if learn else 0) | (2 if reset_prior else 0)),
+              self._h, "sgp_train_step")
+
+    def train_end(self):
+        """Wait for the queued steps; returns (theta_raw, optimiser steps taken, minibatches skipped)."""
+        th = np.empty(1 + self._n_ell)
+        counts = (C.c_int64 * 2)()
+        check(self._lib.sgp_train_end(self._h, ptr(th), counts), self._h, "sgp_train_end")
+        return th, int(counts[0]), int(counts[1])
+
     def time_kernel(self, which: int, iters: int = 20, stream: int = 0) -> float:
         """Average launch duration (microseconds, HIP events) of the Gram or streaming-SYRK kernel."""
         v = C.c_double()

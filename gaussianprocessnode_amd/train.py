@@ -37,14 +37,23 @@ def sigmoid(x):
 
 
 def perform_inference(theta, xtrain, ytrain, Xu, engine, *, batch_size=500, epochs=1, w_val=1e4, prior_var=50.0,
-                      jitter=0.0, optimizer=None, learn_theta=True):
+                      jitter=0.0, optimizer=None, learn_theta=True, device_paced=None):
     """Returns (q_v of the last minibatch, theta) like `PerformInference` (:196-230).  `theta` is the raw
-    (pre-softplus) parameter vector of `kernel_gp` (:108); `engine` an SGPDevice sized for `batch_size` points."""
+    (pre-softplus) parameter vector of `kernel_gp` (:108); `engine` an SGPDevice sized for `batch_size` points.
+
+    device_paced (default: whenever the engine offers `train_begin`): the training set, theta and the optimiser state
+    stay on the device and the loop below only enqueues (sgp_train_* in include/sgp_hip.h); otherwise every minibatch
+    goes through the setters, `theta_objective` and the host-side `AdaMax` (the same arithmetic, host-paced)."""
     theta = np.array(theta, dtype=np.float64)
     xtrain = np.asarray(xtrain, dtype=np.float64).reshape(len(ytrain), -1)
     Xu = np.asarray(Xu, dtype=np.float64).reshape(-1, xtrain.shape[1])
     M = Xu.shape[0]
     optimizer = optimizer or AdaMax()
+    if device_paced is None:
+        device_paced = hasattr(engine, "train_begin")
+    if device_paced:
+        return _perform_inference_device(theta, xtrain, ytrain, Xu, engine, batch_size, epochs, w_val, prior_var, jitter,
+                                         optimizer, learn_theta)
     xb, yb = split2batch((xtrain, np.asarray(ytrain, dtype=np.float64)), batch_size)
     engine.set_inducing(Xu)
     engine.set_noise([[w_val]])
@@ -72,6 +81,27 @@ def perform_inference(theta, xtrain, ytrain, Xu, engine, *, batch_size=500, epoc
     if device_carry:
         mu, Sigma, _ = engine.posterior(want_uv=False)
     return MvNormalMeanCovariance(mu, Sigma), theta
+
+
+def _perform_inference_device(theta, xtrain, ytrain, Xu, engine, batch_size, epochs, w_val, prior_var, jitter, optimizer,
+                              learn_theta):
+    """The same loop with the device pacing itself: one `train_step` per minibatch, an isotropic-prior reset per epoch
+    (:203-204); the host waits once, at the end."""
+    N = len(ytrain)
+    if optimizer._state:
+        raise ValueError("perform_inference(device_paced=True) starts AdaMax from zero state; pass a fresh optimizer")
+    engine.set_inducing(Xu)
+    engine.set_noise([[w_val]])
+    engine.set_prior_isotropic(prior_var)                                  # :203-204, put back by reset_prior every epoch
+    engine.train_begin(xtrain, ytrain, theta, jitter=jitter, eta=optimizer.eta, beta=optimizer.beta, eps=optimizer.eps)
+    for _ in range(epochs):
+        for o in range(0, N, batch_size):
+            engine.train_step(o, min(batch_size, N - o), learn_theta, reset_prior=(o == 0))
+    theta, _, skipped = engine.train_end()
+    if skipped:
+        raise np.linalg.LinAlgError(f"{skipped} minibatch(es) had a K_uu or Lambda that is not positive definite")
+    mu, Sigma, _ = engine.posterior(want_uv=False)
+    return MvNormalMeanCovariance(mu, Sigma), np.asarray(theta)
 
 
 def probit_marginal(y, mz, vz):

@@ -188,6 +188,31 @@ int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const double* mu
  * entries (grad_llh_new!, derivative_helper.jl:59-63 uses ForwardDiff; here the analytic kernel-derivative contraction). */
 int sgp_theta_objective(sgp_handle* h, double* value, double* grad);
 
+/* ---- device-paced minibatch training: `PerformInference` of experiments/regression_kin40k.ipynb:196-230 ---------------
+ * The reference's loop is, per minibatch, infer(iterations = 1) (:205-211), q(v) carried over as the next prior (:212),
+ * grad_llh_new! at that q(v) (:214-221) and Flux.Optimise.update!(AdaMax, theta, grad) (:222) with
+ * theta -> softplus(theta) inside `kernel_gp` (:108).  sgp_train_* keeps all of it on the device: the training set is
+ * uploaded once, a minibatch is a window of it, the optimiser state lives in device memory and every sweep reads its
+ * kernel parameters from where the optimiser kernel wrote them, so the host only enqueues and never waits in the loop.
+ *   sgp_train_begin  X is n_total x D point-major (row i = point i), y n_total; theta_raw[1 + n_ell] the raw
+ *                    (pre-softplus) parameters (sigma2 first); noise, prior and inducing inputs as the setters left them;
+ *                    AdaMax(eta, (beta1, beta2), eps) starts from zero state.  UniSGP handles without SGP_FLAG_GRAPH and
+ *                    without an all-reduce hook.  Until sgp_train_end every setter, sgp_predict and
+ *                    sgp_theta_objective return SGP_ERR_ARG.
+ *   sgp_train_step   one minibatch = points [offset, offset + n), n <= n_max.  flags: SGP_TRAIN_LEARN = gradient and
+ *                    optimiser step (without it theta stays); SGP_TRAIN_RESET_PRIOR = before this minibatch the prior
+ *                    goes back to the isotropic N(0, variance I) last given to sgp_set_prior(form 2) (the per-epoch
+ *                    reset, :203-204).  Asynchronous.  A minibatch whose K_uu or Lambda is not positive definite leaves
+ *                    theta alone and is counted.
+ *   sgp_train_end    waits; theta_raw out (may be NULL); counts[0] = optimiser steps taken, counts[1] = minibatches
+ *                    skipped (may be NULL).  The posterior getters then return the last minibatch's q(v); the kernel is
+ *                    set to softplus(theta); sgp_set_data is needed again before another sgp_sweep. */
+int sgp_train_begin(sgp_handle* h, const double* X, const double* y, int64_t n_total, const double* theta_raw,
+                    int32_t n_ell, double jitter, double eta, double beta1, double beta2, double eps);
+enum { SGP_TRAIN_LEARN = 1, SGP_TRAIN_RESET_PRIOR = 2 };
+int sgp_train_step(sgp_handle* h, int64_t offset, int64_t n, int32_t flags);
+int sgp_train_end(sgp_handle* h, double* theta_raw, int64_t* counts /* 2 */);
+
 /* ---- building blocks exposed for tests / other callers (host pointers, blocking) ------------
  * K = sigma2 * exp(-0.5 |(a-b)/ell|^2): kernelmatrix(kernel(theta), A, B) of KernelFunctions.jl as called at
  * GPnode/UniSGPnode.jl:102,153; A is D x na, B is D x nb, K is na x nb column-major. */

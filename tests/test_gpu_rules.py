@@ -238,9 +238,12 @@ def test_multisgp_rule_theta_closure(graph):
             assert abs(nu.logpdf(np.array(th)) - ref(np.array(th))) <= tol, (th, nu.logpdf(np.array(th)), ref(np.array(th)), tol)
 
 
-def test_streaming_driver_matches_oracle_loop():
+@pytest.mark.parametrize("device_paced", [True, False])
+def test_streaming_driver_matches_oracle_loop(device_paced):
     """PerformInference (experiments/regression_kin40k.ipynb:196-230) -- posterior carry over ragged
-    minibatches and AdaMax steps on theta, against the same loop written with the oracle."""
+    minibatches and AdaMax steps on theta, against the same loop written with the oracle.  Both pacings: the device-paced
+    run (sgp_train_*: resident set, optimiser and softplus map on the device, the host only enqueues) and the host-paced
+    one (setters + sgp_theta_objective + AdaMax in numpy)."""
     import gaussianprocessnode_amd as G
     from gaussianprocessnode_amd.train import AdaMax, perform_inference, sigmoid
     rng = np.random.default_rng(2)
@@ -251,7 +254,8 @@ def test_streaming_driver_matches_oracle_loop():
     theta0 = O.invsoftplus(np.array([1.0, 1.5, 1.2]))
     w = 50.0
     with G.SGPDevice(bs, M, D) as eng:
-        qv, theta = perform_inference(theta0, X, y, Xu, eng, batch_size=bs, epochs=2, w_val=w, optimizer=AdaMax(eta=0.01))
+        qv, theta = perform_inference(theta0, X, y, Xu, eng, batch_size=bs, epochs=2, w_val=w, optimizer=AdaMax(eta=0.01),
+                                      device_paced=device_paced)
     # oracle loop
     th, opt = theta0.copy(), AdaMax(eta=0.01)
     for _ in range(2):
@@ -267,6 +271,51 @@ def test_streaming_driver_matches_oracle_loop():
     np.testing.assert_allclose(theta, th, rtol=1e-5, atol=1e-7)
     assert np.linalg.norm(qv.m - mu) / np.linalg.norm(mu) < 1e-5
     assert np.linalg.norm(qv.S - Sig) / np.linalg.norm(Sig) < 1e-5
+
+
+def test_device_paced_run_guards_and_counts():
+    """sgp_train_* (include/sgp_hip.h): while a run is open the setters, predict and theta_objective refuse; windows are
+    checked against the resident set and n_max; train_end reports the optimiser steps taken and leaves an ordinary handle
+    (kernel = softplus(theta), posterior = the last minibatch's q(v)); learn = False leaves theta alone bit for bit."""
+    import gaussianprocessnode_amd as G
+    rng = np.random.default_rng(8)
+    N, M, D, bs = 96, 12, 3, 40
+    X = rng.uniform(-1.5, 1.5, (N, D))
+    y = np.cos(X[:, 0]) + 0.05 * rng.normal(size=N)
+    Xu = X[:M].copy()
+    th0 = O.invsoftplus(np.array([1.2, 0.9, 1.1, 1.4]))
+    with G.SGPDevice(bs, M, D) as eng:
+        eng.set_inducing(Xu)
+        eng.set_noise([[20.0]])
+        eng.set_prior_isotropic(50.0)
+        with pytest.raises(Exception):
+            eng.train_step(0, bs)                                          # no run open
+        eng.train_begin(X, y, th0, eta=0.01)
+        for bad in [lambda: eng.set_kernel(1.0, [1.0] * D, 0.0), lambda: eng.set_data(X[:bs], y[:bs]),
+                    lambda: eng.predict(X[:4], np.zeros(M)), lambda: eng.train_step(80, bs), lambda: eng.train_step(0, bs + 1),
+                    lambda: eng.train_step(-1, 4)]:
+            with pytest.raises(Exception):
+                bad()
+        eng.train_step(0, bs, learn=False, reset_prior=True)
+        th, steps, skipped = eng.train_end()
+        assert (steps, skipped) == (0, 0) and np.array_equal(th, th0)
+        mu, Sig, _ = eng.posterior(want_uv=False)
+        p = O.softplus(th0)
+        r = O.vmp_sweep(Xu, X[:bs], y[:bs], None, p[0], p[1:], 20.0, mu0=np.zeros(M), Sigma0=50.0 * np.eye(M))
+        assert np.linalg.norm(mu - r.mu_v) / np.linalg.norm(r.mu_v) < 1e-8
+        assert np.linalg.norm(Sig - r.Sigma_v) / np.linalg.norm(r.Sigma_v) < 1e-8
+        # a second run on the same handle: three learning steps, then the handle predicts with softplus(theta)
+        eng.train_begin(X, y, th0, eta=0.01)
+        eng.train_step(0, bs, reset_prior=True)
+        eng.train_step(40, bs)
+        eng.train_step(80, 16)
+        th, steps, skipped = eng.train_end()
+        assert (steps, skipped) == (3, 0) and not np.array_equal(th, th0)
+        mu, _, _ = eng.posterior(want_uv=False)
+        p = O.softplus(th)
+        got = eng.predict(X[:7], mu)
+        want = O.kernelmatrix(p[0], p[1:], X[:7], Xu) @ mu
+        np.testing.assert_allclose(np.ravel(got), want, rtol=1e-9, atol=1e-12)
 
 
 def test_uncertain_input_v_and_out_rules():
