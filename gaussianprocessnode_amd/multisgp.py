@@ -5,7 +5,15 @@ The reference evaluates, per time step, cubature Psi-statistics (5 Gram columns 
 `kron(W, Psi2)` message and a DM x DM Gaussian product.  Here the cubature points of ALL steps go to the device as weighted
 data in one call; the summed statistics give q(v), the Wishart inverse scale and the average energy in one sweep
 (eq. M).  Per-step rule functions are provided for interface parity (they run the same device
-kernels on one step).  Everything numeric comes from `meta.engine` (C ABI); no CPU fallback.
+kernels on one step).
+
+What runs where: Gram matrices, Psi-statistics, every factorisation / inverse, q(v), the Wishart inverse scale, the energy
+and the per-point quadratic forms come from `meta.engine` and the device building blocks (C ABI); there is no CPU
+fallback for them.  What stays in NumPy is bookkeeping of a few d_out x d_out or M x M operands that are arguments of
+those calls, not results of the node's algebra: cubature points and weights of q_in (cubature.py), `slogdet` of the
+d_out x d_out mean(q_w) when q_w has no `mean_logdet` (:83), the block contraction S = sum_ij W_ij Rv[i][j] and
+s = sum_d mu_v^(d) (mu_y' W)_d of `_second_moment_contraction`, a trace, and the Laplace step of `rule_in` (L-BFGS and a
+finite-difference Hessian in d_in dimensions around the device-evaluated closure; the reference uses ForwardDiff).
 """
 from __future__ import annotations
 
@@ -241,11 +249,10 @@ def rule_theta(q_out, q_in, q_v, q_w, meta: MultiSGPMeta):
     """@rule MultiSGP(:theta) (GPnode/MultiSGPnode.jl:447-466): theta -> -1/2 tr(W) (Psi0 - tr(Kuu^-1 Psi2')) + Psi1 . s
     - 1/2 tr(Psi2' S), Psi2' = Psi2 + 1e-7 I (:458), Kuu(theta) without jitter (:455), Psi by meta.method's cubature over q_in.
     Per cubature point this is the :in closure, so one device pass per theta (K_uu chain at theta, K_uf for the points, the
-    two per-point quadratic forms); the 1e-7 I term adds 1e-7 (tr(W) tr(Kuu^-1) - tr(S)) / 2, tr(Kuu^-1) from the device's
-    factor."""
-    from scipy.linalg import solve_triangular
+    two per-point quadratic forms); the 1e-7 I term adds 1e-7 (tr(W) tr(Kuu^-1) - tr(S)) / 2, with Kuu^-1 from the device
+    (sgp_kernelmatrix + sgp_potri); the host only takes its trace."""
     from .unisgp import LogPdfClosure
-    from .device import potrf
+    from .device import kernelmatrix, potri, potrf
     if meta.method is None:
         raise ValueError("MultiSGP(:theta) needs meta.method (a cubature rule)")
     Xu = np.asarray(meta.Xu, dtype=np.float64)
@@ -266,6 +273,6 @@ def rule_theta(q_out, q_in, q_v, q_w, meta: MultiSGPMeta):
         eng.sweep_local()
         eng.set_posterior(s_vec, US)
         I1, I2 = eng.w_stats()
-        Linv = solve_triangular(eng.kuu_chol(), np.eye(M), lower=True)
-        return float(wts @ (-0.5 * trW * I1 - 0.5 * (I2 - 1.0)) + 0.5e-7 * (trW * np.sum(Linv * Linv) - trS))
+        tr_kinv = float(np.trace(potri(kernelmatrix(Xu, Xu, sigma2, ell, meta.device), meta.device)))
+        return float(wts @ (-0.5 * trW * I1 - 0.5 * (I2 - 1.0)) + 0.5e-7 * (trW * tr_kinv - trS))
     return LogPdfClosure(log_backwardmess, multivariate=True)

@@ -116,6 +116,56 @@ def probit_marginal(y, mz, vz):
     return mz + s * vz * r / np.sqrt(1.0 + vz), vz - vz * vz / (1.0 + vz) * r * (g + r)
 
 
+def vmp_regression(p, xtrain, ytrain, Xu, engine, *, iterations=7, prior_var=50.0, shape=1e-2, rate=1e-2, jitter=1e-8):
+    """The inner `infer(...)` of experiments/GPT_regression.ipynb's `my_free_energy` (cell 9; model cell 6:
+    `v ~ MvNormal(0, 50 I); w ~ Gamma(1e-2, 1e-2); y[i] ~ UniSGP(x[i], v, w, theta)`, mean field q(v) q(w), q(w) initialised
+    at its prior, 7 iterations) at the kernel parameters p = (sigma2, lengthscale...) -- BASELINE config 1.  Per iteration:
+    one sweep for q(v) at mean(q_w), then q(w) = Gamma(shape + N/2, rate + (sum I1 + sum I2)/2) from that q(v)
+    (GPnode/UniSGPnode.jl:56-73,196-238).  Returns (q_v, (shape, rate))."""
+    xtrain = np.asarray(xtrain, dtype=np.float64).reshape(len(ytrain), -1)
+    Xu = np.asarray(Xu, dtype=np.float64).reshape(-1, xtrain.shape[1])
+    p = np.asarray(p, dtype=np.float64)
+    a, b = float(shape), float(rate)
+    engine.set_inducing(Xu)
+    engine.set_kernel(float(p[0]), p[1:], jitter)
+    engine.set_prior_isotropic(prior_var)
+    engine.set_data(xtrain, np.asarray(ytrain, dtype=np.float64))
+    for _ in range(iterations):
+        engine.set_noise([[a / b]])
+        engine.sweep()
+        sc = engine.scalars()
+        a, b = shape + 0.5 * len(ytrain), rate + 0.5 * (sc.sum_I1 + sc.sum_I2)
+    mu, Sigma, _ = engine.posterior(want_uv=False)
+    return MvNormalMeanCovariance(mu, Sigma), (a, b)
+
+
+def vmp_classification(p, xtrain, ytrain, Xu, engine, *, iterations=30, prior_var=50.0, shape=1e-2, rate=1e-2, jitter=0.0):
+    """The inner `infer(...)` of experiments/GPT_classification.ipynb's `my_free_energy` (cell 9; model cell 7:
+    `f[i] ~ UniSGP(x[i], v, w, theta); y[i] ~ Probit(f[i])`, mean field q(f) q(v) q(w), q(v) and q(w) initialised at their
+    priors, 30 iterations, K_uu without jitter).  Per iteration: q(f_i) from the :out message N(k_i' mu_v, 1 / mean(q_w))
+    and the Probit likelihood, one sweep for q(v) with q_out = q(f), then q(w).  Returns (q_v, (shape, rate))."""
+    xtrain = np.asarray(xtrain, dtype=np.float64).reshape(len(ytrain), -1)
+    ytrain = np.asarray(ytrain, dtype=np.float64)
+    Xu = np.asarray(Xu, dtype=np.float64).reshape(-1, xtrain.shape[1])
+    p = np.asarray(p, dtype=np.float64)
+    a, b = float(shape), float(rate)
+    mu = np.zeros(Xu.shape[0])
+    engine.set_inducing(Xu)
+    engine.set_kernel(float(p[0]), p[1:], jitter)
+    engine.set_prior_isotropic(prior_var)
+    for _ in range(iterations):
+        w = a / b
+        mf, vf = probit_marginal(ytrain, engine.predict(xtrain, mu), 1.0 / w)
+        engine.set_data(xtrain, mf, vf)
+        engine.set_noise([[w]])
+        engine.sweep()
+        sc = engine.scalars()
+        a, b = shape + 0.5 * len(ytrain), rate + 0.5 * (sc.sum_I1 + sc.sum_I2)
+        mu = engine.posterior(want_cov=False, want_uv=False)[0]
+    mu, Sigma, _ = engine.posterior(want_uv=False)
+    return MvNormalMeanCovariance(mu, Sigma), (a, b)
+
+
 def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch_size=200, epochs=1, prior_var=50.0,
                                      shape=0.01, rate=0.01, jitter=1e-8, optimizer=None):
     """`PerformInference` of experiments/classification_banana.ipynb (model `f[i] ~ UniSGP(x[i], v, w, theta);

@@ -9,8 +9,12 @@ the device as cubature-weighted data: `:v` (:125-140) and `:out` (:85-93) inside
 average-energy variants (:177-192,290-313,390-409), the `:in` closure (:107-122) and the `:theta` closures (:242-287)
 as stand-alone per-point evaluations at whatever q_v / meta.Uv the caller passes.
 
-Nothing here computes the node's mathematics on the CPU: every number comes from `meta.engine`
-(`SGPDevice`, the C ABI).  Without the HIP library and a gfx950 GPU the first sweep raises.
+What runs where: Gram matrices, Psi-statistics, the factorisations, q(v), `meta.Uv`, the :w / energy sums and the
+per-point quadratic forms come from `meta.engine` (`SGPDevice`, the C ABI); without the HIP library and a gfx950 GPU the
+first sweep raises -- there is no CPU fallback.  What stays on the host is message bookkeeping: the token counter,
+cubature points and weights of an uncertain input (cubature.py), scalar arithmetic on the returned sums (Gamma shape and
+rate, the energy's constants), and the conversion of a caller-supplied q_v into the (mean, upper factor) pair the cold
+rules upload -- that factor is taken on the device too (`potrf`).
 """
 from __future__ import annotations
 

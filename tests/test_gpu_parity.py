@@ -19,6 +19,16 @@ def relF(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
 
 
+def kuu_tol(cond_K):
+    """Bound on |L_dev - L_ref|_F / |L_ref|_F for the K_uu factor."""
+    return max(1e-13, 0.05 * np.finfo(float).eps * cond_K)
+
+
+def post_tol(cond_L):
+    """The north star's bound is 1e-5 relative Frobenius; what FP64 can deliver is ~cond(Lambda) * eps, so the tighter."""
+    return min(1e-5, max(1e-9, 20 * np.finfo(float).eps * cond_L))
+
+
 @pytest.fixture(scope="module")
 def G():
     import gaussianprocessnode_amd as g
@@ -103,6 +113,7 @@ CASES = [
     ("ragged", 333, 37, 3, 10.0, 1e-8, False),          # nothing a multiple of anything
     ("banana-C4", 1000, 128, 2, 3.0, 1e-8, True),       # config 4 shape, classification (v_y present)
     ("kin40k-C2", 2000, 256, 8, 1e4, 0.0, False),       # config 2 shape, reduced N
+    ("kin40k-C2-full", 10000, 256, 8, 1e4, 0.0, False), # BASELINE config 2 at its full size
     ("kin40k-T", 1500, 512, 8, 1e4, 0.0, False),        # north-star M
     ("kin40k-M600", 500, 600, 8, 1e4, 0.0, False),      # the reference's real M with one minibatch (N < M)
 ]
@@ -133,20 +144,22 @@ def test_sweep_matches_oracle(G, name, N, M, D, w, jit, cls):
     assert relF(B, ref.stats.b) < 1e-13
     assert math.isclose(sc_data[0], ref.stats.s_yy[0, 0], rel_tol=1e-13)
     assert sc_data[1] == N and sc_data[2] == N
-    # K_uu factor
-    assert relF(KuuL, ref.KuuL) < 1e-9
+    # K_uu factor: two FP64 Cholesky factorisations differ by a small multiple of cond(K_uu) * eps (the toy shape has
+    # cond ~ 1e9-1e10; the worst ratio over 300 random draws is 0.006, profiles/r01_accuracy_sweep.txt)
+    Kuu = O.kernelmatrix(s2, ell, Xu) + jit * np.eye(M)
+    cond_K = np.linalg.cond(Kuu)
+    assert relF(KuuL, ref.KuuL) < kuu_tol(cond_K), (relF(KuuL, ref.KuuL), cond_K)
     # posterior: the north star's bound is 1e-5 relative Frobenius; what FP64 can deliver is ~cond(Lambda) * eps
     # (two independent FP64 evaluations differ by that much), so assert the tighter of the two.
     cond_L = np.linalg.cond(np.eye(M) / 50.0 + w * ref.stats.Psi2)
-    tol_post = min(1e-5, max(1e-9, 20 * np.finfo(float).eps * cond_L))
+    tol_post = post_tol(cond_L)
     assert relF(mu, ref.mu_v) < tol_post, (relF(mu, ref.mu_v), cond_L)
     assert relF(Sig, ref.Sigma_v) < tol_post, (relF(Sig, ref.Sigma_v), cond_L)
     assert relF(Uv, ref.Uv) < tol_post
     assert np.allclose(np.tril(Uv, -1), 0.0)
     # summed :w messages and average energy.  sum I1 = s_kk - tr(Kuu^-1 Psi2) cancels against s_kk, so its
     # attainable accuracy is cond(Kuu) * eps * s_kk (see test_oracle_identities); the toy case has cond ~ 1e9.
-    Kuu = O.kernelmatrix(s2, ell, Xu) + jit * np.eye(M)
-    tol_I1 = 50 * np.finfo(float).eps * np.linalg.cond(Kuu) * ref.stats.s_kk + 1e-12
+    tol_I1 = 50 * np.finfo(float).eps * cond_K * ref.stats.s_kk + 1e-12
     assert abs(sc.sum_I1 - ref.sum_I1) <= tol_I1
     assert math.isclose(sc.sum_I2, ref.sum_I2, rel_tol=max(1e-7, tol_post))
     assert abs(sc.energy - ref.energy) <= max(1e-7, tol_post) * abs(ref.energy) + 0.5 * w * tol_I1
@@ -161,6 +174,43 @@ def test_sweep_matches_oracle(G, name, N, M, D, w, jit, cls):
     # theta objective at the sweep's own posterior (helper_functions/derivative_helper.jl:23-39)
     ref_obj = O.theta_objective(Xu, X, y, s2, ell, ref.mu_v, ref.Uv, w, jitter=jit)
     assert abs(obj - ref_obj) <= 1e-7 * abs(ref_obj) + 0.5 * w * tol_I1
+
+
+SWEEP_SHAPES = [("toy", 50, 20, 1, 100.0, 1e-8), ("ragged", 333, 37, 3, 10.0, 1e-8), ("mid", 700, 130, 2, 30.0, 1e-8)]
+
+
+@pytest.mark.parametrize("name,N,M,D,w,jit", SWEEP_SHAPES, ids=[c[0] for c in SWEEP_SHAPES])
+def test_accuracy_over_random_draws(G, name, N, M, D, w, jit):
+    """tools/accuracy_sweep.py as a test: 24 random draws per shape (the toy shape has cond(K_uu) ~ 1e9-1e10), K_uu factor
+    and posterior against the oracle at the conditioning-aware bounds of test_sweep_matches_oracle.  A variant of the pivot
+    loop that let the two triangles of the diagonal block drift apart passed the fixed-seed cases and failed 8 of 120 draws
+    of this kind; the fixed-seed cases alone do not guard the factorisation kernels."""
+    eps = np.finfo(float).eps
+    worst = {"kuu": 0.0, "mu": 0.0, "sig": 0.0, "uv": 0.0}
+    s2, ell = 0.9, np.linspace(1.5, 3.0, D)
+    with G.SGPDevice(N, M, D) as dev:
+        for seed in range(24):
+            X, Xu, y, vy = synth(N, M, D, seed=1000 + seed)
+            dev.set_inducing(Xu)
+            dev.set_data(X, y, vy)
+            dev.set_kernel(s2, ell, jit)
+            dev.set_prior_isotropic(50.0)
+            dev.set_noise([[w]], math.log(w) - 0.01)
+            dev.sweep()
+            KuuL = dev.kuu_chol()
+            mu, Sig, Uv = dev.posterior()
+            ref = O.vmp_sweep(Xu, X, y, vy, s2, ell, w, E_logw=math.log(w) - 0.01, jitter=jit, Lambda0=np.eye(M) / 50.0,
+                              xi0=np.zeros(M))
+            cK = np.linalg.cond(O.kernelmatrix(s2, ell, Xu) + jit * np.eye(M))
+            cL = np.linalg.cond(np.eye(M) / 50.0 + w * ref.stats.Psi2)
+            errs = {"kuu": relF(KuuL, ref.KuuL), "mu": relF(mu, ref.mu_v), "sig": relF(Sig, ref.Sigma_v), "uv": relF(Uv, ref.Uv)}
+            assert errs["kuu"] < kuu_tol(cK), (seed, errs, cK)
+            for k in ("mu", "sig", "uv"):
+                assert errs[k] < post_tol(cL), (seed, k, errs, cL)
+            worst["kuu"] = max(worst["kuu"], errs["kuu"] / (cK * eps))
+            for k in ("mu", "sig", "uv"):
+                worst[k] = max(worst[k], errs[k] / (cL * eps))
+    print(name, "worst error / (cond * eps):", {k: round(v, 4) for k, v in worst.items()})
 
 
 def test_prior_forms_agree(G):

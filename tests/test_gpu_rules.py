@@ -318,6 +318,37 @@ def test_device_paced_run_guards_and_counts():
         np.testing.assert_allclose(np.ravel(got), want, rtol=1e-9, atol=1e-12)
 
 
+def test_toy_experiments_on_the_reference_data():
+    """The reference's two toy notebooks on their own saved data (tests/golden/toy*_fixture.npz) through the device path:
+    GPT_regression.ipynb (config 1: 7 VMP iterations with q(w) updates; printed SMSE 0.008131895454357316, cell 17) and
+    GPT_classification.ipynb (30 iterations of q(f), q(v), q(w); printed "Number of error:35.0", cell 21), both at the
+    notebooks' printed optimal hyper-parameters; and the same loops through the oracle-backed engine, to FP64 agreement."""
+    import gaussianprocessnode_amd as G
+    from gaussianprocessnode_amd.meta import SMSE, num_error
+    from gaussianprocessnode_amd.train import vmp_classification, vmp_regression
+    from tests.cpu_engine import OracleDevice
+    from tests.test_host_logic import TOY_CLS_ERRORS, TOY_CLS_THETA, TOY_REG_SMSE, TOY_REG_THETA, toy_fixture
+    x, y, xt, yt, Xu = toy_fixture("toyregression")
+    with G.SGPDevice(len(y), len(Xu), 1) as eng:
+        qv, (a, b) = vmp_regression(TOY_REG_THETA, x, y, Xu, eng)
+        eng.set_kernel(TOY_REG_THETA[0], TOY_REG_THETA[1:], 1e-8)
+        pred = eng.predict(xt.reshape(-1, 1), qv.m)
+    assert abs(SMSE(yt, pred) - TOY_REG_SMSE) < 2e-3 * TOY_REG_SMSE
+    ref, (ra, rb) = vmp_regression(TOY_REG_THETA, x, y, Xu, OracleDevice(len(y), len(Xu), 1))
+    # cond(K_uu) ~ 1e9 here (20 inducing inputs, lengthscale 0.54 on [-4, 4], jitter 1e-8): two FP64 evaluations of the 7
+    # coupled iterations agree to about cond * eps
+    assert np.linalg.norm(qv.m - ref.m) / np.linalg.norm(ref.m) < 1e-6
+    assert math.isclose(a / b, ra / rb, rel_tol=1e-6)
+    x, y, xt, yt, Xu = toy_fixture("toyclassification")
+    with G.SGPDevice(len(y), len(Xu), 1) as eng:
+        qv, (a, b) = vmp_classification(TOY_CLS_THETA, x, y, Xu, eng)
+        pred = eng.predict(xt.reshape(-1, 1), qv.m)
+    assert num_error(yt, (np.ravel(pred) > 0).astype(float)) == TOY_CLS_ERRORS
+    ref, (ra, rb) = vmp_classification(TOY_CLS_THETA, x, y, Xu, OracleDevice(len(y), len(Xu), 1))
+    assert np.linalg.norm(qv.m - ref.m) / np.linalg.norm(ref.m) < 1e-6
+    assert math.isclose(a / b, ra / rb, rel_tol=1e-6)
+
+
 def test_uncertain_input_v_and_out_rules():
     """GPtest.jl:153-161,184-192 (q_in::Normal): Psi-statistics by ghcubature(21), `Psi2 + 1e-8 I` per message
     (GPnode/UniSGPnode.jl:134-139); here all N messages are folded with the prior in one sweep."""

@@ -181,3 +181,45 @@ def test_sharded_sweep_world_size_2_gloo(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's toy experiments on its own saved data (tests/golden/toy*_fixture.npz), host loops over the CPU engine
+# ------------------------------------------------------------------------------------------------
+TOY_REG_THETA = np.array([0.03619750112503042, 0.5397814213749237])      # "Optimal hyperparameters", GPT_regression.ipynb cell 12
+TOY_REG_SMSE = 0.008131895454357316                                      # "SMSE value of SGP node", cell 17
+TOY_CLS_THETA = np.array([0.28307103179255905, 1.3847608644015856])      # GPT_classification.ipynb cell 11
+TOY_CLS_ERRORS = 35                                                      # "Number of error:35.0", cell 21
+
+
+def toy_fixture(kind):
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{kind}_fixture.npz"))
+    return d["xtrain"], d["ytrain"], d["xtest"], d["ytest"], d["Xu"]
+
+
+def test_toy_regression_reaches_the_notebooks_smse():
+    """BASELINE config 1 on the reference's data: 7 VMP iterations with q(w) updates (GPT_regression.ipynb cells 6-9) at
+    the printed optimum, prediction on the 600 test inputs (cells 14-15), SMSE against the printed 0.00813.  (The
+    notebook's last q(v) was inferred one LBFGS round before the printed theta, so the match is to 1e-3, not to rounding.)"""
+    from gaussianprocessnode_amd.meta import SMSE
+    from gaussianprocessnode_amd.train import vmp_regression
+    x, y, xt, yt, Xu = toy_fixture("toyregression")
+    eng = OracleDevice(len(y), len(Xu), 1)
+    qv, (a, b) = vmp_regression(TOY_REG_THETA, x, y, Xu, eng)
+    assert a == 0.01 + 25.0 and 100.0 < a / b < 130.0                     # the data were drawn with precision 100 (cell 3)
+    eng.set_kernel(TOY_REG_THETA[0], TOY_REG_THETA[1:], 1e-8)
+    pred = eng.predict(xt.reshape(-1, 1), qv.m)
+    assert abs(SMSE(yt, pred) - TOY_REG_SMSE) < 2e-3 * TOY_REG_SMSE
+
+
+def test_toy_classification_reaches_the_notebooks_error_count():
+    """GPT_classification.ipynb cells 7-9 (30 iterations of q(f), q(v), q(w)) at the printed optimum, then cells 13-21:
+    the predicted class is 1 where the predictive mean of f is positive; the notebook counts 35 errors on its 400 test
+    labels."""
+    from gaussianprocessnode_amd.meta import num_error
+    from gaussianprocessnode_amd.train import vmp_classification
+    x, y, xt, yt, Xu = toy_fixture("toyclassification")
+    eng = OracleDevice(len(y), len(Xu), 1)
+    qv, (a, b) = vmp_classification(TOY_CLS_THETA, x, y, Xu, eng)
+    pred = eng.predict(xt.reshape(-1, 1), qv.m)
+    assert num_error(yt, (np.ravel(pred) > 0).astype(float)) == TOY_CLS_ERRORS
