@@ -167,7 +167,7 @@ def vmp_classification(p, xtrain, ytrain, Xu, engine, *, iterations=30, prior_va
 
 
 def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch_size=200, epochs=1, prior_var=50.0,
-                                     shape=0.01, rate=0.01, jitter=1e-8, optimizer=None):
+                                     shape=0.01, rate=0.01, jitter=1e-8, optimizer=None, w_schedule="after_v"):
     """`PerformInference` of experiments/classification_banana.ipynb (model `f[i] ~ UniSGP(x[i], v, w, theta);
     y[i] ~ Probit(f[i])`, mean-field q(f) q(v) q(w), one VMP iteration per minibatch, q(v) and q(w) carried over every
     minibatch and never reset).  Per minibatch:
@@ -176,9 +176,18 @@ def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch
       q(w)    Gamma(a + n/2, b + (sum I1 + sum I2)/2) with the NEW q(v) and the `meta.Uv` its product hook just stored
               (:56-73, :219-238);
       theta   one optimiser step on neg_log_backwardmess_fast with y_data = mean(q_f), w = mean(new q_w).
-    Returns (q_v, (shape, rate), theta).  The reference's own trajectory is not reproducible bit for bit: its gradient
-    factors K_uu WITHOUT jitter (derivative_helper.jl:24-25), which for the banana inducing inputs is numerically
-    indefinite; here the gradient uses the same jittered K_uu as the sweep."""
+    Returns (q_v, (shape, rate), theta).
+
+    w_schedule: which q(v) the q(w) update sees within the single VMP iteration -- "after_v" (default: the minibatch's new
+    q(v) and the `meta.Uv` its product hook just stored), "before_v" (the q(v) the iteration started with) or "w_then_v"
+    (as before_v, and the sweep already uses the new mean(q_w)).  The reference's end point (softplus(theta) = [0.986,
+    1.028, 1.022], q(w) rate 1.72e6) is NOT reproduced by any of them (rates 5.9e5 / 3.6e9 / 2.5e9,
+    profiles/r02_train_banana_schedules.jsonl): mean(q_w) obeys b/a = mean(I1 + I2) ~ 1/mean(q_w) for ANY value, i.e. its
+    dynamics are neutrally stable and the end point is set by update-order details of RxInfer's reactive schedule (no
+    Manifest.toml pins its version), not by the node's arithmetic.  The un-jittered K_uu of the reference's gradient
+    (derivative_helper.jl:24-25; numerically indefinite for the banana inducing inputs) is NOT the cause: three readings of
+    its non-failing Cholesky move the first gradient by 7e-5 .. 6e-3 (tools/banana_gradient_probe.py).  Here the gradient
+    uses the same jittered K_uu as the sweep.  See DESIGN.md section 2."""
     theta = np.array(theta, dtype=np.float64)
     xtrain = np.asarray(xtrain, dtype=np.float64).reshape(len(ytrain), -1)
     ytrain = np.asarray(ytrain, dtype=np.float64)
@@ -190,6 +199,7 @@ def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch
     engine.set_inducing(Xu)
     engine.set_prior_precision(np.zeros(M), np.eye(M) / prior_var)
     mu = np.zeros(M)
+    Uv_old = np.sqrt(prior_var) * np.eye(M)
     first = True
     for _ in range(epochs):
         for xi, yi in zip(xb, yb):
@@ -200,9 +210,22 @@ def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch
             mf, vf = probit_marginal(yi, mz, 1.0 / w0)
             engine.set_data(xi, mf, vf)
             engine.set_noise([[w0]])
+            if w_schedule in ("before_v", "w_then_v"):
+                # q(w) from the q(v) this iteration STARTED with: the per-point I1 / I2 at the carried posterior, before the
+                # sweep replaces it ("w_then_v": the sweep then already uses the new mean(q_w))
+                engine.sweep_local()
+                engine.set_posterior(mu, Uv_old)
+                I1, I2 = engine.w_stats()
+                s_I = float(np.sum(I1) + np.sum(I2))
+                if w_schedule == "w_then_v":
+                    engine.set_noise([[(a + 0.5 * len(yi)) / (b + 0.5 * s_I)]])
             engine.sweep()
-            sc = engine.scalars()
-            a, b = a + 0.5 * len(yi), b + 0.5 * (sc.sum_I1 + sc.sum_I2)
+            if w_schedule == "after_v":
+                sc = engine.scalars()
+                s_I = sc.sum_I1 + sc.sum_I2
+            else:
+                mu, _, Uv_old = engine.posterior(want_cov=False)
+            a, b = a + 0.5 * len(yi), b + 0.5 * s_I
             engine.carry_posterior()
             engine.set_noise([[a / b]])                                # grad_llh_new!(...; w = mean(qw))
             _, g = engine.theta_objective(want_grad=True, n_ell=len(p) - 1)
