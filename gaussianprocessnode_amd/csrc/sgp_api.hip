@@ -222,11 +222,11 @@ static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, doub
     };
     for (int j = 0; j < Tn; ++j) {
         const int nt = Tn - j;
-        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + extras(j)), dim3(256), 0, s, A, ld, j, Tn, info, n_valid,
+        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + extras(j)), dim3(PSTEP_THREADS), 0, s, A, ld, j, Tn, info, n_valid,
                            scratch, Winv, Sacc, tv_xi, tv_t, (j == 0 && form) ? *form : none);
     }
     if (Winv && extras(Tn) > 0)
-        hipLaunchKernelGGL(k_potrf_step, dim3(extras(Tn)), dim3(256), 0, s, A, ld, Tn, Tn, info, n_valid, scratch, Winv, Sacc,
+        hipLaunchKernelGGL(k_potrf_step, dim3(extras(Tn)), dim3(PSTEP_THREADS), 0, s, A, ld, Tn, Tn, info, n_valid, scratch, Winv, Sacc,
                            tv_xi, tv_t, none);
 }
 // C = W^T W (rev: written index-reversed).  With mu: also R = C + mu mu^T, and with Psi2 the per-block shares of tr(R Psi2).

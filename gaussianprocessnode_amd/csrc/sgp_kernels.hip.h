@@ -790,8 +790,9 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
 // by potf2_tile, with Dp and rinv), rinv = 1 / diag(L).  Blocked by 16 columns and entirely WAVE-LOCAL (wave w owns rows
 // 16 w .. 16 w + 15, no workgroup barrier): for each 16-column block the contribution of the blocks to its left is one
 // MFMA product per wave (K = 16 cb), the 16 x 16 triangle is then solved with 4 lanes per row in registers.
+template <bool SYNC = false>
 __device__ __forceinline__ void trsm_tile(double* X, const double* S, const double* Dp, const double* rinv) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;   // (the solve group of an 8-wave workgroup: waves 4 .. 7)
     const int r0 = 16 * wave;
     const int li = lane & 15, lk = lane >> 4;            // MFMA operand coordinates
     const int rr = lane >> 2, q = lane & 3;              // solve coordinates: row r0 + rr, quarter q
@@ -820,6 +821,7 @@ __device__ __forceinline__ void trsm_tile(double* X, const double* S, const doub
         solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [](auto) {});
 #pragma unroll
         for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
+        if constexpr (SYNC) __syncthreads();              // (in step with the factoring group's barriers, see k_potrf_step)
     });
 }
 
@@ -834,7 +836,7 @@ __device__ __forceinline__ void trsm_tile(double* X, const double* S, const doub
 template <bool DIAGW>
 __device__ __forceinline__ void trsm_tile_next(double* X, const double* S, const double* Dp, const double* rinv,
                                                double* __restrict__ Dn) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
     const int r0 = 16 * wave;
     const int li = lane & 15, lk = lane >> 4;
     const int rr = lane >> 2, q = lane & 3;
@@ -989,7 +991,7 @@ struct TileRegs { double v[16]; };
 __device__ __forceinline__ void tile_g2r(TileRegs& t, const double* __restrict__ A, size_t ld, int row0, int col0) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int e = threadIdx.x + 256 * u, c = e >> 5, r = (e & 31) * 2;
+        const int e = (threadIdx.x & 255) + 256 * u, c = e >> 5, r = (e & 31) * 2;
         const double2 w = *reinterpret_cast<const double2*>(A + (size_t)(col0 + c) * ld + row0 + r);
         t.v[2 * u] = w.x;
         t.v[2 * u + 1] = w.y;
@@ -1032,7 +1034,7 @@ __device__ __forceinline__ void tile_form_r_impl(TileRegs& t, const LamForm& f, 
     const double prior_iso = f.P->prior_iso, w00 = f.P->W[0];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        const int e = threadIdx.x + 256 * (u >> 1), c = e >> 5, r = (e & 31) * 2 + (u & 1);      // the layout of tile_g2r
+        const int e = (threadIdx.x & 255) + 256 * (u >> 1), c = e >> 5, r = (e & 31) * 2 + (u & 1);      // the layout of tile_g2r
         t.v[u] = lambda_entry<DENSE, MULTI>(f, Qp - 1 - (row0 + r), Qp - 1 - (col0 + c), Qp, prior_iso, w00);
     }
 }
@@ -1044,7 +1046,7 @@ __device__ __forceinline__ void tile_form_r(TileRegs& t, const LamForm& f, int Q
 __device__ __forceinline__ void tile_r2s(double* S, const TileRegs& t) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        const int e = threadIdx.x + 256 * (u >> 1), c = e >> 5, r = (e & 31) * 2 + (u & 1);
+        const int e = (threadIdx.x & 255) + 256 * (u >> 1), c = e >> 5, r = (e & 31) * 2 + (u & 1);
         S[r * LT + c] = t.v[u];
     }
 }
@@ -1054,7 +1056,7 @@ __device__ __forceinline__ void tile_g2s(double* S, const double* __restrict__ A
     tile_r2s(S, t);
 }
 __device__ __forceinline__ void tile_s2g(const double* S, double* __restrict__ A, size_t ld, int row0, int col0) {
-    for (int e = threadIdx.x; e < TB * TB; e += 256) {
+    for (int e = threadIdx.x & 255; e < TB * TB; e += 256) {
         int c = e >> 6, r = e & 63;
         A[(size_t)(col0 + c) * ld + row0 + r] = S[r * LT + c];
     }
@@ -1274,7 +1276,26 @@ __device__ __forceinline__ void tvec_role(const double* __restrict__ L, const do
     if (part == 0) t[i * TB + r] = (red[r] + red[TB + r]) + (red[2 * TB + r] + red[3 * TB + r]);
 }
 
-__global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
+// xi = xi0 + vec(B W) of the Lambda chain's step 0 (one workgroup, 256 threads)
+__device__ __forceinline__ void form_xi(const LamForm& form, int ld, int tid) {
+    const double* B = form.stats + (size_t)form.Mp * form.Mp;
+    for (int gi = tid; gi < ld; gi += 256) {
+        double v = 0.0;
+        if (gi < form.Q) {
+            const int aa = gi / form.M, i = gi % form.M;
+            v = (form.prior_form == 1) ? form.xi0[gi] : 0.0;
+            for (int e = 0; e < form.d_out; ++e) v = fma(B[(size_t)e * form.Mp + i], form.P->W[e + aa * form.d_out], v);
+        }
+        form.xi[gi] = v;
+    }
+}
+
+// Workgroups are launched with PSTEP_THREADS = 512 threads.  Only the blocks of the panel column below the diagonal use
+// the second half (the "solve group", waves 4 .. 7: they carry the block's own tile -- its rank-64 update, then its
+// triangular solve column block by column block, in step with the factoring group's eight barriers -- while waves 0 .. 3
+// factor the diagonal tile); everywhere else waves 4 .. 7 leave at once (ended waves do not count at a barrier).
+constexpr int PSTEP_THREADS = 512;
+__global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
                                                     int n_valid, double* __restrict__ scratch, double* __restrict__ Winv,
                                                     double* __restrict__ Sacc, const double* __restrict__ tv_xi,
                                                     double* __restrict__ tv_t, LamForm form) {
@@ -1284,10 +1305,12 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     __shared__ __attribute__((aligned(16))) double tiles[2 * TB * LT];
     __shared__ double dprep[4 * DPB];                     // the diagonal tile's 16 x 16 blocks as solve16 reads them
     __shared__ double rinv[TB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const bool xgroup = threadIdx.x >= 256;               // the solve group
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     {
         const int npot = (Tn - j) * (Tn - j + 1) / 2;     // this step's own tiles; the workgroups beyond them work on
         if ((int)blockIdx.x >= npot) {                    // the inverse factor (winv_row_tile): finish block row j - 1,
+            if (xgroup) return;
             int e = blockIdx.x - npot;                    // then pre-accumulate block row j; Sigma = W^T W collects the
             const int nfin = (j >= 2) ? 2 * (j - 1) : 0;  // contribution of block row j - 2 (sigma_row_tile); and one
             const int npre = (j < Tn) ? nfin : 0;         // workgroup advances the forward solve t = W (P xi) (tvec_role)
@@ -1314,6 +1337,7 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     Acc4 accX;
     acc_zero(accX);
     const bool panel = (b == 0);
+    if (xgroup && !(panel && a != 0)) return;
     // scratch: tile 0 parks L_jj; tiles 1 and 2 (alternating with the step's parity: a late workgroup of step j + 1 may
     // still read one while step j + 1's owner of tile (j + 2, j + 1) writes the other) carry the next diagonal tile's
     // update L_{j+1,j} L_{j+1,j}^T from the workgroup that solved L_{j+1,j} to the next launch (trsm_tile_next)
@@ -1325,61 +1349,38 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
     }
     // the tiles this block updates are fetched into registers now, so that their latency hides behind the MFMA phase
     TileRegs rX, rS, rD;
-    if (j == 0 && form.stats) {
-        // step 0 of the Lambda chain forms its tiles instead of loading them; the last workgroup also writes xi
-        stamp_enter(form.stamps);
-        if (!panel) tile_form_r(rX, form, ld, i0, k0);
-        else {
-            tile_form_r(rS, form, ld, j0, j0);
-            if (a != 0) tile_form_r(rX, form, ld, i0, j0);
-        }
-        if (blockIdx.x == gridDim.x - 1) {
-            const double* B = form.stats + (size_t)form.Mp * form.Mp;
-            for (int gi = tid; gi < ld; gi += 256) {
-                double v = 0.0;
-                if (gi < form.Q) {
-                    const int aa = gi / form.M, i = gi % form.M;
-                    v = (form.prior_form == 1) ? form.xi0[gi] : 0.0;
-                    for (int e = 0; e < form.d_out; ++e) v = fma(B[(size_t)e * form.Mp + i], form.P->W[e + aa * form.d_out], v);
-                }
-                form.xi[gi] = v;
+    const bool form_now = (j == 0 && form.stats);
+    if (form_now) stamp_enter(form.stamps);
+    if (panel && a != 0) {
+        // ---- a block of the panel column below the diagonal: two groups of four waves ----
+        if (!xgroup) {
+            // factoring group: the diagonal tile A_jj (minus the rank-64 update the previous launch formed), factored here
+            // redundantly -- no inter-block hand-off -- while the solve group works on the block's own tile
+            if (form_now) tile_form_r(rS, form, ld, j0, j0);
+            else tile_g2r(rS, A, ld, j0, j0);
+            if (j > 0) {
+                tile_g2r(rD, Dn_in, TB, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) rS.v[u] -= rD.v[u];
             }
-        }
-    } else if (!panel) tile_g2r(rX, A, ld, i0, k0);
-    else {
-        tile_g2r(rS, A, ld, j0, j0);
-        if (a != 0) tile_g2r(rX, A, ld, i0, j0);
-    }
-    if (panel && j > 0) tile_g2r(rD, Dn_in, TB, 0, 0);    // the diagonal tile's rank-64 update, formed by the previous launch
-    if (j > 0 && !(panel && a == 0)) {
-        const int p0 = (j - 1) * TB;
-        load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
-        if (a != b) load_panel_n(P1, A, ld, k0, p0, TB, tid);   // L_{k, j-1}
-        if (!panel) {
+            if (form_now && blockIdx.x == gridDim.x - 1) form_xi(form, ld, tid);
+            tile_r2s(S, rS);
             __syncthreads();
-            tile_mma(accX, P0, (a != b) ? P1 : P0, TB, lane, wr, wc);
-            __syncthreads();
+            potf2_tile(S, dprep, rinv, info, j0, n_valid);
+            return;
         }
-        // panel blocks: their own tile's update (P0 P1^T) waits for the idle slots of the factorisation below
-    }
-    if (!panel) {
-        // plain trailing tile: A_ik -= acc, through LDS for coalesced global access
+        // solve group: the own tile (j + a, j).  Its rank-64 update L_{i,j-1} L_{j,j-1}^T takes the first four of the
+        // factoring group's eight barrier intervals (one 16-deep K-slice each, 16 MFMAs per wave), the triangular solve
+        // against L_jj the other four: column block cb of L_jj is final two intervals before it is needed here.
+        if (form_now) tile_form_r(rX, form, ld, i0, j0);
+        else tile_g2r(rX, A, ld, i0, j0);
+        if (j > 0) {
+            const int p0 = (j - 1) * TB;
+            load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
+            load_panel_n(P1, A, ld, k0, p0, TB, tid);         // L_{j, j-1}
+        }
         tile_r2s(X, rX);
         __syncthreads();
-        tile_sub_acc(X, accX, lane, wr, wc);
-        __syncthreads();
-        tile_s2g(X, A, ld, i0, k0);
-        return;
-    }
-    if (j > 0) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) rS.v[u] -= rD.v[u];
-    }
-    tile_r2s(S, rS);
-    if (a != 0) tile_r2s(X, rX);
-    __syncthreads();
-    if (a != 0 && j > 0) {
-        // K-slice s of the own-tile update: k in [16 s, 16 s + 16), this wave's 32 x 32 quadrant (16 MFMAs)
         auto own_slice = [&](int sl) {
             const int li = lane & 15, lk = lane >> 4;
             const double* ap = P0 + (16 * sl + lk) * PS + wr * 32 + li;
@@ -1394,38 +1395,63 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, int 
                 ap += 4 * PS; bp += 4 * PS;
             }
         };
-        // every wave idles during three of the four pivot runs: it does slices 0 and 1 in the first of them, then 2, then 3
-        // -- the whole rank-64 update of the block's own tile hides behind the factorisation.  (A slice, ~0.95 us, is
-        // about as long as a pivot run, so the doubled run stalls its barrier; putting the fourth slice into the solve
-        // phases instead -- as a whole while a wave waits there, or one MFMA per solve pivot -- measured 2-4 us worse.)
-        potf2_tile(S, dprep, rinv, info, j0, n_valid, [&](int cb) {
-            const int ord = cb - (cb > wave ? 1 : 0);
-            if (ord == 0) { own_slice(0); own_slice(1); }
-            else own_slice(ord + 1);
-        }, [](auto, auto) {}, [](auto) {});
-        tile_sub_acc(X, accX, lane, wr, wc);
-        __syncthreads();
-    } else {
-        potf2_tile(S, dprep, rinv, info, j0, n_valid);
-    }
-    if (a == 0) {
-        if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);       // no other block reads A_jj in the last step
-        else
-            for (int e = tid; e < TB * TB; e += 256) scratch[e] = S[(e & 63) * LT + (e >> 6)];   // column-major tile
-        if (Winv) {
-            trtri_tile(S, rinv, X, lds);
-            tile_s2g(X, Winv, ld, j0, j0);
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            if (j > 0) {
+                own_slice(sl);
+                if (sl == 3) tile_sub_acc(X, accX, lane, wr, wc);
+            }
+            __syncthreads();
         }
+        if (a == 1) {
+            if (wave == 0 || wave == 3) trsm_tile_next<true>(X, S, dprep, rinv, Dn_out);
+            else trsm_tile_next<false>(X, S, dprep, rinv, Dn_out);
+        } else {
+            trsm_tile<true>(X, S, dprep, rinv);
+        }
+        tile_s2g(X, A, ld, i0, j0);
         return;
     }
-    if (a == 1) {
-        if (wave == 0 || wave == 3) trsm_tile_next<true>(X, S, dprep, rinv, Dn_out);
-        else trsm_tile_next<false>(X, S, dprep, rinv, Dn_out);
-    } else {
-        trsm_tile(X, S, dprep, rinv);
+    if (form_now) {
+        // step 0 of the Lambda chain forms its tiles instead of loading them; the last workgroup also writes xi
+        if (!panel) tile_form_r(rX, form, ld, i0, k0);
+        else tile_form_r(rS, form, ld, j0, j0);
+        if (blockIdx.x == gridDim.x - 1) form_xi(form, ld, tid);
+    } else if (!panel) tile_g2r(rX, A, ld, i0, k0);
+    else tile_g2r(rS, A, ld, j0, j0);
+    if (panel && j > 0) tile_g2r(rD, Dn_in, TB, 0, 0);    // the diagonal tile's rank-64 update, formed by the previous launch
+    if (!panel) {
+        if (j > 0) {
+            const int p0 = (j - 1) * TB;
+            load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
+            if (a != b) load_panel_n(P1, A, ld, k0, p0, TB, tid);   // L_{k, j-1}
+            __syncthreads();
+            tile_mma(accX, P0, (a != b) ? P1 : P0, TB, lane, wr, wc);
+            __syncthreads();
+        }
+        // plain trailing tile: A_ik -= acc, through LDS for coalesced global access
+        tile_r2s(X, rX);
         __syncthreads();
+        tile_sub_acc(X, accX, lane, wr, wc);
+        __syncthreads();
+        tile_s2g(X, A, ld, i0, k0);
+        return;
     }
-    tile_s2g(X, A, ld, i0, j0);
+    // ---- the diagonal block (a == b == 0) ----
+    if (j > 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) rS.v[u] -= rD.v[u];
+    }
+    tile_r2s(S, rS);
+    __syncthreads();
+    potf2_tile(S, dprep, rinv, info, j0, n_valid);
+    if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);       // no other block reads A_jj in the last step
+    else
+        for (int e = tid; e < TB * TB; e += 256) scratch[e] = S[(e & 63) * LT + (e >> 6)];   // column-major tile
+    if (Winv) {
+        trtri_tile(S, rinv, X, lds);
+        tile_s2g(X, Winv, ld, j0, j0);
+    }
 }
 
 // v[kk] = V[64 kb + kk][j] = W'[Qp-1-64kb-kk][Qp-1-j]: 64 contiguous doubles of column Qp-1-j of W' (descending), read
