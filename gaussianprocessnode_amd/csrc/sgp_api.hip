@@ -1109,6 +1109,13 @@ extern "C" int sgp_get_chain_trace(sgp_handle* h, int32_t which, int64_t* out) {
     return 0;
 }
 
+extern "C" int sgp_get_step_trace(int64_t* out) {
+    if (!out) return SGP_ERR_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return SGP_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_trace), sizeof(long long) * 16 * 32) != hipSuccess) return SGP_ERR_HIP;
+    return 0;
+}
+
 extern "C" int sgp_get_phase_totals(sgp_handle* h, int64_t* totals, int64_t* count, int32_t reset) {
     if (!h || !totals || !count) return SGP_ERR_ARG;
     int rc = sync_all(h);

@@ -666,15 +666,21 @@ __device__ __forceinline__ void solve16(double (&x)[4], const double* Dp, const 
 // Factor the 64 x 64 tile S (LDS, S[r][c], stride LT, lower part valid) in place: on exit S holds L (strict upper part
 // zero), rinv[c] = 1 / L_cc and Dp (4 DPB doubles of LDS) the four diagonal 16 x 16 blocks in the form solve16 reads.
 // Blocked by 16 columns, wave w owns rows 16 w .. 16 w + 15:
-//   (1) every wave w >= cb subtracts the contribution of the block columns to the left from its 16 x 16 block (one MFMA
-//       product, K = 16 cb, wave-local);
+//   (1) every wave w > cb subtracts the contribution of the block columns to the left from its 16 x 16 block (w, cb) (one
+//       MFMA product, K = 16 cb, wave-local);
 //   (2) wave cb factors its diagonal 16 x 16 block: entries in registers, the pivot row / column exchanged by DPP row
 //       broadcast and ds_bpermute -- all inside ONE wave, so the 16 pivots need no workgroup barrier;
-//   (3) after a barrier the waves below solve their 16 x 16 block against it (rows independent, in registers).
+//   (3) after a barrier the waves below solve their 16 x 16 block against it (rows independent, in registers) and at once
+//       subtract its square from their own diagonal block (w, w).
 // Two workgroup barriers per 16 pivots instead of one per pivot.  `idle_work(cb)` is called by the three waves that wait
 // while wave cb runs its 16 pivots (k_potrf_step gives them a slice of the block's own rank-64 update).
 // `solve_hook(cb, k)` is called once per pivot by the waves that solve below block cb, `solve_idle(cb)` by wave cb, which
 // waits there.
+#ifdef SGP_POTF2_LEFT_LOOKING          // A/B switch: the diagonal blocks updated left-looking, in front of their pivot runs
+constexpr int POTF2_LEFT = 1;
+#else
+constexpr int POTF2_LEFT = 0;
+#endif
 template <class IdleWork, class SolveHook, class SolveIdle>
 __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, int* info, int col_base, int n_valid,
                                            IdleWork&& idle_work, SolveHook&& solve_hook, SolveIdle&& solve_idle) {
@@ -685,14 +691,21 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
     static_for<4>([&](auto cbc) {
         constexpr int cb = decltype(cbc)::value;
         if constexpr (cb > 0) {
-            if (wave >= cb) {
-                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+            if (wave > cb - POTF2_LEFT) {                                // (the pivot wave's own block is already up to date, see (3))
+                d4 acc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
                 const double* ap = S + (r0 + li) * LT + lk;              // A[i][k] = L[r0 + i][k]
                 const double* bp = S + (16 * cb + li) * LT + lk;         // B[k][j] = L[16 cb + j][k]
+                double av[4 * cb], bv[4 * cb];
 #pragma unroll
-                for (int s4 = 0; s4 < 4 * cb; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s4], bp[4 * s4], acc, 0, 0, 0);
+                for (int s4 = 0; s4 < 4 * cb; ++s4) { av[s4] = ap[4 * s4]; bv[s4] = bp[4 * s4]; }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= acc[r];
+                for (int s4 = 0; s4 < 4 * cb; ++s4)
+                    acc[s4 & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc[s4 & 3], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    S[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
             }
         }
         if (wave == cb) {
@@ -771,6 +784,23 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
             solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [&](auto kc) { solve_hook(cbc, kc); });
 #pragma unroll
             for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
+            // The wave's OWN diagonal block loses L(w, cb) L(w, cb)^T right away -- its rows only, no other wave involved --
+            // so that a wave that becomes the pivot wave starts its 16 pivots with nothing left to subtract: the
+            // left-looking form put 4 cb dependent MFMAs (~200 cycles each) in front of every pivot run.
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (!POTF2_LEFT) {
+                const double* dp = S + (r0 + li) * LT + 16 * cb + lk;    // A[i][k] = L[r0 + i][16 cb + k] = B[k][i]
+                double dv[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) dv[s4] = dp[4 * s4];
+                d4 g[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    g[s4] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[s4], dv[s4], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    S[(r0 + lk + 4 * r) * LT + r0 + li] -= (g[0][r] + g[1][r]) + (g[2][r] + g[3][r]);
+            }
         } else if (wave == cb) {
             solve_idle(cbc);
         } else {
@@ -1290,6 +1320,15 @@ __device__ __forceinline__ void form_xi(const LamForm& form, int ld, int tid) {
     }
 }
 
+// Diagnostics (build with -DSGP_STEP_TRACE): 100 MHz stamps of the workgroup that owns tile (j + 1, j) of the Lambda chain,
+// slot 16 g + e of step j for event e of group g (0 factoring, 1 solve); read back with sgp_get_step_trace.
+__device__ long long g_step_trace[16 * 32];
+#ifdef SGP_STEP_TRACE
+#define STEP_TRACE(e) do { if (tv_t && a == 1 && b == 0 && lane == 0 && wave == 0 && j < 16) g_step_trace[j * 32 + (xgroup ? 16 : 0) + (e)] = realtime_ticks(); } while (0)
+#else
+#define STEP_TRACE(e) do { } while (0)
+#endif
+
 // Workgroups are launched with PSTEP_THREADS = 512 threads.  Only the blocks of the panel column below the diagonal use
 // the second half (the "solve group", waves 4 .. 7: they carry the block's own tile -- its rank-64 update, then its
 // triangular solve column block by column block, in step with the factoring group's eight barriers -- while waves 0 .. 3
@@ -1351,11 +1390,13 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     TileRegs rX, rS, rD;
     const bool form_now = (j == 0 && form.stats);
     if (form_now) stamp_enter(form.stamps);
+    STEP_TRACE(0);
     if (panel && a != 0) {
         // ---- a block of the panel column below the diagonal: two groups of four waves ----
         if (!xgroup) {
             // factoring group: the diagonal tile A_jj (minus the rank-64 update the previous launch formed), factored here
             // redundantly -- no inter-block hand-off -- while the solve group works on the block's own tile
+            __builtin_amdgcn_s_setprio(3);                // (the latency-bound group goes first where both want the same SIMD)
             if (form_now) tile_form_r(rS, form, ld, j0, j0);
             else tile_g2r(rS, A, ld, j0, j0);
             if (j > 0) {
@@ -1365,8 +1406,11 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             }
             if (form_now && blockIdx.x == gridDim.x - 1) form_xi(form, ld, tid);
             tile_r2s(S, rS);
+            STEP_TRACE(1);
             __syncthreads();
+            STEP_TRACE(2);
             potf2_tile(S, dprep, rinv, info, j0, n_valid);
+            STEP_TRACE(3);
             return;
         }
         // solve group: the own tile (j + a, j).  Its rank-64 update L_{i,j-1} L_{j,j-1}^T takes the first four of the
@@ -1380,7 +1424,9 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             load_panel_n(P1, A, ld, k0, p0, TB, tid);         // L_{j, j-1}
         }
         tile_r2s(X, rX);
+        STEP_TRACE(1);
         __syncthreads();
+        STEP_TRACE(2);
         auto own_slice = [&](int sl) {
             const int li = lane & 15, lk = lane >> 4;
             const double* ap = P0 + (16 * sl + lk) * PS + wr * 32 + li;
@@ -1397,11 +1443,15 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         };
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
+#ifndef SGP_EXPERIMENT_NO_SLICES
             if (j > 0) {
                 own_slice(sl);
                 if (sl == 3) tile_sub_acc(X, accX, lane, wr, wc);
             }
+#endif
+            STEP_TRACE(3 + 2 * sl);
             __syncthreads();
+            STEP_TRACE(4 + 2 * sl);
         }
         if (a == 1) {
             if (wave == 0 || wave == 3) trsm_tile_next<true>(X, S, dprep, rinv, Dn_out);
@@ -1409,7 +1459,9 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         } else {
             trsm_tile<true>(X, S, dprep, rinv);
         }
+        STEP_TRACE(11);
         tile_s2g(X, A, ld, i0, j0);
+        STEP_TRACE(12);
         return;
     }
     if (form_now) {

@@ -242,6 +242,10 @@ int sgp_get_phase_totals(sgp_handle* h, int64_t* totals /* SGP_T_COUNT */, int64
  * [14] last product slice awaited, [10] ... done, [11] / [12] shipment stored by waves 0 / 4.
  * [16 + 4 cb ..]: that feeder's wave 0 at column block cb: block in registers, solved, published, updates applied.
  * which: 0 = K_uu chain, 1 = Lambda chain. */
+/* diagnostics of the Cholesky step kernel (all zeros unless the library was built with -DSGP_STEP_TRACE): out[512],
+ * 100 MHz stamps of the workgroup that owns tile (j + 1, j) of the Lambda chain; slot 32 j + 16 g + e = event e of wave
+ * group g (0 factoring, 1 solve) in step j. */
+int sgp_get_step_trace(int64_t* out /* 512 */);
 int sgp_get_chain_trace(sgp_handle* h, int32_t which, int64_t* out /* 384 */);
 /* HIP-event timing of one data-sized kernel (which = SGP_T_GRAM or SGP_T_SYRK) launched eagerly `iters` times on
  * `stream` with the resident data of the last sweep; returns the average launch duration in microseconds. */

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-phase timing of the Cholesky step kernel's critical workgroup (tile (j+1, j) of the Lambda chain), from a library built
+with -DSGP_STEP_TRACE:  SGP_LIB=ab/lib_trace.so python tools/step_trace.py"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import gaussianprocessnode_amd as G
+from gaussianprocessnode_amd import _lib
+
+N, M, D = 10000, 512, 8
+rng = np.random.default_rng(0)
+X = rng.uniform(-1.7, 1.7, (N, D)); Xu = X[:M].copy(); y = np.sin(X.sum(1))
+with G.SGPDevice(N, M, D) as dev:
+    dev.set_inducing(Xu); dev.set_data(X, y); dev.set_kernel(0.9, np.linspace(1.5, 3, D), 0.0)
+    dev.set_prior_isotropic(50.0); dev.set_noise([[1e4]])
+    for _ in range(20): dev.sweep()
+    try:
+        dev.scalars()
+    except Exception as e:                      # (experimental builds may produce garbage; the stamps are still valid)
+        print('note:', type(e).__name__)
+    out = (C.c_int64 * 512)()
+    _lib.load().sgp_get_step_trace(out)
+t = np.array(out[:], dtype=np.int64).reshape(16, 2, 16)
+names_f = ["entry", "tiles in LDS", "barrier", "potf2 done"]
+names_x = ["entry", "tiles in LDS", "barrier", "slice0", "b", "slice1", "b", "slice2", "b", "slice3+sub", "b", "trsm done", "stored"]
+for j in range(8):
+    f, x = t[j, 0], t[j, 1]
+    if f[0] == 0: continue
+    t0 = min(f[0], x[0])
+    print(f"step {j}: factoring " + " ".join(f"{n}={(f[i]-t0)/100:.2f}" for i, n in enumerate(names_f)))
+    print(f"        solve     " + " ".join(f"{n}={(x[i]-t0)/100:.2f}" for i, n in enumerate(names_x)))
+    if j + 1 < 8 and t[j + 1, 0, 0]: print(f"        next step's entry at {(min(t[j+1,0,0], t[j+1,1,0]) - t0)/100:.2f}")
