@@ -164,6 +164,10 @@ def main():
     import ctypes as C
     sclk = C.c_double()
     _lib.check(dev._lib.sgp_measure_sclk_mhz(local_rank, C.byref(sclk)), None, "sgp_measure_sclk_mhz")
+    clocks = (C.c_double * 4)()
+    _lib.check(dev._lib.sgp_measure_clocks(local_rank, clocks), None, "sgp_measure_clocks")
+    sclk_mfma, mfma_probe_tflops, n_cus = clocks[0], clocks[1], int(clocks[3])
+    peak_at_clock = n_cus * 4 * 32.0 * sclk_mfma * 1e6 / 1e12     # 4 SIMDs x (2048 flop / 64 cycles) per CU at the measured clock
     f1_us = tick_us(_lib.SGP_T_FINISH1)
     Qp = (M + 63) // 64 * 64
     chain_floor_us = Qp * PIVOT_CYCLES / sclk.value              # the pivots of one factorisation, nothing else
@@ -190,6 +194,7 @@ def main():
                                   "where": "inside sgp_sweep (C ABI all-reduce hook) on the sweep's stream" if sweep.hooked
                                            else "none (single rank)"}},
         "sclk_mhz": sclk.value,
+        "sclk_mhz_under_mfma_f64": sclk_mfma,
         "roofline": {"kernel": "k_syrk_stream (Psi2 = K_uf K_uf^T, v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -198,8 +203,13 @@ def main():
                      "launch_us": syrk_us_alone, "launch_us_in_timed_region": syrk_us, "launches_averaged": int(n_counted),
                      "achieved_in_timed_region": syrk_flops / (syrk_us * 1e-6) / 1e12 if syrk_us > 0 else None,
                      "algorithmic_flops_per_launch": syrk_flops,
-                     "peak_note": "78.6 = MI355X FP64 matrix spec; a back-to-back MFMA loop (tools/mfma_f64_probe.hip) saturates at "
-                                  "49 at the sclk above, v_fma_f64 at 63-67"},
+                     "peak_at_measured_clock": peak_at_clock, "frac_of_peak_at_measured_clock": achieved / peak_at_clock if peak_at_clock > 0 else None,
+                     "mfma_probe_tflops": mfma_probe_tflops,
+                     "frac_of_mfma_probe": achieved / mfma_probe_tflops if mfma_probe_tflops > 0 else None,
+                     "peak_note": "78.6 = MI355X FP64 matrix spec (256 CUs x 4 SIMDs x 2048 flop / 64 cycles at 2.4 GHz); "
+                                  "peak_at_measured_clock = the same arithmetic at the shader clock the chip holds under "
+                                  "back-to-back v_mfma_f64 (sclk_mhz_under_mfma_f64, sgp_measure_clocks); mfma_probe_tflops = "
+                                  "what that back-to-back loop itself attains on this box"},
         # the sweep's critical path is the Lambda factorisation chain: latency-bound, priced against its pivot floor
         "roofline_chain": {"kernel": "k_potrf_step x (M/64 + 1) + k_trmv_mu_scan (Lambda = L L^T, inverse factor, Sigma rows, t, mu)",
                            "bound": "latency (dependent pivot chain)", "achieved_us": f1_us, "floor_us": chain_floor_us,

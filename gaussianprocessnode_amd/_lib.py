@@ -28,7 +28,7 @@ EXPORTS = [
     "sgp_stats_layout", "sgp_bind_stats", "sgp_get_posterior", "sgp_get_scalars", "sgp_get_stats",
     "sgp_get_kuu_chol", "sgp_get_wishart_invscale", "sgp_w_stats", "sgp_predict", "sgp_theta_objective", "sgp_carry_posterior", "sgp_set_posterior",
     "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_get_phase_totals", "sgp_time_kernel", "sgp_get_chain_trace", "sgp_set_allreduce", "sgp_use_rccl", "sgp_measure_sclk_mhz",
-    "sgp_train_begin", "sgp_train_step", "sgp_train_end", "sgp_get_step_trace",
+    "sgp_train_begin", "sgp_train_step", "sgp_train_end", "sgp_get_step_trace", "sgp_measure_clocks",
 ]
 
 
@@ -119,6 +119,7 @@ def load(build_if_missing: bool = True):
     lib.sgp_train_step.argtypes = [vp, C.c_int64, C.c_int64, C.c_int32]
     lib.sgp_train_end.argtypes = [vp, dp, C.POINTER(C.c_int64)]
     lib.sgp_get_step_trace.argtypes = [C.POINTER(C.c_int64)]
+    lib.sgp_measure_clocks.argtypes = [C.c_int32, dp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "sgp_last_error":

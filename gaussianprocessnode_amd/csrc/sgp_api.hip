@@ -972,6 +972,54 @@ extern "C" int sgp_measure_sclk_mhz(int32_t device, double* mhz) {
     return 0;
 }
 
+// The same under matrix-core load: every wave issues independent v_mfma_f64_16x16x4_f64 back to back (4 accumulators), one
+// resident round of 4 workgroups per CU.  out[0] = shader clock (MHz) during the loop, out[1] = FP64 matrix rate the loop
+// attained (TFLOP/s, 2048 flop per instruction), out[2] = shader clock under the v_fma_f64 loop above, out[3] = number of CUs.
+__global__ void __launch_bounds__(256) k_clock_probe_mfma(long long* out, int iters) {
+    typedef double d4v __attribute__((ext_vector_type(4)));
+    d4v c0v = {0.0, 0.0, 0.0, 0.0}, c1v = c0v, c2v = c0v, c3v = c0v;
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 1e-9;
+    const long long c0 = (long long)__builtin_amdgcn_s_memtime(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        c0v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0v, 0, 0, 0);
+        c1v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1v, 0, 0, 0);
+        c2v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2v, 0, 0, 0);
+        c3v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3v, 0, 0, 0);
+    }
+    const long long c1 = (long long)__builtin_amdgcn_s_memtime(), r1 = (long long)__builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = (long long)(c0v[0] + c1v[1] + c2v[2] + c3v[3]); }
+}
+extern "C" int sgp_measure_clocks(int32_t device, double* out) {
+    if (!out) return SGP_ERR_ARG;
+    int rc = set_device_checked(device);
+    if (rc) return rc;
+    sgp_handle* h = nullptr;
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, device));
+    const int cus = prop.multiProcessorCount, blocks = 4 * cus, iters = 4000;
+    DevBuf b;
+    HIPCHK(h, b.alloc(3 * sizeof(long long)));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_clock_probe_mfma, dim3(blocks), dim3(256), 0, 0, b.as<long long>(), iters);       // warm the clocks
+    HIPCHK(h, hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_clock_probe_mfma, dim3(blocks), dim3(256), 0, 0, b.as<long long>(), iters);
+    HIPCHK(h, hipEventRecord(e1, 0));
+    HIPCHK(h, hipDeviceSynchronize());
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    long long v[3];
+    HIPCHK(h, hipMemcpy(v, b.p, sizeof v, hipMemcpyDeviceToHost));
+    out[0] = v[1] > 0 ? 100.0 * (double)v[0] / (double)v[1] : 0.0;
+    out[1] = ms > 0.f ? (double)blocks * 4.0 * iters * 4.0 * 2048.0 / (ms * 1e-3) * 1e-12 : 0.0;
+    rc = sgp_measure_sclk_mhz(device, out + 2);
+    out[3] = cus;
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // results
 // ------------------------------------------------------------------------------------------------

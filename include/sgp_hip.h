@@ -141,6 +141,11 @@ int sgp_use_rccl(sgp_handle* h, void* nccl_comm);
 /* shader clock the chip holds under a short FP64 load (MHz): Delta s_memtime / Delta s_memrealtime x 100 MHz (bench.py reports it
  * next to the roofline fractions) */
 int sgp_measure_sclk_mhz(int32_t device, double* mhz);
+/* sgp_measure_clocks: the same under matrix-core load.  out[0] = shader clock (MHz) while every wave issues independent
+ * v_mfma_f64_16x16x4_f64 back to back (one resident round, 4 workgroups per CU), out[1] = the FP64 matrix rate that loop
+ * attains (TFLOP/s) -- the attainable peak the SYRK roofline can be priced against --, out[2] = shader clock under the
+ * v_fma_f64 loop of sgp_measure_sclk_mhz, out[3] = number of CUs. */
+int sgp_measure_clocks(int32_t device, double* out /* 4 */);
 
 /* packed statistics buffer (device): [Psi2: Mp*Mp | B: Mp*d_out | scalars: SGP_S_COUNT (+ d_out*d_out Ryy)]
  * Mp = M rounded up to the tile size; count = total doubles to all-reduce. */

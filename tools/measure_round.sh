@@ -18,7 +18,7 @@ rm -rf /tmp/pmc_m && timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MF
 h=$(find /tmp/pmc_m -name "*counter_collection.csv" | head -1); cp $h $O/pmc_mfma_raw.csv; python3 $R/tools/pmc_mfma_summary.py $h > $O/pmc_mfma.txt 2>&1; echo "pmc mfma done"
 rm -rf /tmp/kt && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline > $O/kt.json 2> $O/kt.err
 f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); g=$(find /tmp/kt -name "*kernel_stats.csv" | head -1)
-python3 $R/tools/timeline.py $f > $O/timeline.txt; cp $g $O/kernel_stats.csv; python3 $R/tools/kstats.py $g 60 > $O/kernel_stats_per_sweep.txt 2>&1
+python3 $R/tools/timeline.py $f > $O/timeline.txt; python3 $R/tools/syrk_launches.py $f > $O/syrk_launches.txt 2>&1; cp $g $O/kernel_stats.csv; python3 $R/tools/kstats.py $g 60 > $O/kernel_stats_per_sweep.txt 2>&1
 echo "trace done"
 cd $R
 timeout -k 10 300 python bench.py > $O/bench_T.json 2> $O/bench_T.err; tail -c 400 $O/bench_T.json; echo
@@ -27,3 +27,5 @@ timeout -k 10 200 python tools/config_rates.py > $O/config_rates.txt 2>&1; tail 
 timeout -k 10 300 python tools/accuracy_sweep.py 100 > $O/accuracy_sweep.txt 2>&1; grep "worst" $O/accuracy_sweep.txt
 timeout -k 10 120 python examples/train_kin40k.py > $O/train_kin40k.txt 2>&1; tail -2 $O/train_kin40k.txt
 timeout -k 10 120 python examples/train_banana.py > $O/train_banana.txt 2>&1; tail -2 $O/train_banana.txt
+L=gaussianprocessnode_amd/csrc/libsgp_hip.so
+if [ -f ab/lib_trace.so ]; then cp $L /tmp/keep.so; cp ab/lib_trace.so $L; timeout -k 10 120 python tools/step_trace.py > $O/step_trace.txt 2>&1; cp /tmp/keep.so $L; fi
