@@ -94,6 +94,9 @@ struct sgp_handle {
     uint64_t main_prep_gen = 0;    // the generation k_prep_xu last mirrored onto the main stream's copies (dXus, dParams)
     Params* dParams = nullptr;
     Params* dParamsK = nullptr;    // the K_uu chain's own copy (it runs on the side stream)
+    long long* dJoin = nullptr;    // device-side join word of the two streams (see UvArgs::join)
+    long long join_epoch = 0;
+    bool join_by_flag = false;     // this sweep's F2 waits on dJoin inside k_gemm32 instead of on evSide
     const Params* params_src = nullptr;   // what k_prep_xu mirrors: hParams, or dTrainParams while a device-paced run is open
     // device-paced training (sgp_train_*): the resident training set, the optimiser state and the parameter source
     double *dTrainX = nullptr, *dTrainY = nullptr;
@@ -351,6 +354,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dBpart, nblk_max * h->dout * Mp);
     ALLOC(h->dSlabs, h->slab_capacity);
     ALLOC(h->dStatsOwn, (size_t)h->stats_count);
+    ALLOC(h->dJoin, 2);
     ALLOC(h->dDataScal, SGP_S_COUNT + (size_t)h->dout * h->dout);
     ALLOC(h->dKuu, Mp * Mp);
     ALLOC(h->dWk, Mp * Mp);
@@ -446,6 +450,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         return SGP_ERR_HIP;
     }
     hipMemset(h->dInfo, 0, 4 * sizeof(int));
+    hipMemset(h->dJoin, 0, 2 * sizeof(long long));
     hipMemset(h->dOut, 0, SGP_R_COUNT * sizeof(double));
     hipMemset(h->dStamps, 0, STAMP_STRIDE * SGP_T_COUNT * sizeof(int64_t));
     hipMemset(h->dStampTotals, 0, (SGP_T_COUNT + 1 + 2 * SGP_T_COUNT) * sizeof(int64_t));
@@ -474,7 +479,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
                     h->dChainRinv[0][0], h->dChainRinv[0][1], h->dChainRinv[1][0], h->dChainRinv[1][1],
                     h->dChainTrace[0], h->dChainTrace[1], h->dKuuAlt, h->dLamAlt,
                     h->dChainArgs[0][0], h->dChainArgs[0][1], h->dChainArgs[1][0], h->dChainArgs[1][1],
-                    h->dTrainX, h->dTrainY, h->dTrain, h->dTrainParams};
+                    h->dTrainX, h->dTrainY, h->dTrain, h->dTrainParams, h->dJoin};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evSide) hipEventDestroy(h->evSide);
@@ -726,6 +731,7 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
         launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk, nullptr, h->dSaccK);
     }
     launch_ata(h->dWk, h->dKinv, Mp, T, s, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->dSaccK);
+    if (h->join_by_flag) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin, h->join_epoch);
 }
 
 static void enqueue_local(sgp_handle* h, hipStream_t s) {
@@ -800,6 +806,8 @@ static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
     UvArgs uv;
     uv.Wp = h->dWl; uv.p = uvp; uv.ck = uvck; uv.ak = uvak; uv.partial = uvpart; uv.LR = h->dUvT;
     uv.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
+    uv.join = h->join_by_flag ? h->dJoin : nullptr;
+    uv.join_need = h->join_epoch;
     if (h->dout == 1) {
         launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, h->dStats, h->dKinv, traceR, &uv, h->dTmp);
         partK = traceR + nata;
@@ -879,6 +887,16 @@ extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) {
     // joined just before the Sigma launch.  The main stream itself only ever WAITS on the side stream's event and records
     // one event at the very end of a sweep: an event record between two of its kernels was measured at ~6 us of idle time.
     HIPCHK(h, hipStreamWaitEvent(h->side, h->evDone, 0));
+    // How F2 will join the K_uu chain: an event wait between two kernels of the main stream costs it ~5 us of idle time even
+    // when the event fired long ago, so the UniSGP path lets the Sigma launch's product workgroups poll a device word in
+    // front of their epilogue instead (k_join_set behind the chain's last kernel).  Only while that launch leaves enough
+    // CUs free for a late chain's workgroups (each needs a whole CU's LDS), and not inside captured graphs.
+    {
+        const int grid = h->TQ * (h->TQ + 1) / 2 * 4 + h->TQ * h->TQ;
+        h->join_by_flag = h->dJoin && h->dout == 1 && !(h->cfg.flags & SGP_FLAG_GRAPH) && grid <= h->num_cus - 40 &&
+                          !getenv("SGP_JOIN_EVENT");
+        ++h->join_epoch;
+    }
     ++h->gate_epoch;
     h->gate_kuu = h->use_chain && h->n > 0;                    // (a SYRK launch follows on the main stream and opens the gate)
     rc = run_sequence(h, h->gKuu, enqueue_kuu, h->side);
@@ -902,7 +920,7 @@ extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
     h->in_flight = true;
     int rc = run_sequence(h, h->gFinish, enqueue_finish1, s);
     if (rc) return rc;
-    HIPCHK(h, hipStreamWaitEvent(s, h->evSide, 0));          // join with the K_uu chain
+    if (!h->join_by_flag) HIPCHK(h, hipStreamWaitEvent(s, h->evSide, 0));          // join with the K_uu chain
     rc = run_sequence(h, h->gFinish2, enqueue_finish2, s);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->evDone, s));                 // the next sweep's K_uu chain may overwrite K_uu^-1 after this

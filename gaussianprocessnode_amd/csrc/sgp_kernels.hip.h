@@ -1528,7 +1528,20 @@ struct UvArgs {
     const double* partial;
     double* LR;
     int64_t* stamps;
+    // device-side join with the K_uu chain (side stream): the product workgroups read K_uu^-1 only in their epilogue and
+    // wait there until *join >= join_need (set by k_join_set behind the chain's last kernel); nullptr = the caller joined
+    // the streams with an event
+    const long long* join;
+    long long join_need;
 };
+constexpr int JOIN_SPIN_LIMIT = 1 << 21;    // polls of >= ~0.5 us before a waiter gives up (its trace shares become NaN)
+__device__ __forceinline__ bool join_ready(const long long* w, long long need) {
+    return __hip_atomic_load((const __attribute__((address_space(1))) long long*)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+}
+__global__ void k_join_set(long long* w, long long v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        __hip_atomic_store((__attribute__((address_space(1))) long long*)w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void uv_cols_role(const UvArgs& u, int Qp, int kb, int jb) {
     const int lane = threadIdx.x, j = 64 * jb + lane;
     double* out = u.LR + (size_t)(64 * kb) * Qp + j;
@@ -1621,6 +1634,9 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
     const size_t offA = (size_t)gcA * ld + grA, offB = (size_t)gcB * ld + grB;
     double2 p0 = make_double2(0.0, 0.0), p1 = p0, q0 = p0, q1 = p0;
     double muA[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, muB[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    // K_uu^-1 comes from the side stream's chain.  Normally that finished long ago: one poll, and the operands are fetched
+    // now like the others.  If not, the product goes first and the workgroup waits in front of its epilogue.
+    bool kinv_late = false;
     if (mode == 0 && mu) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { muA[e] = mu[grA + e]; muB[e] = mu[grB + e]; }
@@ -1628,7 +1644,8 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
         muB[4] = mu[gcB];
         if (Psi2) {
             p0 = *reinterpret_cast<const double2*>(Psi2 + offA); p1 = *reinterpret_cast<const double2*>(Psi2 + offA + 2);
-            q0 = *reinterpret_cast<const double2*>(Kinv + offA); q1 = *reinterpret_cast<const double2*>(Kinv + offA + 2);
+            kinv_late = uv.join && !join_ready(uv.join, uv.join_need);
+            if (!kinv_late) { q0 = *reinterpret_cast<const double2*>(Kinv + offA); q1 = *reinterpret_cast<const double2*>(Kinv + offA + 2); }
         }
     }
     for (int k = kbeg; k < kend; ++k) {
@@ -1672,6 +1689,20 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
             *reinterpret_cast<double2*>(R + offA + 2) = make_double2(rv[2], rv[3]);
             if (Psi2) {
                 tsum = fma(rv[0], p0.x, fma(rv[1], p0.y, fma(rv[2], p1.x, rv[3] * p1.y)));
+                if (kinv_late) {                                         // the K_uu chain was still running at entry
+                    int it = 0;
+                    while (!join_ready(uv.join, uv.join_need) && ++it < JOIN_SPIN_LIMIT) __builtin_amdgcn_s_sleep(8);
+                    if (it < JOIN_SPIN_LIMIT) {
+                        // (bypassing this XCD's L2: lines of the previous sweep's K_uu^-1 may sit there -- the kernel-start
+                        // invalidate came before the chain's write-back)
+                        const __attribute__((address_space(1))) double* kq = (const __attribute__((address_space(1))) double*)(Kinv + offA);
+                        q0.x = __hip_atomic_load(kq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        q0.y = __hip_atomic_load(kq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        q1.x = __hip_atomic_load(kq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        q1.y = __hip_atomic_load(kq + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else
+                        q0.x = __builtin_nan("");                        // gave up: the trace (and the energy) come out NaN
+                }
                 tsumK = fma(q0.x, p0.x, fma(q0.y, p0.y, fma(q1.x, p1.x, q1.y * p1.y)));
             }
         }
