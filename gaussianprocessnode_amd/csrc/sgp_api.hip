@@ -97,6 +97,7 @@ struct sgp_handle {
     long long* dJoin = nullptr;    // device-side join word of the two streams (see UvArgs::join)
     long long join_epoch = 0;
     bool join_by_flag = false;     // this sweep's F2 waits on dJoin inside k_gemm32 instead of on evSide
+    long long done_epoch = 0;      // dJoin[1]: the last value a sweep's final kernel was told to write (see k_scalars)
     const Params* params_src = nullptr;   // what k_prep_xu mirrors: hParams, or dTrainParams while a device-paced run is open
     // device-paced training (sgp_train_*): the resident training set, the optimiser state and the parameter source
     double *dTrainX = nullptr, *dTrainY = nullptr;
@@ -718,8 +719,10 @@ extern "C" int sgp_bind_stats(sgp_handle* h, void* stats_dev) {
 // different streams (parallel branches inside ONE captured graph were observed to execute back to back).
 static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
+    const bool words = !(h->cfg.flags & SGP_FLAG_GRAPH) && s == h->side;
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->params_src,
-                       h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0);
+                       h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0,
+                       words ? (const long long*)(h->dJoin + 1) : (const long long*)nullptr, h->done_epoch);
     if (h->use_chain) {
         if (h->gate_kuu)
             hipLaunchKernelGGL(k_chain_gate, dim3(1), dim3(64), 0, s, (const long long*)(h->dChainFlags[0] + CH_F_GATE), h->gate_epoch);
@@ -742,7 +745,8 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     const bool prep = h->main_prep_gen != h->params_gen || (h->cfg.flags & SGP_FLAG_GRAPH) || h->n <= 0;
     if (prep) {
         hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->params_src,
-                           h->dParams, (int*)nullptr, M, Mp, D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP);
+                           h->dParams, (int*)nullptr, M, Mp, D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP,
+                           (const long long*)nullptr, 0LL);
         h->main_prep_gen = h->params_gen;
     }
     if (h->n > 0) {
@@ -820,7 +824,8 @@ static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
     }
     hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, partK, nK, (const double*)traceR, nR, h->dMu, h->dKuu,
                        h->dLam, h->dInfo, h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q,
-                       h->dStamps + STAMP_STRIDE * SGP_T_FINISH2, h->dStamps, h->dStampTotals);
+                       h->dStamps + STAMP_STRIDE * SGP_T_FINISH2, h->dStamps, h->dStampTotals,
+                       (h->cfg.flags & SGP_FLAG_GRAPH) ? (long long*)nullptr : h->dJoin + 1, h->done_epoch);
 }
 
 static int set_device_checked(int device) {
@@ -886,7 +891,8 @@ extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) {
     // sweep has finished with its outputs, runs beside the data-sized kernels, the all-reduce and the Lambda chain, and is
     // joined just before the Sigma launch.  The main stream itself only ever WAITS on the side stream's event and records
     // one event at the very end of a sweep: an event record between two of its kernels was measured at ~6 us of idle time.
-    HIPCHK(h, hipStreamWaitEvent(h->side, h->evDone, 0));
+    // (eager launches: the chain's first kernel waits for the previous sweep's done word itself, see enqueue_kuu)
+    if (h->cfg.flags & SGP_FLAG_GRAPH) HIPCHK(h, hipStreamWaitEvent(h->side, h->evDone, 0));
     // How F2 will join the K_uu chain: an event wait between two kernels of the main stream costs it ~5 us of idle time even
     // when the event fired long ago, so the UniSGP path lets the Sigma launch's product workgroups poll a device word in
     // front of their epilogue instead (k_join_set behind the chain's last kernel).  Only while that launch leaves enough
@@ -921,9 +927,11 @@ extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
     int rc = run_sequence(h, h->gFinish, enqueue_finish1, s);
     if (rc) return rc;
     if (!h->join_by_flag) HIPCHK(h, hipStreamWaitEvent(s, h->evSide, 0));          // join with the K_uu chain
+    ++h->done_epoch;                                         // what this sweep's k_scalars writes when it is through
     rc = run_sequence(h, h->gFinish2, enqueue_finish2, s);
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->evDone, s));                 // the next sweep's K_uu chain may overwrite K_uu^-1 after this
+    // the next sweep's K_uu chain may overwrite K_uu^-1 after this
+    if (h->cfg.flags & SGP_FLAG_GRAPH) HIPCHK(h, hipEventRecord(h->evDone, s));
     h->swept = true;
     return 0;
 }
@@ -1294,7 +1302,7 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
     // sgp_theta_objective at unchanged theta still read (a predict between set_noise and theta_objective scaled
     // the gradient by w_new / w_old twice).
     hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, (const Params*)h->hParams,
-                       h->dParamsK, (int*)nullptr, h->M, h->Mp, h->D, (int64_t*)nullptr, 0, 0);
+                       h->dParamsK, (int*)nullptr, h->M, h->Mp, h->D, (int64_t*)nullptr, 0, 0, (const long long*)nullptr, 0LL);
     switch (h->D) {
         case 1: launch_predict<1>(h, dXs, dMu, dMean, ns, s); break;
         case 2: launch_predict<2>(h, dXs, dMu, dMean, ns, s); break;
@@ -1360,7 +1368,7 @@ static int theta_objective_eval(sgp_handle* h, hipStream_t s, double* value) {
     hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, (const double*)h->dTrace, (int)TRACE_BLOCKS,
                        (const double*)(h->dTrace + TRACE_BLOCKS), (int)TRACE_BLOCKS, h->dMu, h->dKuu, h->dLam, h->dInfo, h->dParams,
                        h->dOut2, h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q, (int64_t*)nullptr, (int64_t*)nullptr,
-                       (int64_t*)nullptr);
+                       (int64_t*)nullptr, (long long*)nullptr, 0LL);
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     double out[SGP_R_COUNT], sc[SGP_S_COUNT];
@@ -1499,7 +1507,7 @@ extern "C" int sgp_train_step(sgp_handle* h, int64_t offset, int64_t n, int32_t 
             hipLaunchKernelGGL(k_train_adamax, dim3(1), dim3(64), 0, s, h->dTrain, (const double*)h->dGrad, (const double*)h->dOut,
                                h->dTrainParams, h->D, h->n_ell, 1);
         // the next K_uu chain (side stream) reads the parameters this step wrote and overwrites the K_uu^-1 its gradient read
-        if (!rc && hipEventRecord(h->evDone, s) != hipSuccess) rc = fail(h, SGP_ERR_HIP, "sgp_train_step: hipEventRecord failed");
+        if (!rc) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + 1, ++h->done_epoch);
     }
     h->dX = ownX; h->dYw = ownYw; h->dY = ownY;
     h->have_data = false;                                      // the window is not the handle's data: set_data again after the run

@@ -139,7 +139,18 @@ __device__ __forceinline__ void stamp_accumulate(int64_t* stamps, int64_t* total
 // Also resets the Cholesky status word of the sequence (`info_reset`) and, on the main stream, the phase stamps.
 __global__ void k_prep_xu(const double* __restrict__ Xu, double* __restrict__ Xus, const Params* __restrict__ hP,
                           Params* __restrict__ dP, int* __restrict__ info_reset, int M, int Mp, int D, int64_t* stamps,
-                          int nslots, int sweep_slot) {
+                          int nslots, int sweep_slot, const long long* wait_word, long long wait_need) {
+    if (wait_word) {
+        // first kernel of the K_uu chain: the previous sweep's last kernel on the other stream still reads what this chain
+        // overwrites (see k_scalars).  Bounded; the buffers it protects are rewritten either way.
+        if (threadIdx.x == 0) {
+            int it = 0;
+            while (__hip_atomic_load((const __attribute__((address_space(1))) long long*)wait_word, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) < wait_need && ++it < (1 << 21))
+                __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+    }
     if (blockIdx.x == 0) {
         if (stamps) {                                               // first kernel of a sweep: reset the phase stamps
             for (int e = threadIdx.x; e < nslots * STAMP_STRIDE; e += blockDim.x) {
@@ -1889,7 +1900,10 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
                                                  const Params* __restrict__ P, double* __restrict__ out,
                                                  double* __restrict__ wishart, int M, int Mp, int d_out, int Q, int Qp,
                                                  int lam_off, int64_t* stamps, int64_t* all_stamps,
-                                                 int64_t* totals) {
+                                                 int64_t* totals, long long* done_word, long long done_value) {
+    // done_word (may be nullptr): set to done_value once this kernel -- the sweep's last reader of the K_uu chain's outputs --
+    // has read them; the next sweep's chain waits for it in its first kernel (k_prep_xu) instead of on an event, which
+    // between two kernels of this stream cost ~6 us of idle time
     __shared__ double red[4];
     __shared__ double redn[4 * 5];
     __shared__ double tr[TRACE_SLOTS];
@@ -1937,6 +1951,8 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
             out[5] = (double)c_i2;
             out[6] = 2.0 * t[2];
             out[7] = 2.0 * t[3];
+            if (done_word)
+                __hip_atomic_store((__attribute__((address_space(1))) long long*)done_word, done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         stamp_exit(stamps);
         if (all_stamps && tid >= 192) stamp_fold_finish(fold, all_stamps, totals, tid - 192);
@@ -2006,6 +2022,8 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
     stamp_exit(stamps);
     // last kernel of a sweep: close the sweep stamp and add this sweep's phase durations to the running totals
     __syncthreads();                                            // every wave's exit stamp of this kernel is in
+    if (done_word && tid == 0)
+        __hip_atomic_store((__attribute__((address_space(1))) long long*)done_word, done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (all_stamps && tid < 64) stamp_accumulate(all_stamps, totals, tid);
 }
 
