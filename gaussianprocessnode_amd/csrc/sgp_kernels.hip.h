@@ -387,7 +387,9 @@ __device__ __forceinline__ void tile_from_index(int t, int& I, int& J) {
 __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
                                                      double* __restrict__ slabs, int Mp, int64_t N, int chunk,
                                                      int ntiles, int nchunks, int64_t* stamps, long long* gate,
-                                                     long long gate_value) {
+                                                     long long gate_value, int accumulate) {
+    // accumulate != 0: the slabs already hold the sums over the earlier point ranges of this sweep (large-N pipeline:
+    // consecutive launches over consecutive ranges, so the summation order stays fixed)
     __shared__ double lds[2 * 2 * KB * PS];           // [buf][panel A|B][KB][PS]
     stamp_enter(stamps);
     // the last workgroup of this launch's single resident round is on a CU: whoever waited for that (k_chain_gate in front of
@@ -467,8 +469,10 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                out[acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj)] = acc.t[ti][tj][r];
+            for (int r = 0; r < 4; ++r) {
+                double* o = out + acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj);
+                *o = accumulate ? *o + acc.t[ti][tj][r] : acc.t[ti][tj][r];
+            }
     stamp_exit(stamps);
 }
 
