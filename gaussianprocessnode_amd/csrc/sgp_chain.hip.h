@@ -452,18 +452,6 @@ __device__ __forceinline__ void publish_zero16(double* A, size_t ld, int grow0, 
 //     wave 0 for X waves 4 and 7, wave 1 for 5, wave 2 for 6 (block 3 the X waves publish themselves: they are done then);
 //   * wave 0: receiving the far part of the next diagonal tile.
 constexpr int D_MAXB = 3;
-#ifdef CH_VARIANT_B
-__device__ __forceinline__ int d_block_count(int wave) { return wave >= 4 ? 0 : ((wave == 1 || wave == 2) ? 3 : 2); }
-__device__ __forceinline__ void d_block(int wave, int e, int& R, int& C) {
-    switch (wave * 4 + e) {
-        case 0: R = 0; C = 0; break;   case 1: R = 1; C = 0; break;
-        case 4: R = 1; C = 1; break;   case 5: R = 2; C = 0; break;   case 6: R = 2; C = 1; break;
-        case 8: R = 2; C = 2; break;   case 9: R = 3; C = 0; break;   case 10: R = 3; C = 1; break;
-        case 12: R = 3; C = 2; break;  case 13: R = 3; C = 3; break;
-        default: R = 0; C = 0; break;
-    }
-}
-#else
 __device__ __forceinline__ int d_block_count(int wave) { return wave >= 4 ? 0 : (wave == 0 ? 1 : 3); }
 __device__ __forceinline__ void d_block(int wave, int e, int& R, int& C) {
     //  wave 0: (0,0)   wave 1: (1,0) (1,1) (2,0)   wave 2: (2,1) (2,2) (3,0)   wave 3: (3,1) (3,2) (3,3)
@@ -475,7 +463,6 @@ __device__ __forceinline__ void d_block(int wave, int e, int& R, int& C) {
         default: R = 0; C = 0; break;
     }
 }
-#endif
 
 __device__ void chain_critical(const ChainArgs& g, double* lds, double* tiles, double* dprep, double* rinv, int* sy) {
     // sy: [0] runDone, [1..8] rowDone[wave], [9] dDone, [10] dtReady, [11] abort

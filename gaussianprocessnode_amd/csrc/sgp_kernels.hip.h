@@ -1458,12 +1458,10 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         };
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
-#ifndef SGP_EXPERIMENT_NO_SLICES
             if (j > 0) {
                 own_slice(sl);
                 if (sl == 3) tile_sub_acc(X, accX, lane, wr, wc);
             }
-#endif
             STEP_TRACE(3 + 2 * sl);
             __syncthreads();
             STEP_TRACE(4 + 2 * sl);
