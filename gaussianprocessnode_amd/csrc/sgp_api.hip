@@ -808,9 +808,14 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
                                    kuf, bp, h->dParams, M, Mp, D, cnt, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, sweep_begin);
             hipEventRecord(h->evPipe[c], h->pipe);
             hipStreamWaitEvent(s, h->evPipe[c], 0);
-            hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->pipe_nchunks), dim3(256), 0, s, kuf,
-                               h->has_omega ? h->dOmega + off : nullptr, h->dSlabs, Mp, cnt, h->pipe_chunk, h->ntiles,
-                               h->pipe_nchunks, h->dStamps + STAMP_STRIDE * SGP_T_SYRK, (long long*)nullptr, 0LL, c > 0 ? 1 : 0);
+            if (c == 0)
+                hipLaunchKernelGGL(k_syrk_stream<false>, dim3(h->ntiles * h->pipe_nchunks), dim3(256), 0, s, kuf,
+                                   h->has_omega ? h->dOmega + off : nullptr, h->dSlabs, Mp, cnt, h->pipe_chunk, h->ntiles,
+                                   h->pipe_nchunks, h->dStamps + STAMP_STRIDE * SGP_T_SYRK, (long long*)nullptr, 0LL);
+            else
+                hipLaunchKernelGGL(k_syrk_stream<true>, dim3(h->ntiles * h->pipe_nchunks), dim3(256), 0, s, kuf,
+                                   h->has_omega ? h->dOmega + off : nullptr, h->dSlabs, Mp, cnt, h->pipe_chunk, h->ntiles,
+                                   h->pipe_nchunks, h->dStamps + STAMP_STRIDE * SGP_T_SYRK, (long long*)nullptr, 0LL);
         }
         asm_chunks = h->pipe_nchunks;
     } else if (h->n > 0) {
@@ -820,10 +825,10 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
         else
             hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, h->dStamps);
-        hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
+        hipLaunchKernelGGL(k_syrk_stream<false>, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                            h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, h->ntiles, h->nchunks,
                            h->dStamps + STAMP_STRIDE * SGP_T_SYRK, h->use_chain ? h->dChainFlags[0] + CH_F_GATE : nullptr,
-                           h->gate_epoch, 0);
+                           h->gate_epoch);
     }
     hipLaunchKernelGGL(k_assemble, dim3(T, T, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
                        h->ntiles, asm_chunks, h->n > 0 ? h->nblk : 0, h->dout,
@@ -1286,9 +1291,9 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
             hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr, (int64_t*)nullptr);
         else
-            hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
+            hipLaunchKernelGGL(k_syrk_stream<false>, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                                h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->chunk, h->ntiles, h->nchunks,
-                               (int64_t*)nullptr, (long long*)nullptr, 0LL, 0);
+                               (int64_t*)nullptr, (long long*)nullptr, 0LL);
     };
     if (which != SGP_T_GRAM && which != SGP_T_SYRK) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: which must be SGP_T_GRAM or SGP_T_SYRK");
     launch();

@@ -125,16 +125,20 @@ class ShardedSweep:
     sweep_finish() and a torch tensor `stats`; `group` is a torch.distributed process group (None = default;
     no collective is issued when torch.distributed is not initialised or the world has one rank)."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, force_hook=False):
         self.engine = engine
         self.group = group
         import torch.distributed as dist
         self.dist = dist
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.backend = dist.get_backend(group) if self.world > 1 else "none"
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if live else 1
+        # force_hook: install the collective even in a one-rank world (what a one-GPU box can rehearse: the RCCL
+        # all-reduce of torch.distributed issued from inside sgp_sweep on the sweep's stream)
+        force_hook = bool(force_hook) and live
+        self.backend = dist.get_backend(group) if (self.world > 1 or force_hook) else "none"
         # Engines that run the exchange step inside their own sweep (HipEngine: the C ABI's all-reduce hook) get the
         # collective installed once; the others are driven half by half.
-        self.hooked = self.world > 1 and hasattr(engine, "install_allreduce")
+        self.hooked = (self.world > 1 or force_hook) and hasattr(engine, "install_allreduce")
         if self.hooked:
             engine.install_allreduce(self._reduce)
 

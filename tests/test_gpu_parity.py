@@ -4,7 +4,7 @@ posterior; FP64 end to end lands orders of magnitude below that, the asserts use
 conditioning allows and state the looser bound where it does not.
 """
 import math
-
+import os
 import zlib
 
 import numpy as np
@@ -898,3 +898,27 @@ def test_large_n_pipeline_matches_the_single_launch_and_the_oracle(G, monkeypatc
     K = O.kernelmatrix(s2, ell, Xu, X)
     assert relF(P2, (K * wts) @ K.T) < 1e-13
     assert relF(B.ravel(), K @ (wts * y)) < 1e-13
+
+
+def test_rccl_adapter_with_a_single_rank_communicator():
+    """sgp_use_rccl (include/sgp_hip.h): the library calls ncclAllReduce itself, inside sgp_sweep, on the sweep's stream.
+    A one-rank communicator is what a one-GPU box can offer: the reduce is the identity, so results must be bitwise those
+    of the handle without it.  Child process: RCCL state stays out of the test session (tests/rccl_single_rank.py)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "rccl_single_rank.py")], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "rccl single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_torch_nccl_allreduce_inside_the_sweep_with_one_rank():
+    """The production multi-GPU path with the one rank a one-GPU box offers: torch.distributed backend "nccl" (RCCL),
+    the all-reduce issued from the library's hook inside sgp_sweep, on the sweep's stream (tests/nccl_single_rank.py)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(os.path.dirname(__file__), "nccl_single_rank.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0 and "nccl single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
