@@ -105,6 +105,7 @@ struct sgp_handle {
     long long* dJoin = nullptr;    // device-side join word of the two streams (see UvArgs::join)
     long long join_epoch = 0;
     bool join_by_flag = false;     // this sweep's F2 waits on dJoin inside k_gemm32 instead of on evSide
+    bool gate_side = false;        // the K_uu chain waits for the SYRK's resident round (dJoin[2]); the SYRK grid then uses all CUs
     long long done_epoch = 0;      // dJoin[1]: the last value a sweep's final kernel was told to write (see k_scalars)
     const Params* params_src = nullptr;   // what k_prep_xu mirrors: hParams, or dTrainParams while a device-paced run is open
     // device-paced training (sgp_train_*): the resident training set, the optimiser state and the parameter source
@@ -195,11 +196,11 @@ static int quiesce(sgp_handle* h) {
 #ifndef SYRK_RESERVED_CUS
 #define SYRK_RESERVED_CUS 8
 #endif
-static void syrk_chunking(int ntiles, int num_cus, int* want, int* align) {
+static void syrk_chunking(int ntiles, int num_cus, int* want, int* align, int reserved = SYRK_RESERVED_CUS) {
     int a = 8;
     for (int g = 2; g <= 8; g *= 2)
         if (ntiles % g == 0) a = 8 / g;                  // smallest a with (ntiles * a) % 8 == 0
-    int w = std::max(1, SYRK_BLOCKS_PER_CU * std::max(8, num_cus - SYRK_RESERVED_CUS) / ntiles);
+    int w = std::max(1, SYRK_BLOCKS_PER_CU * std::max(8, num_cus - reserved) / ntiles);
     if (w > a) w = w / a * a;
     *want = w;
     *align = a;
@@ -363,7 +364,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dBpart, nblk_max * h->dout * Mp);
     ALLOC(h->dSlabs, h->slab_capacity);
     ALLOC(h->dStatsOwn, (size_t)h->stats_count);
-    ALLOC(h->dJoin, 2);
+    ALLOC(h->dJoin, 4);
     ALLOC(h->dDataScal, SGP_S_COUNT + (size_t)h->dout * h->dout);
     ALLOC(h->dKuu, Mp * Mp);
     ALLOC(h->dWk, Mp * Mp);
@@ -459,7 +460,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         return SGP_ERR_HIP;
     }
     hipMemset(h->dInfo, 0, 4 * sizeof(int));
-    hipMemset(h->dJoin, 0, 2 * sizeof(long long));
+    hipMemset(h->dJoin, 0, 4 * sizeof(long long));
     hipMemset(h->dOut, 0, SGP_R_COUNT * sizeof(double));
     hipMemset(h->dStamps, 0, STAMP_STRIDE * SGP_T_COUNT * sizeof(int64_t));
     hipMemset(h->dStampTotals, 0, (SGP_T_COUNT + 1 + 2 * SGP_T_COUNT) * sizeof(int64_t));
@@ -520,7 +521,13 @@ static int set_point_count(sgp_handle* h, int64_t n) {
     h->nblk = (int)((n + TB - 1) / TB);
     // split the point axis into one resident round of workgroups (see syrk_chunking), chunk a multiple of the stage size
     int want = 1, align = 1;
-    syrk_chunking(h->ntiles, h->num_cus, &want, &align);
+    // Eager launches with a SYRK big enough to fill the chip: the K_uu chain is held back until this launch is resident
+    // (enqueue_kuu), so nothing is reserved for it and the grid is sized for all CUs (T: 25 -> 28 chunks, 62.7 -> 57.4 us; the
+    // chain then runs after the SYRK and still ends ~9 us before its join).  Small problems keep the early chain: there the
+    // two chains are the sweep, and a late K_uu chain is waited for (C1: -15 %, C5: -2 % with the gate).
+    h->gate_side = n * (int64_t)h->ntiles >= 200000 && h->dJoin && !(h->cfg.flags & SGP_FLAG_GRAPH) && !h->use_chain &&
+                   !getenv("SGP_NO_GATE");
+    syrk_chunking(h->ntiles, h->num_cus, &want, &align, h->gate_side ? 0 : SYRK_RESERVED_CUS);
     int64_t per = (n + want - 1) / want;
     per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);
     h->chunk = (int)per;
@@ -762,7 +769,9 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     const bool words = !(h->cfg.flags & SGP_FLAG_GRAPH) && s == h->side;
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->params_src,
                        h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0,
-                       words ? (const long long*)(h->dJoin + 1) : (const long long*)nullptr, h->done_epoch);
+                       words ? (const long long*)(h->dJoin + 1) : (const long long*)nullptr, h->done_epoch,
+                       (words && h->gate_side && h->pipe_ranges == 1) ? (const long long*)(h->dJoin + 2) : (const long long*)nullptr,
+                       h->gate_epoch);
     if (h->use_chain) {
         if (h->gate_kuu)
             hipLaunchKernelGGL(k_chain_gate, dim3(1), dim3(64), 0, s, (const long long*)(h->dChainFlags[0] + CH_F_GATE), h->gate_epoch);
@@ -786,7 +795,7 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     if (prep) {
         hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->params_src,
                            h->dParams, (int*)nullptr, M, Mp, D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP,
-                           (const long long*)nullptr, 0LL);
+                           (const long long*)nullptr, 0LL, (const long long*)nullptr, 0LL);
         h->main_prep_gen = h->params_gen;
     }
     int asm_chunks = h->n > 0 ? h->nchunks : 0;
@@ -827,8 +836,8 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
                                h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, h->dStamps);
         hipLaunchKernelGGL(k_syrk_stream<false>, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                            h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, h->ntiles, h->nchunks,
-                           h->dStamps + STAMP_STRIDE * SGP_T_SYRK, h->use_chain ? h->dChainFlags[0] + CH_F_GATE : nullptr,
-                           h->gate_epoch);
+                           h->dStamps + STAMP_STRIDE * SGP_T_SYRK,
+                           h->use_chain ? h->dChainFlags[0] + CH_F_GATE : (h->gate_side ? h->dJoin + 2 : nullptr), h->gate_epoch);
     }
     hipLaunchKernelGGL(k_assemble, dim3(T, T, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
                        h->ntiles, asm_chunks, h->n > 0 ? h->nblk : 0, h->dout,
@@ -1371,7 +1380,8 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
     // sgp_theta_objective at unchanged theta still read (a predict between set_noise and theta_objective scaled
     // the gradient by w_new / w_old twice).
     hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, (const Params*)h->hParams,
-                       h->dParamsK, (int*)nullptr, h->M, h->Mp, h->D, (int64_t*)nullptr, 0, 0, (const long long*)nullptr, 0LL);
+                       h->dParamsK, (int*)nullptr, h->M, h->Mp, h->D, (int64_t*)nullptr, 0, 0, (const long long*)nullptr, 0LL,
+                       (const long long*)nullptr, 0LL);
     switch (h->D) {
         case 1: launch_predict<1>(h, dXs, dMu, dMean, ns, s); break;
         case 2: launch_predict<2>(h, dXs, dMu, dMean, ns, s); break;

@@ -139,7 +139,19 @@ __device__ __forceinline__ void stamp_accumulate(int64_t* stamps, int64_t* total
 // Also resets the Cholesky status word of the sequence (`info_reset`) and, on the main stream, the phase stamps.
 __global__ void k_prep_xu(const double* __restrict__ Xu, double* __restrict__ Xus, const Params* __restrict__ hP,
                           Params* __restrict__ dP, int* __restrict__ info_reset, int M, int Mp, int D, int64_t* stamps,
-                          int nslots, int sweep_slot, const long long* wait_word, long long wait_need) {
+                          int nslots, int sweep_slot, const long long* wait_word, long long wait_need,
+                          const long long* gate_word, long long gate_need) {
+    if (gate_word) {
+        // ... and the chain's workgroups (each takes a whole CU's LDS) stay off the CUs until the sweep's streaming SYRK has
+        // its single resident round on them (its last workgroup sets the gate when it starts): that grid is sized for ALL CUs
+        if (threadIdx.x == 0) {
+            int it = 0;
+            while (__hip_atomic_load((const __attribute__((address_space(1))) long long*)gate_word, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) < gate_need && ++it < (1 << 21))
+                __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+    }
     if (wait_word) {
         // first kernel of the K_uu chain: the previous sweep's last kernel on the other stream still reads what this chain
         // overwrites (see k_scalars).  Bounded; the buffers it protects are rewritten either way.
