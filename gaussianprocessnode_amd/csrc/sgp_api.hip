@@ -48,8 +48,6 @@ struct Graph {
 
 }  // namespace
 
-constexpr int PIPE_MAX = 32;
-constexpr int64_t PIPE_MIN_POINTS = 1 << 18;     // below this the single Gram + SYRK pair is used (T: 10 000 points)
 struct sgp_handle {
     sgp_config cfg{};
     int M = 0, Mp = 0, D = 0, dout = 1, Q = 0, Qp = 0, T = 0, TQ = 0;
@@ -96,12 +94,6 @@ struct sgp_handle {
     uint64_t main_prep_gen = 0;    // the generation k_prep_xu last mirrored onto the main stream's copies (dXus, dParams)
     Params* dParams = nullptr;
     Params* dParamsK = nullptr;    // the K_uu chain's own copy (it runs on the side stream)
-    // large-N pipeline of the data-sized kernels (see enqueue_local): K_uf of point range c + 1 is assembled on `pipe` while
-    // the SYRK of range c runs on the sweep's stream
-    hipStream_t pipe = nullptr;
-    hipEvent_t evPipe0 = nullptr, evPipe[PIPE_MAX] = {nullptr};
-    int pipe_ranges = 1, pipe_chunk = 0, pipe_nchunks = 0;
-    int64_t pipe_points = 0;       // points per range (a multiple of the tile size)
     long long* dJoin = nullptr;    // device-side join word of the two streams (see UvArgs::join)
     long long join_epoch = 0;
     bool join_by_flag = false;     // this sweep's F2 waits on dJoin inside k_gemm32 instead of on evSide
@@ -339,7 +331,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
                          ? prop.multiProcessorCount : 256;
     }
     int want_chunks = 1, align_chunks = 1;
-    syrk_chunking(h->ntiles, h->num_cus, &want_chunks, &align_chunks);
+    syrk_chunking(h->ntiles, h->num_cus, &want_chunks, &align_chunks, 0);      // (the larger of the two geometries, see set_point_count)
     int max_chunks = want_chunks + align_chunks;
     h->slab_capacity = (size_t)max_chunks * h->ntiles * TB * TB;
     const size_t nblk_max = (nmax + TB - 1) / TB;
@@ -492,9 +484,6 @@ extern "C" int sgp_destroy(sgp_handle* h) {
                     h->dTrainX, h->dTrainY, h->dTrain, h->dTrainParams, h->dJoin};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->hParams) hipHostFree(h->hParams);
-    if (h->pipe) hipStreamDestroy(h->pipe);
-    if (h->evPipe0) hipEventDestroy(h->evPipe0);
-    for (hipEvent_t e : h->evPipe) if (e) hipEventDestroy(e);
     if (h->evSide) hipEventDestroy(h->evSide);
     if (h->evDone) hipEventDestroy(h->evDone);
     if (h->own) hipStreamDestroy(h->own);
@@ -535,35 +524,6 @@ static int set_point_count(sgp_handle* h, int64_t n) {
     if (h->nchunks > align) h->nchunks = (h->nchunks + align - 1) / align * align;   // trailing chunks may be empty (zero slabs)
     if ((size_t)h->nchunks * h->ntiles * TB * TB > h->slab_capacity)
         return fail(h, SGP_ERR_ARG, "sgp_set_data: internal slab capacity exceeded");
-    // Large N: the point axis is cut into ranges of ~170 000 points; the Gram kernel of range c + 1 (HBM-write bound) runs on
-    // a stream of its own and fills the CUs that the SYRK of range c (MFMA bound) leaves idle towards the end of its single
-    // resident round.  The SYRK launches accumulate into the same slabs in range order (fixed summation order).  Measured at
-    // N = 10^6, M = 512 on one box (sweeps/s): one Gram + one SYRK 114.2; 4 / 5 / 6 / 8 / 10 / 12 ranges 116.8 / 120.4 /
-    // 122.5 / 117.6 / 121.0 / 120.6; a SYRK grid of three workgroups per CU (room for the Gram kernel's workgroups beside
-    // them) was worse: 118.4 at 6 ranges, 118.9 at 15.
-    h->pipe_ranges = 1;
-    if (n >= PIPE_MIN_POINTS && h->dout == 1 && !(h->cfg.flags & SGP_FLAG_GRAPH) && !h->use_chain && !getenv("SGP_NO_PIPELINE")) {
-        int ranges = (int)std::max<int64_t>(2, std::min<int64_t>(PIPE_MAX, (n + 85000) / 170000));
-        if (const char* e = getenv("SGP_PIPE_RANGES")) ranges = std::max(2, std::min(PIPE_MAX, atoi(e)));
-        const int per_cu = getenv("SGP_PIPE_WG") ? atoi(getenv("SGP_PIPE_WG")) : SYRK_BLOCKS_PER_CU;
-        int64_t pts = (n + ranges - 1) / ranges;
-        pts = (pts + TB - 1) / TB * TB;
-        ranges = (int)((n + pts - 1) / pts);
-        int w3 = std::max(1, per_cu * std::max(8, h->num_cus - SYRK_RESERVED_CUS) / h->ntiles);
-        if (w3 > align) w3 = w3 / align * align;
-        int64_t per3 = (pts + w3 - 1) / w3;
-        per3 = std::max<int64_t>(KB, (per3 + KB - 1) / KB * KB);
-        int nch = (int)std::max<int64_t>(1, (pts + per3 - 1) / per3);
-        if (nch > align) nch = (nch + align - 1) / align * align;
-        if ((size_t)nch * h->ntiles * TB * TB <= h->slab_capacity) {
-            if (!h->pipe) {
-                HIPCHK(h, hipStreamCreateWithFlags(&h->pipe, hipStreamNonBlocking));
-                HIPCHK(h, hipEventCreateWithFlags(&h->evPipe0, hipEventDisableTiming));
-                for (int i = 0; i < PIPE_MAX; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->evPipe[i], hipEventDisableTiming));
-            }
-            h->pipe_ranges = ranges; h->pipe_points = pts; h->pipe_chunk = (int)per3; h->pipe_nchunks = nch;
-        }
-    }
     return 0;
 }
 
@@ -770,7 +730,7 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->params_src,
                        h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0,
                        words ? (const long long*)(h->dJoin + 1) : (const long long*)nullptr, h->done_epoch,
-                       (words && h->gate_side && h->pipe_ranges == 1) ? (const long long*)(h->dJoin + 2) : (const long long*)nullptr,
+                       (words && h->gate_side) ? (const long long*)(h->dJoin + 2) : (const long long*)nullptr,
                        h->gate_epoch);
     if (h->use_chain) {
         if (h->gate_kuu)
@@ -798,49 +758,20 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
                            (const long long*)nullptr, 0LL, (const long long*)nullptr, 0LL);
         h->main_prep_gen = h->params_gen;
     }
-    int asm_chunks = h->n > 0 ? h->nchunks : 0;
-    if (h->n > 0 && h->pipe_ranges > 1) {
-        // (K_uf, X, y are indexed by point: a range is a pointer offset; the B partials are indexed by point block)
-        hipEventRecord(h->evPipe0, s);                       // the Gram stream starts where this stream is: parameters
-        hipStreamWaitEvent(h->pipe, h->evPipe0, 0);          // mirrored, the previous sweep's SYRK done with K_uf
-        for (int c = 0; c < h->pipe_ranges; ++c) {
-            const int64_t off = (int64_t)c * h->pipe_points, cnt = std::min<int64_t>(h->pipe_points, h->n - off);
-            const int blks = (int)((cnt + TB - 1) / TB);
-            double* kuf = h->dKuf + (size_t)off * Mp;
-            double* bp = h->dBpart + (size_t)(off / TB) * h->dout * Mp;
-            int64_t* sweep_begin = (c == 0) ? h->dStamps : nullptr;
-            if (D <= 8)
-                hipLaunchKernelGGL(k_gram_uf<8>, dim3(blks, T), dim3(256), 0, h->pipe, h->dXus, h->dX + (size_t)off * D, h->dYw + off,
-                                   kuf, bp, h->dParams, M, Mp, D, cnt, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, sweep_begin);
-            else
-                hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(blks, T), dim3(256), 0, h->pipe, h->dXus, h->dX + (size_t)off * D, h->dYw + off,
-                                   kuf, bp, h->dParams, M, Mp, D, cnt, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, sweep_begin);
-            hipEventRecord(h->evPipe[c], h->pipe);
-            hipStreamWaitEvent(s, h->evPipe[c], 0);
-            if (c == 0)
-                hipLaunchKernelGGL(k_syrk_stream<false>, dim3(h->ntiles * h->pipe_nchunks), dim3(256), 0, s, kuf,
-                                   h->has_omega ? h->dOmega + off : nullptr, h->dSlabs, Mp, cnt, h->pipe_chunk, h->ntiles,
-                                   h->pipe_nchunks, h->dStamps + STAMP_STRIDE * SGP_T_SYRK, (long long*)nullptr, 0LL);
-            else
-                hipLaunchKernelGGL(k_syrk_stream<true>, dim3(h->ntiles * h->pipe_nchunks), dim3(256), 0, s, kuf,
-                                   h->has_omega ? h->dOmega + off : nullptr, h->dSlabs, Mp, cnt, h->pipe_chunk, h->ntiles,
-                                   h->pipe_nchunks, h->dStamps + STAMP_STRIDE * SGP_T_SYRK, (long long*)nullptr, 0LL);
-        }
-        asm_chunks = h->pipe_nchunks;
-    } else if (h->n > 0) {
+    if (h->n > 0) {
         if (D <= 8)
             hipLaunchKernelGGL(k_gram_uf<8>, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, h->dStamps);
         else
             hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, h->dStamps);
-        hipLaunchKernelGGL(k_syrk_stream<false>, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
+        hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                            h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, h->ntiles, h->nchunks,
                            h->dStamps + STAMP_STRIDE * SGP_T_SYRK,
                            h->use_chain ? h->dChainFlags[0] + CH_F_GATE : (h->gate_side ? h->dJoin + 2 : nullptr), h->gate_epoch);
     }
     hipLaunchKernelGGL(k_assemble, dim3(T, T, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
-                       h->ntiles, asm_chunks, h->n > 0 ? h->nblk : 0, h->dout,
+                       h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
                        SGP_S_COUNT + h->dout * h->dout, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL, h->dInfo + 1);
 }
 
@@ -1300,7 +1231,7 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
             hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr, (int64_t*)nullptr);
         else
-            hipLaunchKernelGGL(k_syrk_stream<false>, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
+            hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
                                h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->chunk, h->ntiles, h->nchunks,
                                (int64_t*)nullptr, (long long*)nullptr, 0LL);
     };

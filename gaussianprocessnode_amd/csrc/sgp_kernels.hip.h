@@ -396,10 +396,6 @@ __device__ __forceinline__ void tile_from_index(int t, int& I, int& J) {
     J = t - i * (i + 1) / 2;
 }
 
-// ACCUMULATE: the slabs already hold the sums over the earlier point ranges of this sweep (large-N pipeline: consecutive
-// launches over consecutive ranges, so the summation order stays fixed).  A template parameter, not an argument: as a
-// run-time flag in the epilogue it cost the plain kernel 6 us of its 63 (T, same-box A/B).
-template <bool ACCUMULATE>
 __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
                                                      double* __restrict__ slabs, int Mp, int64_t N, int chunk,
                                                      int ntiles, int nchunks, int64_t* stamps, long long* gate,
@@ -483,10 +479,8 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr (ACCUMULATE) out[acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj)] += acc.t[ti][tj][r];
-                else out[acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj)] = acc.t[ti][tj][r];
-            }
+            for (int r = 0; r < 4; ++r)
+                out[acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj)] = acc.t[ti][tj][r];
     stamp_exit(stamps);
 }
 

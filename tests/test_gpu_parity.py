@@ -866,40 +866,6 @@ def test_shader_clock_probe(G):
     assert 500.0 < v.value < 3000.0
 
 
-def test_large_n_pipeline_matches_the_single_launch_and_the_oracle(G, monkeypatch):
-    """From 2^18 points on the data-sized kernels run as a pipeline over point ranges (Gram of range c + 1 on a stream of its
-    own beside the SYRK of range c, the SYRK launches accumulating into the same slabs; csrc/sgp_api.hip, set_point_count).
-    Same statistics as the single Gram + SYRK pair (up to the summation partition), same posterior, bitwise repeatable,
-    and Psi2 / B against the oracle."""
-    N, M, D = 300_000, 96, 5                                 # two ranges, ragged last range (300 000 is no multiple of 64)
-    X, Xu, y, _ = synth(N, M, D, seed=77)
-    wts = np.random.default_rng(5).uniform(0.5, 1.5, N)
-    s2, ell, w = 0.9, np.linspace(1.5, 3.0, D), 30.0
-    res = {}
-    for mode in ("pipeline", "pipeline-again", "single"):
-        if mode == "single":
-            monkeypatch.setenv("SGP_NO_PIPELINE", "1")
-        with G.SGPDevice(N, M, D) as dev:
-            dev.set_inducing(Xu)
-            dev.set_data(X, y, None, wts)
-            dev.set_kernel(s2, ell, 1e-8)
-            dev.set_prior_isotropic(50.0)
-            dev.set_noise([[w]])
-            dev.sweep()
-            res[mode] = (dev.stats(), dev.posterior(), dev.scalars())
-    (P2, B, sc), (mu, Sig, Uv), scal = res["pipeline"]
-    (P2b, Bb, _), (mub, Sigb, _), scalb = res["pipeline-again"]
-    assert np.array_equal(P2, P2b) and np.array_equal(B, Bb) and np.array_equal(mu, mub) and np.array_equal(Sig, Sigb)
-    (P2s, Bs, scs), (mus, Sigs, Uvs), scals = res["single"]
-    assert relF(P2, P2s) < 1e-14 and relF(B, Bs) < 1e-14 and np.array_equal(sc, scs)
-    tol = post_tol(np.linalg.cond(np.eye(M) / 50.0 + w * P2))       # statistics that differ in the last bits, amplified by cond(Lambda)
-    assert relF(mu, mus) < tol and relF(Sig, Sigs) < tol and relF(Uv, Uvs) < tol, (relF(mu, mus), tol)
-    assert math.isclose(scal.energy, scals.energy, rel_tol=max(1e-9, tol))
-    K = O.kernelmatrix(s2, ell, Xu, X)
-    assert relF(P2, (K * wts) @ K.T) < 1e-13
-    assert relF(B.ravel(), K @ (wts * y)) < 1e-13
-
-
 def test_rccl_adapter_with_a_single_rank_communicator():
     """sgp_use_rccl (include/sgp_hip.h): the library calls ncclAllReduce itself, inside sgp_sweep, on the sweep's stream.
     A one-rank communicator is what a one-GPU box can offer: the reduce is the identity, so results must be bitwise those
