@@ -864,6 +864,17 @@ def test_shader_clock_probe(G):
     v = C.c_double()
     _lib.check(_lib.load().sgp_measure_sclk_mhz(0, C.byref(v)), None, "sgp_measure_sclk_mhz")
     assert 500.0 < v.value < 3000.0
+    # the same under FP64 matrix load, with the rate that back-to-back v_mfma_f64_16x16x4_f64 attain: what bench.py prices the
+    # SYRK against next to the spec peak.  The loop cannot beat the arithmetic of its own clock (4 SIMDs x 32 flop/cycle per CU).
+    out = (C.c_double * 4)()
+    _lib.check(_lib.load().sgp_measure_clocks(0, out), None, "sgp_measure_clocks")
+    sclk_mfma, tflops, sclk_fma, cus = out[0], out[1], out[2], out[3]
+    assert 500.0 < sclk_mfma < 3000.0 and 500.0 < sclk_fma < 3000.0 and cus >= 64
+    assert 10.0 < tflops <= cus * 4 * 32.0 * sclk_mfma * 1e6 / 1e12 * 1.02
+    # the step kernel's diagnostics are compiled out of the product build
+    tr = (C.c_int64 * 512)()
+    _lib.check(_lib.load().sgp_get_step_trace(tr), None, "sgp_get_step_trace")
+    assert not any(tr)
 
 
 def test_rccl_adapter_with_a_single_rank_communicator():
