@@ -4,11 +4,13 @@ and of the posterior, in units of cond * eps, and the number of draws that would
 Usage: accuracy_sweep.py <seeds> [toy]   (run it after any change to the factorisation kernels; a variant of the pivot loop
 that let the two triangles of the diagonal block drift apart passed the fixed-seed tests and failed 8 of 120 draws here)"""
 import sys, math, zlib
-sys.path.insert(0, __file__.rsplit('/', 2)[0])
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import numpy as np
 import gaussianprocessnode_amd as G
 from oracle import sgp_oracle as O
-sys.path.insert(0, __file__.rsplit('/', 2)[0] + '/tests')
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from test_gpu_parity import synth, relF
 shapes_all = [("toy", 50, 20, 1, 100.0, 1e-8, False), ("ragged", 333, 37, 3, 10.0, 1e-8, False), ("mid", 700, 130, 2, 30.0, 1e-8, False)]
 shapes = shapes_all[:1] if len(sys.argv) > 2 else shapes_all

@@ -3,7 +3,7 @@
 against NumPy, for every tile count it supports, then one sweep against the oracle."""
 import os, sys
 os.environ.setdefault("SGP_CHAIN", "persistent"), time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import gaussianprocessnode_amd as G

@@ -2,7 +2,9 @@
 """Random-shape parity fuzz: device sweep vs oracle over ragged sizes, weights, uncertain outputs and prior forms."""
 import math, sys
 import numpy as np
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import gaussianprocessnode_amd as G
 from oracle import sgp_oracle as O
 

@@ -181,7 +181,7 @@ SWEEP_SHAPES = [("toy", 50, 20, 1, 100.0, 1e-8), ("ragged", 333, 37, 3, 10.0, 1e
 
 @pytest.mark.parametrize("name,N,M,D,w,jit", SWEEP_SHAPES, ids=[c[0] for c in SWEEP_SHAPES])
 def test_accuracy_over_random_draws(G, name, N, M, D, w, jit):
-    """tools/accuracy_sweep.py as a test: 24 random draws per shape (the toy shape has cond(K_uu) ~ 1e9-1e10), K_uu factor
+    """tests/scripts/accuracy_sweep.py as a test: 24 random draws per shape (the toy shape has cond(K_uu) ~ 1e9-1e10), K_uu factor
     and posterior against the oracle at the conditioning-aware bounds of test_sweep_matches_oracle.  A variant of the pivot
     loop that let the two triangles of the diagonal block drift apart passed the fixed-seed cases and failed 8 of 120 draws
     of this kind; the fixed-seed cases alone do not guard the factorisation kernels."""

@@ -24,7 +24,7 @@ cd $R
 timeout -k 10 300 python bench.py > $O/bench_T.json 2> $O/bench_T.err; tail -c 400 $O/bench_T.json; echo
 timeout -k 10 300 python bench.py --workload N1M --no-cpu-baseline > $O/bench_N1M.json 2> $O/bench_N1M.err; tail -c 300 $O/bench_N1M.json; echo
 timeout -k 10 200 python tools/config_rates.py > $O/config_rates.txt 2>&1; tail -8 $O/config_rates.txt
-timeout -k 10 300 python tools/accuracy_sweep.py 100 > $O/accuracy_sweep.txt 2>&1; grep "worst" $O/accuracy_sweep.txt
+timeout -k 10 300 python tests/scripts/accuracy_sweep.py 100 > $O/accuracy_sweep.txt 2>&1; grep "worst" $O/accuracy_sweep.txt
 timeout -k 10 120 python examples/train_kin40k.py > $O/train_kin40k.txt 2>&1; tail -2 $O/train_kin40k.txt
 timeout -k 10 120 python examples/train_banana.py > $O/train_banana.txt 2>&1; tail -2 $O/train_banana.txt
 L=gaussianprocessnode_amd/csrc/libsgp_hip.so
