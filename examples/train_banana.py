@@ -6,7 +6,7 @@ every minibatch without reset), then the 1300-point test prediction.
 The reference reports 125 errors (rate 0.0961538) after 2965.757395 s.  Data and inducing inputs are the committed
 golden fixtures (tests/golden/banana_fixture.npz).  The final theta and q(w) rate differ from the reference's saved ones
 (softplus(theta) = [0.986, 1.028, 1.022], rate 1.72e6): the q(w) / theta dynamics of this model are neutrally stable and
-end where the message schedule puts them (--w-schedule shows three).  Prints one JSON line.
+end where the message schedule puts them (--w-schedule shows five).  Prints one JSON line.
 """
 import argparse
 import json
@@ -56,7 +56,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=500)
     ap.add_argument("--batch", type=int, default=200)
-    ap.add_argument("--w-schedule", choices=["after_v", "before_v", "w_then_v"], default="after_v",
+    ap.add_argument("--w-schedule", choices=["after_v", "before_v", "w_then_v", "f_again", "f_again_w"], default="after_v",
                     help="q(w) from the minibatch's new q(v) (after_v) or from the q(v) the iteration started with (before_v)")
     args = ap.parse_args()
     print(json.dumps(run(args.epochs, args.batch, args.w_schedule)))

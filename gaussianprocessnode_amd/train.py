@@ -178,16 +178,16 @@ def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch
       theta   one optimiser step on neg_log_backwardmess_fast with y_data = mean(q_f), w = mean(new q_w).
     Returns (q_v, (shape, rate), theta).
 
-    w_schedule: which q(v) the q(w) update sees within the single VMP iteration -- "after_v" (default: the minibatch's new
-    q(v) and the `meta.Uv` its product hook just stored), "before_v" (the q(v) the iteration started with) or "w_then_v"
-    (as before_v, and the sweep already uses the new mean(q_w)).  The reference's end point (softplus(theta) = [0.986,
-    1.028, 1.022], q(w) rate 1.72e6) is NOT reproduced by any of them (rates 5.9e5 / 3.6e9 / 2.5e9,
-    profiles/r02_train_banana_schedules.jsonl): mean(q_w) obeys b/a = mean(I1 + I2) ~ 1/mean(q_w) for ANY value, i.e. its
-    dynamics are neutrally stable and the end point is set by update-order details of RxInfer's reactive schedule (no
-    Manifest.toml pins its version), not by the node's arithmetic.  The un-jittered K_uu of the reference's gradient
-    (derivative_helper.jl:24-25; numerically indefinite for the banana inducing inputs) is NOT the cause: three readings of
-    its non-failing Cholesky move the first gradient by 7e-5 .. 6e-3 (tools/banana_gradient_probe.py).  Here the gradient
-    uses the same jittered K_uu as the sweep.  See DESIGN.md section 2."""
+    w_schedule: the order of the updates inside the single VMP iteration -- "after_v" (default: q(w) from the minibatch's
+    new q(v) and the `meta.Uv` its product hook just stored), "before_v" (from the q(v) the iteration started with),
+    "w_then_v" (as before_v, and the sweep already uses the new mean(q_w)), "f_again_w" (q(f) recomputed from the new q(v)
+    before q(w)), "f_again" (only the gradient sees the recomputed q(f)).  None reproduces the reference's end point
+    (softplus(theta) = [0.986, 1.028, 1.022], q(w) rate 1.72e6): rates 5.9e5 / 3.6e9 / 2.5e9 / 7.2e5 / 5.9e5
+    (profiles/r02_train_banana_schedules.jsonl).  mean(q_w) is neutrally stable (b/a = mean(I1 + I2) ~ 1/mean(q_w) holds
+    for any value) and sigma2 is nearly degenerate with the scale of v, so the end point follows update-order details of
+    RxInfer's scheduler and the jitter / fallback treatment of K_uu in the reference's gradient
+    (derivative_helper.jl:24-25; tools/banana_gradient_probe.py bounds its effect on the first gradient at 7e-5 .. 6e-3),
+    both unpinned (no Manifest.toml).  Here the gradient uses the same jittered K_uu as the sweep.  DESIGN.md section 2."""
     theta = np.array(theta, dtype=np.float64)
     xtrain = np.asarray(xtrain, dtype=np.float64).reshape(len(ytrain), -1)
     ytrain = np.asarray(ytrain, dtype=np.float64)
@@ -220,13 +220,33 @@ def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch
                 if w_schedule == "w_then_v":
                     engine.set_noise([[(a + 0.5 * len(yi)) / (b + 0.5 * s_I)]])
             engine.sweep()
-            if w_schedule == "after_v":
+            if w_schedule in ("after_v", "f_again", "f_again_w"):
                 sc = engine.scalars()
                 s_I = sc.sum_I1 + sc.sum_I2
             else:
                 mu, _, Uv_old = engine.posterior(want_cov=False)
-            a, b = a + 0.5 * len(yi), b + 0.5 * s_I
-            engine.carry_posterior()
+            if w_schedule == "f_again_w":
+                # q(f) once more from the NEW q(v) (still at the old mean(q_w)), and q(w) from that q(f) and the new q(v)
+                mu_n, _, Uv_n = engine.posterior(want_cov=False)
+                mf, vf = probit_marginal(yi, engine.predict(xi, None), 1.0 / w0)
+                engine.carry_posterior()
+                engine.set_data(xi, mf, vf)
+                engine.sweep_local()
+                engine.set_posterior(mu_n, Uv_n)
+                I1, I2 = engine.w_stats()
+                s_I = float(np.sum(I1) + np.sum(I2))
+                a, b = a + 0.5 * len(yi), b + 0.5 * s_I
+            else:
+                a, b = a + 0.5 * len(yi), b + 0.5 * s_I
+                engine.carry_posterior()
+                if w_schedule == "f_again":
+                    # the q(f) the iteration ENDS with: recomputed from the new q(v) and the new mean(q_w); it is what the
+                    # gradient then sees as y_data (the statistics are re-formed with it, q(v) re-installed unchanged)
+                    mu_n, _, Uv_n = engine.posterior(want_cov=False)
+                    mf, vf = probit_marginal(yi, engine.predict(xi, None), b / a)
+                    engine.set_data(xi, mf, vf)
+                    engine.sweep_local()
+                    engine.set_posterior(mu_n, Uv_n)
             engine.set_noise([[a / b]])                                # grad_llh_new!(...; w = mean(qw))
             _, g = engine.theta_objective(want_grad=True, n_ell=len(p) - 1)
             optimizer.update(theta, g * sigmoid(theta))
