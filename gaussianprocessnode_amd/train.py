@@ -167,7 +167,8 @@ def vmp_classification(p, xtrain, ytrain, Xu, engine, *, iterations=30, prior_va
 
 
 def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch_size=200, epochs=1, prior_var=50.0,
-                                     shape=0.01, rate=0.01, jitter=1e-8, optimizer=None, w_schedule="after_v"):
+                                     shape=0.01, rate=0.01, jitter=1e-8, optimizer=None, w_schedule="after_v",
+                                     grad_jitter=None, reset_v_each_epoch=False):
     """`PerformInference` of experiments/classification_banana.ipynb (model `f[i] ~ UniSGP(x[i], v, w, theta);
     y[i] ~ Probit(f[i])`, mean-field q(f) q(v) q(w), one VMP iteration per minibatch, q(v) and q(w) carried over every
     minibatch and never reset).  Per minibatch:
@@ -184,10 +185,10 @@ def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch
     before q(w)), "f_again" (only the gradient sees the recomputed q(f)).  None reproduces the reference's end point
     (softplus(theta) = [0.986, 1.028, 1.022], q(w) rate 1.72e6): rates 5.9e5 / 3.6e9 / 2.5e9 / 7.2e5 / 5.9e5
     (profiles/r02_train_banana_schedules.jsonl).  mean(q_w) is neutrally stable (b/a = mean(I1 + I2) ~ 1/mean(q_w) holds
-    for any value) and sigma2 is nearly degenerate with the scale of v, so the end point follows update-order details of
-    RxInfer's scheduler and the jitter / fallback treatment of K_uu in the reference's gradient
-    (derivative_helper.jl:24-25; tools/banana_gradient_probe.py bounds its effect on the first gradient at 7e-5 .. 6e-3),
-    both unpinned (no Manifest.toml).  Here the gradient uses the same jittered K_uu as the sweep.  DESIGN.md section 2."""
+    for any value), so it follows the update order; the K_uu treatment of the reference's gradient (no jitter,
+    derivative_helper.jl:24-25) is not the lever: tools/banana_gradient_probe.py bounds its effect on the first gradient at
+    7e-5 .. 6e-3, and `grad_jitter` (a different jitter in the gradient only) from 1e-11 to 1e-4 leaves the end point where
+    it is.  `reset_v_each_epoch` (the notebook's commented-out lines) does not reproduce it either.  DESIGN.md section 2."""
     theta = np.array(theta, dtype=np.float64)
     xtrain = np.asarray(xtrain, dtype=np.float64).reshape(len(ytrain), -1)
     ytrain = np.asarray(ytrain, dtype=np.float64)
@@ -202,6 +203,11 @@ def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch
     Uv_old = np.sqrt(prior_var) * np.eye(M)
     first = True
     for _ in range(epochs):
+        if reset_v_each_epoch and not first:                               # (experiment: q(v) back to its prior every epoch, q(w) kept)
+            engine.set_prior_precision(np.zeros(M), np.eye(M) / prior_var)
+            mu = np.zeros(M)
+            Uv_old = np.sqrt(prior_var) * np.eye(M)
+            first = True
         for xi, yi in zip(xb, yb):
             p = softplus(theta)
             w0 = a / b
@@ -248,6 +254,8 @@ def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch
                     engine.sweep_local()
                     engine.set_posterior(mu_n, Uv_n)
             engine.set_noise([[a / b]])                                # grad_llh_new!(...; w = mean(qw))
+            if grad_jitter is not None:                                # (experiment: a different K_uu jitter in the gradient only)
+                engine.set_kernel(float(p[0]), p[1:], grad_jitter)
             _, g = engine.theta_objective(want_grad=True, n_ell=len(p) - 1)
             optimizer.update(theta, g * sigmoid(theta))
             first = False
