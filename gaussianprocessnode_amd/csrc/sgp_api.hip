@@ -98,6 +98,7 @@ struct sgp_handle {
     long long join_epoch = 0;
     bool join_by_flag = false;     // this sweep's F2 waits on dJoin inside k_gemm32 instead of on evSide
     bool gate_side = false;        // the K_uu chain waits for the SYRK's resident round (dJoin[2]); the SYRK grid then uses all CUs
+    long long grad_epoch = 0;      // dJoin[3]: the K_uu half of the theta gradient is complete (enqueue_theta_grad)
     long long done_epoch = 0;      // dJoin[1]: the last value a sweep's final kernel was told to write (see k_scalars)
     const Params* params_src = nullptr;   // what k_prep_xu mirrors: hParams, or dTrainParams while a device-paced run is open
     // device-paced training (sgp_train_*): the resident training set, the optimiser state and the parameter source
@@ -1353,17 +1354,26 @@ static int enqueue_theta_grad(sgp_handle* h, hipStream_t s) {
     // split the K loop of the G K_uf product when there are few point blocks (minibatches), so that the launch fills the chip
     const int KS = h->n > 0 ? std::max(1, std::min(T, 512 / std::max(1, h->nblk * T))) : 1;
     const int n_uf = h->n > 0 ? h->nblk * T * KS : 0;
-    hipLaunchKernelGGL(k_form_G, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->dR, h->dKinv, dG, cnt);
-    hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)h->dKinv, (const double*)h->dStats, dT1,
+    // The gradient has two independent halves: the data half (G = R - K_uu^-1, then G K_uf contracted with the kernel
+    // derivatives) and the K_uu half (H = K_uu^-1 Psi2 K_uu^-1 against dK_uu).  On the library's own streams they run side
+    // by side -- the K_uu half on the side stream, which idles between two sweeps -- and meet in the finishing kernel through
+    // a device word (an event would cost the main stream ~6 us, see sgp_sweep_finish).
+    const bool split = s == h->own && h->dJoin && !(h->cfg.flags & SGP_FLAG_GRAPH) && !getenv("SGP_GRAD_ONE_STREAM");
+    hipStream_t su = split ? h->side : s;
+    if (split) hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, su, (const long long*)(h->dJoin + 1), h->done_epoch);
+    hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, su, (const double*)h->dKinv, (const double*)h->dStats, dT1,
                        Mp, T, 3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{}, (const double*)nullptr);
-    hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, s, (const double*)dT1, (const double*)h->dKinv, dH, Mp, T,
+    hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, su, (const double*)dT1, (const double*)h->dKinv, dH, Mp, T,
                        3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{}, (const double*)nullptr);
+    hipLaunchKernelGGL(k_theta_grad_uu, dim3(T, T), dim3(256), 0, su, dH, h->dXus, h->dParams, part_uu, h->M, Mp, h->D);
+    if (split) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, su, h->dJoin + 3, ++h->grad_epoch);
+    hipLaunchKernelGGL(k_form_G, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->dR, h->dKinv, dG, cnt);
     if (h->n > 0)
         hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T, KS), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
                            h->has_omega ? h->dOmega : nullptr, h->dMu, h->dParams, part_uf, Mp, T, h->D, h->n);
-    hipLaunchKernelGGL(k_theta_grad_uu, dim3(T, T), dim3(256), 0, s, dH, h->dXus, h->dParams, part_uu, h->M, Mp, h->D);
     hipLaunchKernelGGL(k_theta_grad_finish, dim3(1), dim3(256), 0, s, part_uf, n_uf, part_uu, T * T,
-                       h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, h->dParams, h->dGrad, h->D, h->n_ell);
+                       h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, h->dParams, h->dGrad, h->D, h->n_ell,
+                       split ? (const long long*)(h->dJoin + 3) : (const long long*)nullptr, h->grad_epoch);
     return 0;
 }
 

@@ -1559,6 +1559,12 @@ constexpr int JOIN_SPIN_LIMIT = 1 << 21;    // polls of >= ~0.5 us before a wait
 __device__ __forceinline__ bool join_ready(const long long* w, long long need) {
     return __hip_atomic_load((const __attribute__((address_space(1))) long long*)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
 }
+__global__ void k_join_wait(const long long* w, long long need) {           // bounded, like every wait on these words
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int it = 0;
+        while (!join_ready(w, need) && ++it < JOIN_SPIN_LIMIT) __builtin_amdgcn_s_sleep(8);
+    }
+}
 __global__ void k_join_set(long long* w, long long v) {
     if (threadIdx.x == 0 && blockIdx.x == 0)
         __hip_atomic_store((__attribute__((address_space(1))) long long*)w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2395,7 +2401,17 @@ __global__ void __launch_bounds__(256) k_theta_grad_uu(const double* __restrict_
 __global__ void __launch_bounds__(256) k_theta_grad_finish(const double* __restrict__ part_uf, int n_uf,
                                                            const double* __restrict__ part_uu, int n_uu,
                                                            const double* __restrict__ stats_scal, const Params* __restrict__ P,
-                                                           double* __restrict__ grad, int D, int n_ell) {
+                                                           double* __restrict__ grad, int D, int n_ell,
+                                                           const long long* wait_word, long long wait_need) {
+    // wait_word (may be nullptr): the K_uu half of the gradient (part_uu) was formed on the other stream; it is complete when
+    // the word reaches wait_need (bounded wait; the partials are then read past this XCD's L2)
+    if (wait_word) {
+        if (threadIdx.x == 0) {
+            int it = 0;
+            while (!join_ready(wait_word, wait_need) && ++it < JOIN_SPIN_LIMIT) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+    }
     // thread t sums the partial blocks t, t + 256, ... for ALL slots at once (independent loads; a first version walked the
     // blocks slot by slot with one wave: 31 us of load latency), then one workgroup reduction per slot -- fixed order
     __shared__ double red[4];
@@ -2412,7 +2428,10 @@ __global__ void __launch_bounds__(256) k_theta_grad_finish(const double* __restr
     for (int b = tid; b < n_uu; b += 256) {
 #pragma unroll
         for (int sl = 0; sl < GRAD_SLOTS; ++sl)
-            if (sl <= D) acc[sl] += part_uu[(size_t)b * GRAD_SLOTS + sl];
+            if (sl <= D)
+                acc[sl] += wait_word ? __hip_atomic_load((const __attribute__((address_space(1))) double*)(part_uu + (size_t)b * GRAD_SLOTS + sl),
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                     : part_uu[(size_t)b * GRAD_SLOTS + sl];
     }
 #pragma unroll
     for (int sl = 0; sl < GRAD_SLOTS; ++sl) {
