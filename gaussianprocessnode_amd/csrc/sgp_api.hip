@@ -685,11 +685,9 @@ extern "C" int sgp_carry_posterior(sgp_handle* h, void* stream) {
         return fail(h, SGP_ERR_ARG, "sgp_carry_posterior: call it right after a finished sweep (before sgp_theta_objective)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
-    const size_t Qp = h->Qp;
-    hipLaunchKernelGGL(k_form_lambda, dim3(h->TQ, h->TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dTmp, h->dXi,
+    // in place: Lambda0 += W (x) Psi2, xi0 += vec(B W), entry by entry (no scratch, no copies)
+    hipLaunchKernelGGL(k_form_lambda, dim3(h->TQ, h->TQ), dim3(256), 0, s, h->dStats, h->dLambda0, h->dXi0, h->dLambda0, h->dXi0,
                        h->dParams, h->M, h->Mp, h->dout, h->Q, h->Qp, h->prior_form, 0, (int64_t*)nullptr, (int*)nullptr);
-    HIPCHK(h, hipMemcpyAsync(h->dLambda0, h->dTmp, sizeof(double) * Qp * Qp, hipMemcpyDeviceToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->dXi0, h->dXi, sizeof(double) * Qp, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipGetLastError());
     h->prior_form = 1;
     h->in_flight = true;                       // (asynchronous: a following setter must wait for it before it touches the prior)

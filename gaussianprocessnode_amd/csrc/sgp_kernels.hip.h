@@ -568,9 +568,10 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
 // N messages of :144-173; MultiSGP: GPnode/MultiSGPnode.jl:306-307).  Q = d_out * M, padded to Qp with I.
 // prior_form: 1 = dense precision Lambda0 (Qp x Qp) + xi0, 2 = isotropic precision P->prior_iso, xi0 = 0.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_form_lambda(const double* __restrict__ stats, const double* __restrict__ Lambda0,
-                                                     const double* __restrict__ xi0, double* __restrict__ Lam,
-                                                     double* __restrict__ xi, const Params* __restrict__ P,
+// (Lam may be Lambda0 and xi may be xi0 when rev == 0: every entry is read and written by the same thread -- the posterior carry
+// updates the prior in place)
+__global__ void __launch_bounds__(256) k_form_lambda(const double* __restrict__ stats, const double* Lambda0,
+                                                     const double* xi0, double* Lam, double* xi, const Params* __restrict__ P,
                                                      int M, int Mp, int d_out, int Q, int Qp, int prior_form, int rev, int64_t* stamps,
                                                      int* __restrict__ info_reset) {
     stamp_enter(stamps);
