@@ -12,6 +12,11 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsgp_hip.so")
+# variant libraries (same ABI, extra compile-time options): "chain" = with the round-2 persistent factorisation launch
+# (csrc/sgp_chain.hip.h; correct, measured slower, kept out of the default library)
+VARIANTS = {"chain": ("libsgp_hip_chain.so", ["-DSGP_WITH_PERSISTENT_CHAIN"]),
+            # diagnostics: in-kernel begin / end stamps of every kernel of a sweep (tools/sweep_trace.py)
+            "trace": ("libsgp_hip_trace.so", ["-DSGP_SWEEP_TRACE"])}
 SOURCES = [os.path.join(CSRC, "sgp_api.hip")]
 HEADERS = [os.path.join(CSRC, "sgp_kernels.hip.h"), os.path.join(CSRC, "sgp_chain.hip.h"), os.path.join(os.path.dirname(HERE), "include", "sgp_hip.h")]
 
@@ -23,24 +28,33 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the gfx950 library cannot be built (no CPU fallback exists)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def lib_path(variant: str | None = None) -> str:
+    return LIB if not variant else os.path.join(CSRC, VARIANTS[variant][0])
+
+
+def needs_build(variant: str | None = None) -> bool:
+    lib = lib_path(variant)
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip for gfx950 into csrc/libsgp_hip.so; returns the library path."""
-    if not force and not needs_build():
-        return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB] + SOURCES
+def build(force: bool = False, verbose: bool = False, variant: str | None = None) -> str:
+    """Compile csrc/*.hip for gfx950 into csrc/libsgp_hip.so (or a variant library); returns the library path."""
+    lib = lib_path(variant)
+    if not force and not needs_build(variant):
+        return lib
+    extra = VARIANTS[variant][1] if variant else []
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"] + extra + [
+           "-o", lib] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    for v in VARIANTS:
+        print(build(force=True, verbose=True, variant=v))

@@ -28,8 +28,10 @@ EXPORTS = [
     "sgp_stats_layout", "sgp_bind_stats", "sgp_get_posterior", "sgp_get_scalars", "sgp_get_stats",
     "sgp_get_kuu_chol", "sgp_get_wishart_invscale", "sgp_w_stats", "sgp_predict", "sgp_theta_objective", "sgp_carry_posterior", "sgp_set_posterior",
     "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_get_phase_totals", "sgp_time_kernel", "sgp_get_chain_trace", "sgp_set_allreduce", "sgp_use_rccl", "sgp_measure_sclk_mhz",
-    "sgp_train_begin", "sgp_train_step", "sgp_train_end", "sgp_get_step_trace", "sgp_measure_clocks",
+    "sgp_train_begin", "sgp_train_step", "sgp_train_end", "sgp_get_step_trace", "sgp_measure_clocks", "sgp_overlap_plan",
+    "sgp_get_sweep_trace",
 ]
+SGP_TIME_GROUP0 = 100
 
 
 class SGPError(RuntimeError):
@@ -52,18 +54,18 @@ class Config(C.Structure):
 # int hook(void* ctx, void* stats_dev, int64_t count, void* stream): the all-reduce step of sgp_sweep (include/sgp_hip.h)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
-_lib = None
+_libs = {}
 
 
-def library_path() -> str:
-    return _build.LIB
+def library_path(variant=None) -> str:
+    return _build.lib_path(variant)
 
 
-def load(build_if_missing: bool = True):
-    """Load csrc/libsgp_hip.so (building it first if hipcc is available).  Raises if it cannot."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(build_if_missing: bool = True, variant=None):
+    """Load csrc/libsgp_hip.so -- or a variant library of the same ABI, see _build.VARIANTS -- building it first if hipcc is
+    available.  Raises if it cannot."""
+    if variant in _libs:
+        return _libs[variant]
     # PyTorch (used for streams / torch.distributed around this library) bundles its own libamdhip64.so.7.
     # A process must hold ONE HIP runtime: import torch first when it is installed so that this library's
     # DT_NEEDED libamdhip64.so.7 resolves to the copy torch already loaded (loading the system runtime
@@ -72,11 +74,11 @@ def load(build_if_missing: bool = True):
         import torch  # noqa: F401
     except ImportError:
         pass
-    path = _build.LIB
+    path = _build.lib_path(variant)
     if not os.path.exists(path):
         if not build_if_missing:
             raise SGPError(f"{path} is missing: build it with `python -m gaussianprocessnode_amd._build`")
-        _build.build()
+        _build.build(variant=variant)
     lib = C.CDLL(path)
     dp = C.POINTER(C.c_double)
     vp = C.c_void_p
@@ -120,11 +122,13 @@ def load(build_if_missing: bool = True):
     lib.sgp_train_end.argtypes = [vp, dp, C.POINTER(C.c_int64)]
     lib.sgp_get_step_trace.argtypes = [C.POINTER(C.c_int64)]
     lib.sgp_measure_clocks.argtypes = [C.c_int32, dp]
+    lib.sgp_overlap_plan.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.sgp_get_sweep_trace.argtypes = [C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "sgp_last_error":
             fn.restype = C.c_int
-    _lib = lib
+    _libs[variant] = lib
     return lib
 
 
@@ -140,10 +144,10 @@ def ptr(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def check(rc: int, handle=None, what: str = ""):
+def check(rc: int, handle=None, what: str = "", lib=None):
     if rc == 0:
         return
-    lib = load()
+    lib = lib or load()
     msg = lib.sgp_last_error(handle)
     msg = msg.decode() if msg else ""
     if rc > 0:

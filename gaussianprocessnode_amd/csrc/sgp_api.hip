@@ -8,9 +8,12 @@
 // Per-sweep scalars travel through a pinned Params block that each sequence's first kernel mirrors on the device.
 #include "../../include/sgp_hip.h"
 #include "sgp_kernels.hip.h"
-#include "sgp_chain.hip.h"
+#ifdef SGP_WITH_PERSISTENT_CHAIN          // the round-2 experiment (one persistent launch per factorisation): correct, slower,
+#include "sgp_chain.hip.h"                // and therefore only in the variant library (`_build.build(variant="chain")`)
+#endif
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,11 +28,14 @@ using namespace sgp;
 namespace {
 
 thread_local std::string g_create_error;
+std::atomic<int> g_live_handles{0};       // handles alive in this process (two sweeping at once cannot promise each other CUs)
 
+#ifdef SGP_WITH_PERSISTENT_CHAIN
 // The persistent factorisation launches need ALL their workgroups resident at once (they wait for each other).  Two handles
 // sweeping at the same time could each hold part of the chip: a handle that starts a sweep while another one's may still
 // be running waits for the device first.
 sgp_handle* g_chain_owner = nullptr;
+#endif
 
 struct Graph {
     hipGraph_t graph = nullptr;
@@ -47,6 +53,27 @@ struct Graph {
 };
 
 }  // namespace
+
+// words of sgp_handle::dJoin
+enum { WORD_JOIN = 0,      // the K_uu chain of the sweep has finished (k_join_set)          -> Sigma launch (k_gemm32)
+       WORD_DONE = 1,      // the sweep's last reader of the K_uu chain's outputs is through   -> next sweep's first kernels
+       WORD_GATE = 2,      // the streaming SYRK's resident round is on the CUs               -> K_uu chain's first kernel
+       WORD_GRAD = 3,      // the K_uu half of the theta gradient is complete                -> k_theta_grad_finish
+       WORD_ASM0 = 4,      // group 0's assembly of overlapped sweep number (value) has started     -> the masked statistics stream
+       WORD_GROUP0 = 8,    // + g: statistics group g of overlapped sweep number (value) is assembled -> Lambda chain, statM
+       WORD_COUNT = 8 + LAM_MAX_GROUPS };
+constexpr int RESERVED_CUS_PER_SE = 2;      // of 8: the masked statistics stream runs on 6 CUs per shader engine (192 of 256)
+
+// one group of tile rows of Psi2 = tile columns [c0, c1) of P Lambda P: its SYRK launch, slab area and assemble launch
+struct StatGroup {
+    int c0, c1;            // tile columns of P Lambda P (index-reversed), formed by the Lambda chain's step `form_step`
+    int row_lo, nrows;     // the same as tile rows of Psi2: [T - c1, T - c0)
+    int tile0, ntiles;     // their lower tiles in the row-major triangle
+    int nchunks, chunk;    // split of the point axis (one resident round of workgroups on the group's CUs)
+    int form_step;
+    bool masked;           // runs on statM
+    size_t slab_off;       // doubles into dSlabs
+};
 
 struct sgp_handle {
     sgp_config cfg{};
@@ -69,12 +96,13 @@ struct sgp_handle {
     double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr, *dOut2 = nullptr, *dUvWork = nullptr;
     double *dGradM = nullptr, *dGradPart = nullptr, *dGrad = nullptr;   // theta-gradient scratch (allocated on first use)
     double* dSaccK = nullptr;      // K_uu chain: Sigma-style accumulator of K_uu^-1 = W_K^T W_K (see sigma_row_tile)
+    bool use_chain = false;        // (always false without SGP_WITH_PERSISTENT_CHAIN)
+    long long gate_epoch = 0;      // value the sweep's SYRK stores into the gate word
+#ifdef SGP_WITH_PERSISTENT_CHAIN
     // persistent factorisation launch (sgp_chain.hip.h), one set per chain: [0] K_uu, [1] Lambda
-    bool use_chain = false;
     long long* dChainFlags[2] = {nullptr, nullptr};
     long long chain_epoch[2] = {0, 0};
-    long long gate_epoch = 0;      // value the sweep's SYRK stores into the gate word (see k_chain_gate)
-    bool gate_kuu = false;         // the K_uu chain of the sweep being enqueued waits behind the gate
+    bool gate_kuu = false;         // the K_uu chain of the sweep being enqueued waits behind the gate (see k_chain_gate)
     double* dKuuAlt = nullptr;     // the other parity of dKuu / dLam: the launches alternate (see sgp_chain.hip.h, hand-offs)
     double* dLamAlt = nullptr;
     double* dChainFar[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};     // [chain][parity] mailbox matrices
@@ -84,6 +112,10 @@ struct sgp_handle {
     ChainArgs* dChainArgs[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [chain][parity]: the launches' argument structs
     ChainArgs chain_args_shadow[2][2];                // what the device copies hold (rewritten only when something changes)
     bool chain_args_valid[2][2] = {{false, false}, {false, false}};
+#endif
+    // environment switches (diagnostics / A-B), read once in sgp_create
+    bool env_no_gate = false, env_join_event = false, env_grad_one_stream = false;
+    int spin_limit = JOIN_SPIN_LIMIT;   // polls before a bounded device-word wait gives up (SGP_SPIN_LIMIT: tests shorten it)
     double* dCall = nullptr;       // scratch of the per-call outputs (sgp_predict, sgp_w_stats): grows, never shrinks
     size_t call_capacity = 0;
     int* dInfo = nullptr;
@@ -96,6 +128,9 @@ struct sgp_handle {
     Params* dParamsK = nullptr;    // the K_uu chain's own copy (it runs on the side stream)
     long long* dJoin = nullptr;    // device-side join word of the two streams (see UvArgs::join)
     long long join_epoch = 0;
+    bool dev_words = false;        // this sweep's streams meet through device words (eager launches)
+    bool use_events = false;       // ... and (captured graphs, sweeps with an all-reduce hook) through events
+    bool overlap_now = false;      // the sweep being enqueued is an overlapped one (sweep_overlapped)
     bool join_by_flag = false;     // this sweep's F2 waits on dJoin inside k_gemm32 instead of on evSide
     bool gate_side = false;        // the K_uu chain waits for the SYRK's resident round (dJoin[2]); the SYRK grid then uses all CUs
     long long grad_epoch = 0;      // dJoin[3]: the K_uu half of the theta gradient is complete (enqueue_theta_grad)
@@ -110,6 +145,18 @@ struct sgp_handle {
     double* dXusK = nullptr;
     hipStream_t own = nullptr, side = nullptr;
     hipEvent_t evSide = nullptr, evDone = nullptr;
+    // Overlapped sweep (plan_overlap): the statistics are produced in groups of tile rows -- the first on the sweep's own stream,
+    // the others on statM, a CU-masked queue that leaves RESERVED_CUS_PER_SE compute units per shader engine to the two
+    // factorisation chains -- while the Lambda chain already factors the tile columns it has.
+    hipStream_t statM = nullptr;
+    int stat_cus_masked = 0;       // CUs statM may use (0: no masked stream -- the overlapped sweep is off)
+    bool overlap = false;          // the resident data / sizes qualify (set_point_count)
+    int ngroups = 0;
+    StatGroup grp[LAM_MAX_GROUPS];
+    long long stat_epoch = 0;      // number of the last overlapped sweep: what its groups' words dJoin[WORD_GROUP0 + g] receive
+    int env_overlap = -1;          // SGP_OVERLAP: 0 off, 1 on wherever it is possible; default: where the planner's model says it pays
+    int env_g1_mode = 2;           // SGP_G1_AFTER (see enqueue_stats_overlapped)
+    std::vector<int> env_overlap_cols;   // SGP_OVERLAP_COLS: group boundaries (tile columns of P Lambda P), e.g. "3" or "2,4"
     int nchunks = 1, chunk = 0, nblk = 0, ntiles = 0, num_cus = 256;
     int64_t stats_count = 0;
     size_t slab_capacity = 0;
@@ -229,7 +276,7 @@ static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, doub
     for (int j = 0; j < Tn; ++j) {
         const int nt = Tn - j;
         hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + extras(j)), dim3(PSTEP_THREADS), 0, s, A, ld, j, Tn, info, n_valid,
-                           scratch, Winv, Sacc, tv_xi, tv_t, (j == 0 && form) ? *form : none);
+                           scratch, Winv, Sacc, tv_xi, tv_t, form ? *form : none);      // (every step: a tile column may be formed later than step 0)
     }
     if (Winv && extras(Tn) > 0)
         hipLaunchKernelGGL(k_potrf_step, dim3(extras(Tn)), dim3(PSTEP_THREADS), 0, s, A, ld, Tn, Tn, info, n_valid, scratch, Winv, Sacc,
@@ -244,10 +291,11 @@ static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s
                        Kinv, trace_part, uv ? *uv : UvArgs{}, Sacc);
 }
 
+#ifdef SGP_WITH_PERSISTENT_CHAIN
 // The same factorisation (and ride-along roles) as launch_potrf, with the Cholesky itself as ONE persistent launch
 // (sgp_chain.hip.h).  `which`: 0 = K_uu chain (the matrix is evaluated from the scaled inducing inputs), 1 = Lambda chain
 // (evaluated from the statistics through `form`).  A receives L; Winv / Sacc / tv_* as in launch_potrf.
-static void launch_chain(sgp_handle* h, int which, double* A, double* A_next, int ld, int Tn, int* info, int n_valid, hipStream_t s,
+static int launch_chain(sgp_handle* h, int which, double* A, double* A_next, int ld, int Tn, int* info, int n_valid, hipStream_t s,
                          double* Winv, const LamForm* form, double* Sacc, const double* tv_xi, double* tv_t, const double* Xus,
                          const Params* P, int M, int D) {
     ChainArgs g;
@@ -266,14 +314,14 @@ static void launch_chain(sgp_handle* h, int which, double* A, double* A_next, in
     // the device copy of the arguments changes rarely (statistics buffer rebound, prior form): rewritten only then, after
     // waiting for whatever may still be reading it
     if (!h->chain_args_valid[which][par] || memcmp(&g, &h->chain_args_shadow[which][par], sizeof g) != 0) {
-        hipDeviceSynchronize();
-        hipMemcpy(h->dChainArgs[which][par], &g, sizeof g, hipMemcpyHostToDevice);
+        HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, hipMemcpy(h->dChainArgs[which][par], &g, sizeof g, hipMemcpyHostToDevice));
         h->chain_args_shadow[which][par] = g;
         h->chain_args_valid[which][par] = true;
     }
     hipLaunchKernelGGL(k_chol_chain, dim3(chain_blocks(Tn, Winv != nullptr)), dim3(CH_THREADS), 0, s,
                        (const ChainArgs*)h->dChainArgs[which][par]);
-    if (!Winv) return;
+    if (!Winv) return 0;
     for (int j = 1; j <= Tn; ++j) {
         int e = 0;
         if (j >= 2) {
@@ -283,7 +331,9 @@ static void launch_chain(sgp_handle* h, int which, double* A, double* A_next, in
         if (tv_t) e += 1;
         if (e > 0) hipLaunchKernelGGL(k_chain_extras, dim3(e), dim3(256), 0, s, A, ld, j, Tn, Winv, Sacc, tv_xi, tv_t);
     }
+    return 0;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 extern "C" int sgp_abi_version(void) { return SGP_ABI_VERSION; }
@@ -315,6 +365,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         return fail(nullptr, SGP_ERR_NODEVICE, "sgp_create: device is not gfx950 (MI355X); this library is built for gfx950 only");
 
     sgp_handle* h = new sgp_handle();
+    ++g_live_handles;
     h->cfg = *cfg;
     h->M = cfg->m; h->D = cfg->d; h->dout = cfg->d_out; h->n_max = cfg->n_max;
     h->Mp = round_up(h->M, TB);
@@ -357,7 +408,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dBpart, nblk_max * h->dout * Mp);
     ALLOC(h->dSlabs, h->slab_capacity);
     ALLOC(h->dStatsOwn, (size_t)h->stats_count);
-    ALLOC(h->dJoin, 4);
+    ALLOC(h->dJoin, WORD_COUNT);
     ALLOC(h->dDataScal, SGP_S_COUNT + (size_t)h->dout * h->dout);
     ALLOC(h->dKuu, Mp * Mp);
     ALLOC(h->dWk, Mp * Mp);
@@ -386,6 +437,22 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dParams, 1);
     ALLOC(h->dParamsK, 1);
     ALLOC(h->dXusK, Mp * h->D);
+    {
+        // diagnostic switches of the environment, read once (not per sweep)
+        h->env_no_gate = getenv("SGP_NO_GATE") != nullptr;
+        h->env_join_event = getenv("SGP_JOIN_EVENT") != nullptr;
+        h->env_grad_one_stream = getenv("SGP_GRAD_ONE_STREAM") != nullptr;
+        if (const char* lim = getenv("SGP_SPIN_LIMIT")) h->spin_limit = std::max(1, atoi(lim));
+        if (const char* ov = getenv("SGP_OVERLAP")) h->env_overlap = atoi(ov);
+        if (const char* g1 = getenv("SGP_G1_AFTER")) h->env_g1_mode = atoi(g1);
+        if (const char* oc = getenv("SGP_OVERLAP_COLS"))
+            for (const char* q = oc; *q;) {
+                h->env_overlap_cols.push_back(atoi(q));
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+    }
+#ifdef SGP_WITH_PERSISTENT_CHAIN
     {
         // opt-in: one persistent launch per factorisation (sgp_chain.hip.h) instead of one launch per 64-column step
         const char* env = getenv("SGP_CHAIN");
@@ -427,6 +494,14 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
             hipDeviceSynchronize();
         }
     }
+#else
+    if ((cfg->flags & SGP_FLAG_PERSISTENT_CHAIN) || (getenv("SGP_CHAIN") && strcmp(getenv("SGP_CHAIN"), "persistent") == 0)) {
+        g_create_error = "sgp_create: this build does not contain the persistent factorisation launch (build the variant library "
+                         "with -DSGP_WITH_PERSISTENT_CHAIN: gaussianprocessnode_amd._build.build(variant=\"chain\"))";
+        sgp_destroy(h);
+        return SGP_ERR_ARG;
+    }
+#endif
     if (cfg->flags & SGP_FLAG_KEEP_KUF) {
         ALLOC(h->dPa, (size_t)h->T * nmax);
         ALLOC(h->dPb, (size_t)h->T * nmax);
@@ -452,8 +527,26 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         sgp_destroy(h);
         return SGP_ERR_HIP;
     }
+    // The overlapped sweep's statistics streams.  statM is a CU-masked queue (hipExtStreamCreateWithCUMask): bit i of the mask
+    // is CU (i / 8 / 4) of shader engine (i / 8) % 4 of XCD i % 8 (measured with tools/cu_mask_probe.hip), so the first
+    // 32 k bits are k CUs on every shader engine of every XCD -- a symmetric mask: an uneven one (e.g. 216 bits) leaves some
+    // engines with fewer CUs than their equal share of the workgroups and costs a second round.
+    if (h->env_overlap != 0 && !(cfg->flags & SGP_FLAG_GRAPH) && h->dout == 1 && h->num_cus % 32 == 0 && h->num_cus / 32 > RESERVED_CUS_PER_SE) {
+        const int keep = h->num_cus - 32 * RESERVED_CUS_PER_SE;
+        uint32_t mask[16] = {0};
+        for (int i = 0; i < keep && i < 512; ++i) mask[i / 32] |= 1u << (i % 32);
+        // (Confining the K_uu chain's stream to the complement, the reserved CUs, was measured and dropped: an unmasked launch
+        // -- the Lambda chain's -- is dealt CUs from both ends of each shader engine's list, the reserved ones included, and the
+        // two chains then queued for the same few CUs while the rest of the chip idled: 47 instead of 18 us per step.)
+        if (hipExtStreamCreateWithCUMask(&h->statM, (uint32_t)((h->num_cus + 31) / 32), mask) == hipSuccess)
+            h->stat_cus_masked = keep;
+        else {
+            (void)hipGetLastError();
+            h->statM = nullptr;
+        }
+    }
     hipMemset(h->dInfo, 0, 4 * sizeof(int));
-    hipMemset(h->dJoin, 0, 4 * sizeof(long long));
+    hipMemset(h->dJoin, 0, WORD_COUNT * sizeof(long long));
     hipMemset(h->dOut, 0, SGP_R_COUNT * sizeof(double));
     hipMemset(h->dStamps, 0, STAMP_STRIDE * SGP_T_COUNT * sizeof(int64_t));
     hipMemset(h->dStampTotals, 0, (SGP_T_COUNT + 1 + 2 * SGP_T_COUNT) * sizeof(int64_t));
@@ -467,7 +560,9 @@ extern "C" int sgp_destroy(sgp_handle* h) {
     if (!h) return 0;
     hipSetDevice(h->cfg.device);
     hipDeviceSynchronize();
+#ifdef SGP_WITH_PERSISTENT_CHAIN
     if (g_chain_owner == h) g_chain_owner = nullptr;
+#endif
     h->gLocal.reset();
     h->gFinish.reset();
     h->gFinish2.reset();
@@ -476,19 +571,25 @@ extern "C" int sgp_destroy(sgp_handle* h) {
                     h->dDataScal, h->dKuu, h->dWk, h->dKinv, h->dLam, h->dWl, h->dSigma, h->dR, h->dTmp, h->dLambda0,
                     h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
                     h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals, h->dUvWork,
-                    h->dGradM, h->dGradPart, h->dGrad, h->dCall, h->dSaccK, h->dChainFlags[0], h->dChainFlags[1],
-                    h->dChainFar[0][0], h->dChainFar[0][1], h->dChainFar[1][0], h->dChainFar[1][1],
-                    h->dChainShip[0][0], h->dChainShip[0][1], h->dChainShip[1][0], h->dChainShip[1][1],
-                    h->dChainRinv[0][0], h->dChainRinv[0][1], h->dChainRinv[1][0], h->dChainRinv[1][1],
-                    h->dChainTrace[0], h->dChainTrace[1], h->dKuuAlt, h->dLamAlt,
-                    h->dChainArgs[0][0], h->dChainArgs[0][1], h->dChainArgs[1][0], h->dChainArgs[1][1],
+                    h->dGradM, h->dGradPart, h->dGrad, h->dCall, h->dSaccK,
                     h->dTrainX, h->dTrainY, h->dTrain, h->dTrainParams, h->dJoin};
     for (void* b : bufs) if (b) hipFree(b);
+#ifdef SGP_WITH_PERSISTENT_CHAIN
+    void* cbufs[] = {h->dChainFlags[0], h->dChainFlags[1],
+                     h->dChainFar[0][0], h->dChainFar[0][1], h->dChainFar[1][0], h->dChainFar[1][1],
+                     h->dChainShip[0][0], h->dChainShip[0][1], h->dChainShip[1][0], h->dChainShip[1][1],
+                     h->dChainRinv[0][0], h->dChainRinv[0][1], h->dChainRinv[1][0], h->dChainRinv[1][1],
+                     h->dChainTrace[0], h->dChainTrace[1], h->dKuuAlt, h->dLamAlt,
+                     h->dChainArgs[0][0], h->dChainArgs[0][1], h->dChainArgs[1][0], h->dChainArgs[1][1]};
+    for (void* b : cbufs) if (b) hipFree(b);
+#endif
     if (h->hParams) hipHostFree(h->hParams);
     if (h->evSide) hipEventDestroy(h->evSide);
     if (h->evDone) hipEventDestroy(h->evDone);
     if (h->own) hipStreamDestroy(h->own);
     if (h->side) hipStreamDestroy(h->side);
+    if (h->statM) hipStreamDestroy(h->statM);
+    --g_live_handles;
     delete h;
     return 0;
 }
@@ -505,6 +606,100 @@ extern "C" int sgp_set_inducing(sgp_handle* h, const double* Xu) {
     return 0;
 }
 
+// split n points into about `want` chunks (a multiple of the stage size each); the chunk count is rounded up to a multiple of
+// `align` (trailing chunks may then be empty: zero slabs)
+static void split_points(int64_t n, int want, int align, int* chunk, int* nchunks) {
+    int64_t per = (n + want - 1) / std::max(want, 1);
+    per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);
+    int nc = (int)std::max<int64_t>(1, (n + per - 1) / per);
+    if (nc > align) nc = (nc + align - 1) / align * align;
+    *chunk = (int)per;
+    *nchunks = nc;
+}
+
+// The overlapped sweep: does this problem qualify, and how are the tile columns of P Lambda P grouped?
+//   * UniSGP, eager launches, the masked statistics stream exists, at least 3 tile rows, a SYRK that fills the chip (the same
+//     bound as the K_uu chain's gate).
+//   * group 0 (tile columns [0, c0) of P Lambda P = the LAST c0 tile rows of Psi2) runs on all CUs in front of the chain, the
+//     other groups on the masked stream while the chain factors; a group must be complete when the chain reaches its first
+//     column.  The cuts are chosen by a small model of that schedule (all plans of up to three groups are tried): per-tile
+//     SYRK time proportional to n (1.63 us per 10 000 points on all CUs, measured at T), the masked groups slower by the CU
+//     ratio, ~12 / ~10 us of launch gaps + assembly per unmasked / masked group, ~18 us per chain step.  Measured at T
+//     (N = 10 000, M = 512; sweeps/s on one box): plain order 3750; cuts {3} 3896, {2} 3832-3950, {2,4} 3925, {1,3} 3656,
+//     {2,3,5} 3790, {1,2,4} 3528 -- the model ranks them the same way.  When no plan beats the plain order by 5 us the plain
+//     order stays (huge N: the masked groups' lost CUs cost more than the chain's early start saves).
+static double model_overlap_end(const sgp_handle* h, int64_t n, const int* cuts, int ncuts, double* classic_end) {
+    const int T = h->T;
+    const double tau0 = 1.63e-4 * (double)n, taum = tau0 * (double)h->num_cus / (double)h->stat_cus_masked;
+    const double ovh0 = 12.0, ovhm = 10.0, step = 18.0;
+    auto tiles_upto = [&](int c) { return c * (2 * T - c + 1) / 2; };
+    if (classic_end) *classic_end = h->ntiles * tau0 + ovh0 + step * T;
+    double ready[LAM_MAX_COLS];
+    double t = tiles_upto(cuts[0]) * tau0 + ovh0;             // group 0 assembled
+    for (int c = 0; c < cuts[0]; ++c) ready[c] = t;
+    for (int g = 0; g < ncuts; ++g) {
+        const int c0 = cuts[g], c1 = (g + 1 < ncuts) ? cuts[g + 1] : T;
+        t += (tiles_upto(c1) - tiles_upto(c0)) * taum + ovhm;
+        for (int c = c0; c < c1; ++c) ready[c] = t;
+    }
+    double end = ready[0];
+    for (int j = 0; j < T; ++j) end = std::max(end, ready[j]) + step;
+    return end;
+}
+
+static void plan_overlap(sgp_handle* h, int64_t n) {
+    h->overlap = false;
+    h->ngroups = 0;
+    const int T = h->T;
+    if (!h->statM || h->env_overlap == 0 || h->dout != 1 || T < 3 || T > LAM_MAX_COLS || h->use_chain || h->training ||
+        (h->cfg.flags & SGP_FLAG_GRAPH) || n < 1 || (!h->gate_side && h->env_overlap != 1))
+        return;
+    std::vector<int> cuts;                                   // group boundaries, ascending, in (0, T)
+    for (int c : h->env_overlap_cols) if (c > 0 && c < T && (cuts.empty() || c > cuts.back())) cuts.push_back(c);
+    if (cuts.empty()) {
+        double classic = 0.0, best = 1e300;
+        int cand[2];
+        for (int a = 1; a < T; ++a)
+            for (int b = a; b < T; ++b) {                    // b == a: one cut
+                cand[0] = a; cand[1] = b;
+                const int nc = (b > a) ? 2 : 1;
+                const double e = model_overlap_end(h, n, cand, nc, &classic);
+                if (e < best - 1e-9) { best = e; cuts.assign(cand, cand + nc); }
+            }
+        if (h->env_overlap != 1 && best > classic - 5.0) return;
+    }
+    if ((int)cuts.size() + 1 > LAM_MAX_GROUPS) return;
+    size_t off = 0;
+    int c0 = 0;
+    for (size_t g = 0; g <= cuts.size(); ++g) {
+        StatGroup& G = h->grp[g];
+        G.c0 = c0;
+        G.c1 = (g < cuts.size()) ? cuts[g] : T;
+        G.row_lo = T - G.c1;
+        G.nrows = G.c1 - G.c0;
+        G.tile0 = G.row_lo * (G.row_lo + 1) / 2;
+        G.ntiles = (T - G.c0) * (T - G.c0 + 1) / 2 - G.tile0;
+        G.masked = g > 0;
+        G.form_step = G.c0;
+        int want = 1, align = 1;
+        syrk_chunking(G.ntiles, G.masked ? h->stat_cus_masked : h->num_cus, &want, &align, 0);
+        split_points(n, want, align, &G.chunk, &G.nchunks);
+        G.slab_off = off;
+        off += (size_t)G.nchunks * G.ntiles * TB * TB;
+        c0 = G.c1;
+    }
+    if (off > h->slab_capacity) {
+        // (only from the blocking setters: nothing is in flight)
+        double* bigger = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&bigger), sizeof(double) * off) != hipSuccess) { (void)hipGetLastError(); return; }
+        hipFree(h->dSlabs);
+        h->dSlabs = bigger;
+        h->slab_capacity = off;
+    }
+    h->ngroups = (int)cuts.size() + 1;
+    h->overlap = true;
+}
+
 // the launch geometry of the data-sized kernels for n points
 static int set_point_count(sgp_handle* h, int64_t n) {
     h->n = n;
@@ -516,15 +711,12 @@ static int set_point_count(sgp_handle* h, int64_t n) {
     // chain then runs after the SYRK and still ends ~9 us before its join).  Small problems keep the early chain: there the
     // two chains are the sweep, and a late K_uu chain is waited for (C1: -15 %, C5: -2 % with the gate).
     h->gate_side = n * (int64_t)h->ntiles >= 200000 && h->dJoin && !(h->cfg.flags & SGP_FLAG_GRAPH) && !h->use_chain &&
-                   !getenv("SGP_NO_GATE");
+                   !h->env_no_gate;
     syrk_chunking(h->ntiles, h->num_cus, &want, &align, h->gate_side ? 0 : SYRK_RESERVED_CUS);
-    int64_t per = (n + want - 1) / want;
-    per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);
-    h->chunk = (int)per;
-    h->nchunks = (int)std::max<int64_t>(1, (n + per - 1) / per);
-    if (h->nchunks > align) h->nchunks = (h->nchunks + align - 1) / align * align;   // trailing chunks may be empty (zero slabs)
+    split_points(n, want, align, &h->chunk, &h->nchunks);
     if ((size_t)h->nchunks * h->ntiles * TB * TB > h->slab_capacity)
         return fail(h, SGP_ERR_ARG, "sgp_set_data: internal slab capacity exceeded");
+    plan_overlap(h, n);
     return 0;
 }
 
@@ -725,24 +917,37 @@ extern "C" int sgp_bind_stats(sgp_handle* h, void* stats_dev) {
 // different streams (parallel branches inside ONE captured graph were observed to execute back to back).
 static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
-    const bool words = !(h->cfg.flags & SGP_FLAG_GRAPH) && s == h->side;
+    const bool words = h->dev_words && s == h->side;
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->params_src,
                        h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0,
-                       words ? (const long long*)(h->dJoin + 1) : (const long long*)nullptr, h->done_epoch,
-                       (words && h->gate_side) ? (const long long*)(h->dJoin + 2) : (const long long*)nullptr,
-                       h->gate_epoch);
+                       words ? (const long long*)(h->dJoin + WORD_DONE) : (const long long*)nullptr, h->done_epoch,
+                       (words && h->gate_side) ? (const long long*)(h->dJoin + WORD_GATE) : (const long long*)nullptr,
+                       h->gate_epoch, h->spin_limit, h->dInfo + 3);
+#ifdef SGP_WITH_PERSISTENT_CHAIN
     if (h->use_chain) {
         if (h->gate_kuu)
             hipLaunchKernelGGL(k_chain_gate, dim3(1), dim3(64), 0, s, (const long long*)(h->dChainFlags[0] + CH_F_GATE), h->gate_epoch);
         std::swap(h->dKuu, h->dKuuAlt);         // this launch's factor goes to the buffer the last one refilled with sentinels
         launch_chain(h, 0, h->dKuu, h->dKuuAlt, Mp, T, h->dInfo + 0, M, s, h->dWk, nullptr, h->dSaccK, nullptr, nullptr, h->dXusK,
                      h->dParamsK, M, D);
-    } else {
+    } else
+#endif
+    {
         hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
         launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk, nullptr, h->dSaccK);
     }
     launch_ata(h->dWk, h->dKinv, Mp, T, s, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->dSaccK);
-    if (h->join_by_flag) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin, h->join_epoch);
+    if (h->join_by_flag) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_JOIN, h->join_epoch);
+}
+
+static void launch_gram(sgp_handle* h, hipStream_t s, bool opens_sweep) {
+    int64_t* sweep_begin = opens_sweep ? h->dStamps : nullptr;
+    if (h->D <= 8)
+        hipLaunchKernelGGL(k_gram_uf<8>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
+                           h->dParams, h->M, h->Mp, h->D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, sweep_begin);
+    else
+        hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
+                           h->dParams, h->M, h->Mp, h->D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, sweep_begin);
 }
 
 static void enqueue_local(sgp_handle* h, hipStream_t s) {
@@ -754,24 +959,64 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     if (prep) {
         hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->params_src,
                            h->dParams, (int*)nullptr, M, Mp, D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP,
-                           (const long long*)nullptr, 0LL, (const long long*)nullptr, 0LL);
+                           (const long long*)nullptr, 0LL, (const long long*)nullptr, 0LL, h->spin_limit, (int*)nullptr);
         h->main_prep_gen = h->params_gen;
     }
     if (h->n > 0) {
-        if (D <= 8)
-            hipLaunchKernelGGL(k_gram_uf<8>, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
-                               h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, h->dStamps);
-        else
-            hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
-                               h->dParams, M, Mp, D, h->n, h->dout, h->dStamps + STAMP_STRIDE * SGP_T_GRAM, h->dStamps);
+        launch_gram(h, s, true);
+        long long* gate = h->gate_side ? h->dJoin + WORD_GATE : nullptr;
+#ifdef SGP_WITH_PERSISTENT_CHAIN
+        if (h->use_chain) gate = h->dChainFlags[0] + CH_F_GATE;
+#endif
         hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
-                           h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, h->ntiles, h->nchunks,
-                           h->dStamps + STAMP_STRIDE * SGP_T_SYRK,
-                           h->use_chain ? h->dChainFlags[0] + CH_F_GATE : (h->gate_side ? h->dJoin + 2 : nullptr), h->gate_epoch);
+                           h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, 0, h->ntiles, h->nchunks,
+                           h->dStamps + STAMP_STRIDE * SGP_T_SYRK, gate, h->gate_epoch);
     }
-    hipLaunchKernelGGL(k_assemble, dim3(T, T, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp,
+    hipLaunchKernelGGL(k_assemble, dim3(T, T + 1, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp, T, 0, 0,
                        h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
-                       SGP_S_COUNT + h->dout * h->dout, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL, h->dInfo + 1);
+                       SGP_S_COUNT + h->dout * h->dout, 1, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL, h->dInfo + 1, (long long*)nullptr, 0LL);
+}
+
+// The statistics of an overlapped sweep (see plan_overlap): the same kernels, the SYRK and the assembly once per tile-row group.
+// Group 0 runs on all CUs on the sweep's own stream, in front of the Lambda chain (plain stream order: no hand-off on the
+// critical path); the other groups on the CU-masked stream (statM), so that they cannot take the compute units the
+// factorisation chains run on.  No events: statM's first kernel waits for the word the first block of group 0's k_assemble
+// sets (group 0's SYRK has drained), a k_join_set behind each masked group's k_assemble writes the sweep's number into the
+// group's word (the kernel boundary in front of it makes the statistics visible device-wide), and the chain step that forms the
+// group polls that word.
+static void enqueue_stats_overlapped(sgp_handle* h, hipStream_t own) {
+    const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
+    ++h->stat_epoch;
+    // (as in enqueue_local: a sweep at unchanged parameters starts with the Gram kernel)
+    const bool prep = h->main_prep_gen != h->params_gen;
+    if (prep) {
+        hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, own, h->dXu, h->dXus, h->params_src,
+                           h->dParams, (int*)nullptr, M, Mp, D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP,
+                           (const long long*)nullptr, 0LL, (const long long*)nullptr, 0LL, h->spin_limit, (int*)nullptr);
+        h->main_prep_gen = h->params_gen;
+    }
+    launch_gram(h, own, true);
+    // When the masked groups may start (A/B switch SGP_G1_AFTER, read in sgp_create): 2 (default) = when group 0's assembly
+    // starts, i.e. its SYRK has drained; 0 = as soon as group 0's SYRK has its round on the CUs (the masked SYRK then fills the
+    // CUs as they drain, but group 0's assembly shares them with it: 12.7 instead of 8.7 us on the critical path);
+    // 1 = when group 0 is assembled (the chains' whole-CU workgroups settle on the idle masked CUs meanwhile and the masked
+    // SYRK no longer fits its single round).  Sweeps/s at T on one box: 3978 / 3975 / 3865.
+    const int g1_mode = h->env_g1_mode;
+    const long long* g1_word = h->dJoin + (g1_mode == 0 ? WORD_GATE : (g1_mode == 1 ? WORD_GROUP0 : WORD_ASM0));
+    hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, h->statM, g1_word, g1_mode == 0 ? h->gate_epoch : h->stat_epoch,
+                       h->spin_limit, h->dInfo + 3, (int)SYNC_LATE_COLUMN);
+    for (int g = 0; g < h->ngroups; ++g) {
+        const StatGroup& G = h->grp[g];
+        hipStream_t s = G.masked ? h->statM : own;
+        hipLaunchKernelGGL(k_syrk_stream, dim3(G.ntiles * G.nchunks), dim3(256), 0, s, h->dKuf, h->has_omega ? h->dOmega : nullptr,
+                           h->dSlabs + G.slab_off, Mp, h->n, G.chunk, G.tile0, G.ntiles, G.nchunks,
+                           h->dStamps + STAMP_STRIDE * SGP_T_SYRK, g == 0 ? h->dJoin + WORD_GATE : (long long*)nullptr, h->gate_epoch);
+        hipLaunchKernelGGL(k_assemble, dim3(G.nrows, T + (g == 0 ? 1 : 0), 16), dim3(256), 0, s, h->dSlabs + G.slab_off, h->dBpart,
+                           h->dDataScal, h->dStats, Mp, T, G.row_lo, G.tile0, G.ntiles, G.nchunks, h->nblk, h->dout,
+                           SGP_S_COUNT + h->dout * h->dout, g == 0 ? 1 : 0, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL,
+                           g == 0 ? h->dInfo + 1 : (int*)nullptr, g == 0 ? h->dJoin + WORD_ASM0 : (long long*)nullptr, h->stat_epoch);
+        if (G.masked || g1_mode == 1) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_GROUP0 + g, h->stat_epoch);
+    }
 }
 
 static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
@@ -781,14 +1026,33 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     // (Lambda = Lambda0 + W (x) Psi2 and xi are formed by step 0 of the factorisation itself; the status word was reset by
     // k_assemble)
     LamForm form;
+    memset(&form, 0, sizeof form);
     form.stats = h->dStats; form.Lambda0 = h->dLambda0; form.xi0 = h->dXi0; form.xi = h->dXi; form.P = h->dParams;
     form.M = M; form.Mp = Mp; form.d_out = h->dout; form.Q = Q; form.prior_form = h->prior_form;
     form.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
+    form.spin_limit = h->spin_limit;
+    form.sync_status = h->dInfo + 3;
+    if (h->overlap_now) {
+        // the statistics arrive group by group while the chain runs (enqueue_stats_overlapped): step G.form_step forms group G.
+        // Group 0 was summed on this very stream: nothing to wait for.  (A step 0 resident from the start of the sweep and
+        // waiting for its statistics itself was measured too: on T + 1 CUs it keeps group 0's SYRK from its full single round,
+        // 54 instead of 35 us.)
+        form.col_words = h->dJoin + WORD_GROUP0;
+        form.col_need = h->stat_epoch;
+        for (int g = 0; g < h->ngroups; ++g) {
+            for (int c = h->grp[g].c0; c < h->grp[g].c1; ++c) {
+                form.form_step[c] = (unsigned char)h->grp[g].form_step;
+                form.col_group[c] = h->grp[g].masked ? (unsigned char)g : (unsigned char)0xff;
+            }
+        }
+    }
     double* uvt0 = h->dUvWork + 2 * (size_t)Qp;     // t = W' P xi, advanced block by block during the factorisation
+#ifdef SGP_WITH_PERSISTENT_CHAIN
     if (h->use_chain) {
         std::swap(h->dLam, h->dLamAlt);
         launch_chain(h, 1, h->dLam, h->dLamAlt, Qp, TQ, h->dInfo + 1, Qp, s, h->dWl, &form, h->dTmp, h->dXi, uvt0, nullptr, nullptr, 0, 0);
     } else
+#endif
         launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + 3 * TB * TB, s, h->dWl, &form, h->dTmp, h->dXi, uvt0);
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
     // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
@@ -818,8 +1082,10 @@ static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
     UvArgs uv;
     uv.Wp = h->dWl; uv.p = uvp; uv.ck = uvck; uv.ak = uvak; uv.partial = uvpart; uv.LR = h->dUvT;
     uv.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
-    uv.join = h->join_by_flag ? h->dJoin : nullptr;
+    uv.join = h->join_by_flag ? h->dJoin + WORD_JOIN : nullptr;
     uv.join_need = h->join_epoch;
+    uv.spin_limit = h->spin_limit;
+    uv.sync_status = h->dInfo + 3;
     if (h->dout == 1) {
         launch_ata(h->dWl, h->dSigma, Qp, TQ, s, 1, h->dMu, h->dR, h->dStats, h->dKinv, traceR, &uv, h->dTmp);
         partK = traceR + nata;
@@ -833,7 +1099,7 @@ static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, partK, nK, (const double*)traceR, nR, h->dMu, h->dKuu,
                        h->dLam, h->dInfo, h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q,
                        h->dStamps + STAMP_STRIDE * SGP_T_FINISH2, h->dStamps, h->dStampTotals,
-                       (h->cfg.flags & SGP_FLAG_GRAPH) ? (long long*)nullptr : h->dJoin + 1, h->done_epoch);
+                       (h->cfg.flags & SGP_FLAG_GRAPH) ? (long long*)nullptr : h->dJoin + WORD_DONE, h->done_epoch);
 }
 
 static int set_device_checked(int device) {
@@ -846,6 +1112,11 @@ static int set_device_checked(int device) {
 
 // device temporaries of the stand-alone building blocks: freed on every exit path
 namespace {
+struct EventPair {                      // a timing pair that is destroyed on every exit path
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+    hipError_t create() { hipError_t e = hipEventCreate(&a); return e != hipSuccess ? e : hipEventCreate(&b); }
+};
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) hipFree(p); }
@@ -885,46 +1156,70 @@ static int check_ready(sgp_handle* h) {
     return 0;
 }
 
-extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) {
+// `overlapped`: the statistics go to the handle's own statistics streams in tile-row groups and the Lambda chain (sgp_sweep_finish
+// on the library's stream) starts on the first group while the others are still being summed (plan_overlap); only from
+// sgp_sweep, which owns both halves.
+static int sweep_local_impl(sgp_handle* h, void* stream, bool overlapped) {
     int rc = check_ready(h);
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
+#ifdef SGP_WITH_PERSISTENT_CHAIN
     if (h->use_chain) {
         if (g_chain_owner && g_chain_owner != h) HIPCHK(h, hipDeviceSynchronize());
         g_chain_owner = h;
     }
+#endif
     h->in_flight = true;
+    h->overlap_now = overlapped;
     // The K_uu chain depends on theta and Xu only: it starts on the (low-priority) side stream as soon as the previous
     // sweep has finished with its outputs, runs beside the data-sized kernels, the all-reduce and the Lambda chain, and is
-    // joined just before the Sigma launch.  The main stream itself only ever WAITS on the side stream's event and records
-    // one event at the very end of a sweep: an event record between two of its kernels was measured at ~6 us of idle time.
-    // (eager launches: the chain's first kernel waits for the previous sweep's done word itself, see enqueue_kuu)
-    if (h->cfg.flags & SGP_FLAG_GRAPH) HIPCHK(h, hipStreamWaitEvent(h->side, h->evDone, 0));
+    // joined just before the Sigma launch.  Eager launches meet through device words (the chain's first kernel waits for the
+    // previous sweep's done word itself, see enqueue_kuu): an event record or wait between two kernels of a stream was
+    // measured at ~6 us of idle time.  Captured graphs use events -- and so does a sweep with an all-reduce hook, in addition:
+    // the words are waited for with a BOUNDED spin (~1 s), and a collective that builds its rings or waits for a straggler
+    // rank may take longer than that.
+    const bool graph = (h->cfg.flags & SGP_FLAG_GRAPH) != 0;
+    const bool hooked = h->allreduce != nullptr && !overlapped;
+    h->dev_words = !graph;
+    h->use_events = graph || hooked;
+    if (h->use_events) HIPCHK(h, hipStreamWaitEvent(h->side, h->evDone, 0));
     // How F2 will join the K_uu chain: an event wait between two kernels of the main stream costs it ~5 us of idle time even
     // when the event fired long ago, so the UniSGP path lets the Sigma launch's product workgroups poll a device word in
     // front of their epilogue instead (k_join_set behind the chain's last kernel).  Only while that launch leaves enough
-    // CUs free for a late chain's workgroups (each needs a whole CU's LDS), and not inside captured graphs.
+    // CUs free for a late chain's workgroups (each needs a whole CU's LDS) -- which nobody can promise when a collective or a
+    // second handle's sweep may hold CUs too --, and not inside captured graphs.
     {
         const int grid = h->TQ * (h->TQ + 1) / 2 * 4 + h->TQ * h->TQ;
-        h->join_by_flag = h->dJoin && h->dout == 1 && !(h->cfg.flags & SGP_FLAG_GRAPH) && grid <= h->num_cus - 40 &&
-                          !getenv("SGP_JOIN_EVENT");
+        h->join_by_flag = h->dJoin && h->dout == 1 && !h->use_events && grid <= h->num_cus - 40 && !h->env_join_event &&
+                          g_live_handles.load() <= 1;
         ++h->join_epoch;
     }
     ++h->gate_epoch;
+#ifdef SGP_WITH_PERSISTENT_CHAIN
     h->gate_kuu = h->use_chain && h->n > 0;                    // (a SYRK launch follows on the main stream and opens the gate)
+#endif
     rc = run_sequence(h, h->gKuu, enqueue_kuu, h->side);
+#ifdef SGP_WITH_PERSISTENT_CHAIN
     h->gate_kuu = false;
+#endif
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->evSide, h->side));
-    rc = run_sequence(h, h->gLocal, enqueue_local, s);
-    if (rc) return rc;
+    if (overlapped) {
+        enqueue_stats_overlapped(h, s);
+        HIPCHK(h, hipGetLastError());
+    } else {
+        rc = run_sequence(h, h->gLocal, enqueue_local, s);
+        if (rc) return rc;
+    }
     h->stats_dirty = false;
     h->swept_params = *h->hParams;
     h->swept_data_gen = h->data_gen;
     h->swept_local = true;
     return 0;
 }
+
+extern "C" int sgp_sweep_local(sgp_handle* h, void* stream) { return sweep_local_impl(h, stream, false); }
 
 extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
     if (!h) return SGP_ERR_ARG;
@@ -939,13 +1234,17 @@ extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
     rc = run_sequence(h, h->gFinish2, enqueue_finish2, s);
     if (rc) return rc;
     // the next sweep's K_uu chain may overwrite K_uu^-1 after this
-    if (h->cfg.flags & SGP_FLAG_GRAPH) HIPCHK(h, hipEventRecord(h->evDone, s));
+    if (h->use_events) HIPCHK(h, hipEventRecord(h->evDone, s));
+    h->overlap_now = false;
     h->swept = true;
     return 0;
 }
 
 extern "C" int sgp_sweep(sgp_handle* h, void* stream) {
-    int rc = sgp_sweep_local(h, stream);
+    if (!h) return SGP_ERR_ARG;
+    // single GPU, the library's own streams, a problem that qualifies: statistics and Lambda chain overlapped
+    const bool overlapped = h->overlap && !h->allreduce && !stream && h->n > 0 && !h->training;
+    int rc = sweep_local_impl(h, stream, overlapped);
     if (rc) return rc;
     if (h->allreduce) {
         // the one exchange step: sum the packed statistics over the ranks, on the sweep's stream (the K_uu chain keeps
@@ -1033,18 +1332,15 @@ extern "C" int sgp_measure_clocks(int32_t device, double* out) {
     const int cus = prop.multiProcessorCount, blocks = 4 * cus, iters = 4000;
     DevBuf b;
     HIPCHK(h, b.alloc(3 * sizeof(long long)));
-    hipEvent_t e0, e1;
-    HIPCHK(h, hipEventCreate(&e0));
-    HIPCHK(h, hipEventCreate(&e1));
+    EventPair ev;
+    HIPCHK(h, ev.create());
     hipLaunchKernelGGL(k_clock_probe_mfma, dim3(blocks), dim3(256), 0, 0, b.as<long long>(), iters);       // warm the clocks
-    HIPCHK(h, hipEventRecord(e0, 0));
+    HIPCHK(h, hipEventRecord(ev.a, 0));
     hipLaunchKernelGGL(k_clock_probe_mfma, dim3(blocks), dim3(256), 0, 0, b.as<long long>(), iters);
-    HIPCHK(h, hipEventRecord(e1, 0));
+    HIPCHK(h, hipEventRecord(ev.b, 0));
     HIPCHK(h, hipDeviceSynchronize());
     float ms = 0.f;
-    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    HIPCHK(h, hipEventElapsedTime(&ms, ev.a, ev.b));
     long long v[3];
     HIPCHK(h, hipMemcpy(v, b.p, sizeof v, hipMemcpyDeviceToHost));
     out[0] = v[1] > 0 ? 100.0 * (double)v[0] / (double)v[1] : 0.0;
@@ -1062,6 +1358,24 @@ static int sync_all(sgp_handle* h) {
     HIPCHK(h, hipDeviceSynchronize());
     h->in_flight = false;
     return 0;
+}
+
+// A bounded wait on a device word gave up somewhere since the last check (dInfo[3], see SYNC_LATE_* in sgp_kernels.hip.h): what
+// the wait protected -- the buffers the two streams hand each other -- cannot be trusted, so the results are refused.  The
+// word is cleared: the next sweep starts clean.  Call after a device synchronisation.
+static int check_sync_status(sgp_handle* h) {
+    int bits = 0;
+    HIPCHK(h, hipMemcpy(&bits, h->dInfo + 3, sizeof(int), hipMemcpyDeviceToHost));
+    if (bits == 0) return 0;
+    HIPCHK(h, hipMemset(h->dInfo + 3, 0, sizeof(int)));
+    std::string msg = "a bounded device-word wait gave up (stream hand-off not honoured; results refused):";
+    if (bits & SYNC_LATE_DONE) msg += " [done word: the next sweep's first kernels started before the previous sweep had finished]";
+    if (bits & SYNC_LATE_GRAD_START) msg += " [done word: the K_uu half of the theta gradient started before the sweep had finished]";
+    if (bits & SYNC_LATE_KINV) msg += " [join word: the Sigma launch did not get K_uu^-1 from the K_uu chain]";
+    if (bits & SYNC_LATE_GRAD_JOIN) msg += " [gradient word: the K_uu half of the theta gradient did not arrive]";
+    if (bits & SYNC_LATE_COLUMN) msg += " [statistics words: a Lambda-chain step did not get its tile columns / the masked stream did not get K_uf]";
+    h->err = msg;
+    return SGP_ERR_HIP;
 }
 
 static int download_square(sgp_handle* h, const double* dsrc, int ld, int n, double* dst) {
@@ -1095,6 +1409,7 @@ extern "C" int sgp_get_scalars(sgp_handle* h, double* out) {
     if (!h->swept) return fail(h, SGP_ERR_ARG, "sgp_get_scalars: no finished sweep");
     int rc = sync_all(h);
     if (rc) return rc;
+    if (int src = check_sync_status(h)) return src;
     HIPCHK(h, hipMemcpy(out, h->dOut, SGP_R_COUNT * sizeof(double), hipMemcpyDeviceToHost));
     if (out[SGP_R_INFO_KUU] < 0 || out[SGP_R_INFO_LAMBDA] < 0)
         return fail(h, SGP_ERR_HIP, "the persistent factorisation launch gave up waiting (deadlock guard): its workgroups were not all resident");
@@ -1113,6 +1428,7 @@ extern "C" int sgp_get_posterior(sgp_handle* h, double* mu_v, double* Sigma_v, d
     if (!h->swept) return fail(h, SGP_ERR_ARG, "sgp_get_posterior: no finished sweep");
     int rc = sync_all(h);
     if (rc) return rc;
+    if (int src = check_sync_status(h)) return src;
     int info[4];
     HIPCHK(h, hipMemcpy(info, h->dInfo, sizeof info, hipMemcpyDeviceToHost));
     if (info[0] < 0 || info[1] < 0)
@@ -1184,17 +1500,29 @@ extern "C" int sgp_get_timestamps(sgp_handle* h, int64_t* out) {
 
 extern "C" int sgp_get_chain_trace(sgp_handle* h, int32_t which, int64_t* out) {
     if (!h || !out || which < 0 || which > 1) return SGP_ERR_ARG;
+#ifdef SGP_WITH_PERSISTENT_CHAIN
     if (!h->dChainTrace[which]) return fail(h, SGP_ERR_ARG, "sgp_get_chain_trace: create the handle with SGP_CHAIN_TRACE set in the environment");
     int rc = sync_all(h);
     if (rc) return rc;
     HIPCHK(h, hipMemcpy(out, h->dChainTrace[which], sizeof(long long) * CH_TMAX * 32, hipMemcpyDeviceToHost));
     return 0;
+#else
+    return fail(h, SGP_ERR_ARG, "sgp_get_chain_trace: this build does not contain the persistent factorisation launch");
+#endif
 }
 
 extern "C" int sgp_get_step_trace(int64_t* out) {
     if (!out) return SGP_ERR_ARG;
     if (hipDeviceSynchronize() != hipSuccess) return SGP_ERR_HIP;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_trace), sizeof(long long) * 16 * 32) != hipSuccess) return SGP_ERR_HIP;
+    return 0;
+}
+
+// diagnostics of the variant library built with -DSGP_SWEEP_TRACE (all zeros otherwise): see g_sweep_trace in sgp_kernels.hip.h
+extern "C" int sgp_get_sweep_trace(int64_t* out) {
+    if (!out) return SGP_ERR_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return SGP_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_trace), sizeof(long long) * TRACE_SLOTS_N * 65) != hipSuccess) return SGP_ERR_HIP;
     return 0;
 }
 
@@ -1219,11 +1547,23 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
     if (!h->swept_local || h->n == 0) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: run a sweep on non-empty data first");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
-    hipEvent_t e0, e1;
-    HIPCHK(h, hipEventCreate(&e0));
-    HIPCHK(h, hipEventCreate(&e1));
+    // which = SGP_TIME_GROUP0 + g: the SYRK launch of statistics group g of the overlapped sweep, on the stream (and CUs) it runs on
+    const StatGroup* G = nullptr;
+    if (which >= SGP_TIME_GROUP0) {
+        if (!h->overlap || which - SGP_TIME_GROUP0 >= h->ngroups) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: no such statistics group");
+        HIPCHK(h, hipDeviceSynchronize());
+        G = &h->grp[which - SGP_TIME_GROUP0];
+        s = G->masked ? h->statM : h->own;
+    }
+    EventPair ev;
+    HIPCHK(h, ev.create());
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     auto launch = [&]() {
-        if (which == SGP_T_GRAM && h->D <= 8)
+        if (G)
+            hipLaunchKernelGGL(k_syrk_stream, dim3(G->ntiles * G->nchunks), dim3(256), 0, s, h->dKuf, h->has_omega ? h->dOmega : nullptr,
+                               h->dSlabs + G->slab_off, h->Mp, h->n, G->chunk, G->tile0, G->ntiles, G->nchunks, (int64_t*)nullptr,
+                               (long long*)nullptr, 0LL);
+        else if (which == SGP_T_GRAM && h->D <= 8)
             hipLaunchKernelGGL(k_gram_uf<8>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr, (int64_t*)nullptr);
         else if (which == SGP_T_GRAM)
@@ -1231,10 +1571,11 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
                                h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr, (int64_t*)nullptr);
         else
             hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
-                               h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->chunk, h->ntiles, h->nchunks,
+                               h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->chunk, 0, h->ntiles, h->nchunks,
                                (int64_t*)nullptr, (long long*)nullptr, 0LL);
     };
-    if (which != SGP_T_GRAM && which != SGP_T_SYRK) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: which must be SGP_T_GRAM or SGP_T_SYRK");
+    if (!G && which != SGP_T_GRAM && which != SGP_T_SYRK)
+        return fail(h, SGP_ERR_ARG, "sgp_time_kernel: which must be SGP_T_GRAM, SGP_T_SYRK or SGP_TIME_GROUP0 + g");
     launch();
     HIPCHK(h, hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i) launch();
@@ -1242,9 +1583,24 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
     HIPCHK(h, hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     *avg_us = 1e3 * (double)ms / iters;
+    return 0;
+}
+
+// The plan of the overlapped sweep for the resident data (plan_overlap): *ngroups = 0 if the next sgp_sweep will not be an
+// overlapped one; else, per group g, info[8 g ..] = first / past-the-last tile column of P Lambda P, lower tiles, point chunks,
+// points per chunk, 1 if it runs on the CU-masked stream, CUs it may use, the Lambda-chain step that forms it.
+extern "C" int sgp_overlap_plan(const sgp_handle* h, int32_t* ngroups, int32_t* info) {
+    if (!h || !ngroups) return SGP_ERR_ARG;
+    const bool on = h->overlap && !h->allreduce && !h->training;
+    *ngroups = on ? h->ngroups : 0;
+    if (!on || !info) return 0;
+    for (int g = 0; g < h->ngroups; ++g) {
+        const StatGroup& G = h->grp[g];
+        int32_t* o = info + 8 * g;
+        o[0] = G.c0; o[1] = G.c1; o[2] = G.ntiles; o[3] = G.nchunks; o[4] = G.chunk; o[5] = G.masked ? 1 : 0;
+        o[6] = G.masked ? h->stat_cus_masked : h->num_cus; o[7] = G.form_step;
+    }
     return 0;
 }
 
@@ -1261,7 +1617,10 @@ extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) 
     const int64_t n = h->n;
     if (n == 0) return 0;
     double *dI1 = nullptr, *dI2 = nullptr;
-    HIPCHK(h, hipDeviceSynchronize());
+    // Ordered after the sweep by the stream when that is the sweep's own (the usual case: no device-wide wait in front of the
+    // three launches); a caller's stream is not ordered against the library's, so then the device is drained first.  The
+    // scratch grows only here and in sgp_predict, both blocking: a reallocation never races with a queued launch.
+    if (s != h->own || 2 * (size_t)n > h->call_capacity) HIPCHK(h, hipDeviceSynchronize());
     if (int crc = call_scratch(h, 2 * (size_t)n, &dI1)) return crc;
     dI2 = dI1 + n;
     // |L^-1 k_n|^2 with the explicit inverse factor W_k, |Uv k_n|^2 = |L_R^T k_n|^2
@@ -1311,7 +1670,7 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
     // the gradient by w_new / w_old twice).
     hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, (const Params*)h->hParams,
                        h->dParamsK, (int*)nullptr, h->M, h->Mp, h->D, (int64_t*)nullptr, 0, 0, (const long long*)nullptr, 0LL,
-                       (const long long*)nullptr, 0LL);
+                       (const long long*)nullptr, 0LL, h->spin_limit, (int*)nullptr);
     switch (h->D) {
         case 1: launch_predict<1>(h, dXs, dMu, dMean, ns, s); break;
         case 2: launch_predict<2>(h, dXs, dMu, dMean, ns, s); break;
@@ -1356,22 +1715,25 @@ static int enqueue_theta_grad(sgp_handle* h, hipStream_t s) {
     // derivatives) and the K_uu half (H = K_uu^-1 Psi2 K_uu^-1 against dK_uu).  On the library's own streams they run side
     // by side -- the K_uu half on the side stream, which idles between two sweeps -- and meet in the finishing kernel through
     // a device word (an event would cost the main stream ~6 us, see sgp_sweep_finish).
-    const bool split = s == h->own && h->dJoin && !(h->cfg.flags & SGP_FLAG_GRAPH) && !getenv("SGP_GRAD_ONE_STREAM");
+    const bool split = s == h->own && h->dJoin && !(h->cfg.flags & SGP_FLAG_GRAPH) && !h->env_grad_one_stream;
     hipStream_t su = split ? h->side : s;
-    if (split) hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, su, (const long long*)(h->dJoin + 1), h->done_epoch);
+    if (split)
+        hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, su, (const long long*)(h->dJoin + WORD_DONE), h->done_epoch,
+                           h->spin_limit, h->dInfo + 3, (int)SYNC_LATE_GRAD_START);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, su, (const double*)h->dKinv, (const double*)h->dStats, dT1,
                        Mp, T, 3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{}, (const double*)nullptr);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, su, (const double*)dT1, (const double*)h->dKinv, dH, Mp, T,
                        3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{}, (const double*)nullptr);
     hipLaunchKernelGGL(k_theta_grad_uu, dim3(T, T), dim3(256), 0, su, dH, h->dXus, h->dParams, part_uu, h->M, Mp, h->D);
-    if (split) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, su, h->dJoin + 3, ++h->grad_epoch);
+    if (split) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, su, h->dJoin + WORD_GRAD, ++h->grad_epoch);
     hipLaunchKernelGGL(k_form_G, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->dR, h->dKinv, dG, cnt);
     if (h->n > 0)
         hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T, KS), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
                            h->has_omega ? h->dOmega : nullptr, h->dMu, h->dParams, part_uf, Mp, T, h->D, h->n);
     hipLaunchKernelGGL(k_theta_grad_finish, dim3(1), dim3(256), 0, s, part_uf, n_uf, part_uu, T * T,
                        h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, h->dParams, h->dGrad, h->D, h->n_ell,
-                       split ? (const long long*)(h->dJoin + 3) : (const long long*)nullptr, h->grad_epoch);
+                       split ? (const long long*)(h->dJoin + WORD_GRAD) : (const long long*)nullptr, h->grad_epoch, h->spin_limit,
+                       h->dInfo + 3);
     return 0;
 }
 
@@ -1484,7 +1846,7 @@ extern "C" int sgp_train_begin(sgp_handle* h, const double* X, const double* y, 
     HIPCHK(h, hipMemcpy(h->dTrainParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice));
     h->n_ell = n_ell;
     hipLaunchKernelGGL(k_train_adamax, dim3(1), dim3(64), 0, h->own, h->dTrain, (const double*)nullptr, (const double*)nullptr,
-                       h->dTrainParams, h->D, n_ell, 0);
+                       h->dTrainParams, h->D, n_ell, 0, (const int*)nullptr);
     HIPCHK(h, hipStreamSynchronize(h->own));
     h->params_src = h->dTrainParams;
     h->have_kernel = true;
@@ -1521,11 +1883,12 @@ extern "C" int sgp_train_step(sgp_handle* h, int64_t offset, int64_t n, int32_t 
         if (!rc) rc = sgp_sweep_finish(h, nullptr);
         if (!rc) rc = sgp_carry_posterior(h, nullptr);
         if (!rc && learn) rc = enqueue_theta_grad(h, s);
-        if (!rc && learn)
+        // (without a learning step the kernel only keeps the books: a failed factorisation is counted either way)
+        if (!rc)
             hipLaunchKernelGGL(k_train_adamax, dim3(1), dim3(64), 0, s, h->dTrain, (const double*)h->dGrad, (const double*)h->dOut,
-                               h->dTrainParams, h->D, h->n_ell, 1);
+                               h->dTrainParams, h->D, h->n_ell, learn ? 1 : 2, (const int*)(h->dInfo + 3));
         // the next K_uu chain (side stream) reads the parameters this step wrote and overwrites the K_uu^-1 its gradient read
-        if (!rc) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + 1, ++h->done_epoch);
+        if (!rc) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_DONE, ++h->done_epoch);
     }
     h->dX = ownX; h->dYw = ownYw; h->dY = ownY;
     h->have_data = false;                                      // the window is not the handle's data: set_data again after the run
@@ -1541,10 +1904,11 @@ extern "C" int sgp_train_end(sgp_handle* h, double* theta_raw, int64_t* counts) 
     if (!h) return SGP_ERR_ARG;
     if (!h->training) return fail(h, SGP_ERR_ARG, "sgp_train_end: no run is open");
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());           // (the run stays open if this fails: steps may still be queued)
     h->training = false;
     h->params_src = h->hParams;
-    HIPCHK(h, hipDeviceSynchronize());
     h->in_flight = false;
+    if (int src = check_sync_status(h)) return src;
     TrainState st;
     HIPCHK(h, hipMemcpy(&st, h->dTrain, sizeof st, hipMemcpyDeviceToHost));
     Params P;
@@ -1611,9 +1975,10 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
         HIPCHK(h, bW.alloc(mat));
         HIPCHK(h, bC.alloc(mat));
     }
+    const double* factor = bA.as<double>();
+#ifdef SGP_WITH_PERSISTENT_CHAIN
     const char* env = getenv("SGP_CHAIN");
     const bool chain = env && strcmp(env, "persistent") == 0 && Tn <= CH_TMAX;
-    const double* factor = bA.as<double>();
     if (chain) {
         // one persistent launch (sgp_chain.hip.h); the factor goes to a buffer of its own (see ChainArgs::Ain)
         if (g_chain_owner) HIPCHK(h, hipDeviceSynchronize());
@@ -1642,7 +2007,11 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
                 hipLaunchKernelGGL(k_chain_extras, dim3(2 * (j - 1) * (j < Tn ? 2 : 1)), dim3(256), 0, 0, bL.as<double>(), np, j, Tn,
                                    bW.as<double>(), (double*)nullptr, (const double*)nullptr, (double*)nullptr);
         factor = bL.as<double>();
-    } else {
+    } else
+#else
+    const bool chain = false;
+#endif
+    {
         HIPCHK(h, bScr.alloc(sizeof(double) * 3 * TB * TB));
         HIPCHK(h, hipMemset(bScr.p, 0, sizeof(double) * 3 * TB * TB));
         launch_potrf(bA.as<double>(), np, Tn, bInfo.as<int>(), n, bScr.as<double>(), 0, bW.as<double>());
@@ -1656,6 +2025,7 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
     HIPCHK(h, hipGetLastError());
     int info = 0;
     HIPCHK(h, hipMemcpy(&info, bInfo.p, sizeof(int), hipMemcpyDeviceToHost));
+#ifdef SGP_WITH_PERSISTENT_CHAIN
     if (chain && getenv("SGP_CHAIN_DUMP")) {              // debugging aid: the mailbox matrices of this call, raw
         std::vector<double> hb((size_t)np * np);
         FILE* f = fopen(getenv("SGP_CHAIN_DUMP"), "wb");
@@ -1669,6 +2039,8 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
             fclose(f);
         }
     }
+#endif
+    (void)chain;
     if (info < 0) return fail(nullptr, SGP_ERR_HIP, "the persistent factorisation launch gave up waiting (deadlock guard)");
     HIPCHK(h, hipMemcpy2D(out, sizeof(double) * n, result, sizeof(double) * np, sizeof(double) * n, n, hipMemcpyDeviceToHost));
     if (!inverse)

@@ -44,6 +44,39 @@ struct Params {
 
 __device__ __forceinline__ int64_t realtime_ticks() { return (int64_t)__builtin_amdgcn_s_memrealtime(); }
 
+// Diagnostics (variant library built with -DSGP_SWEEP_TRACE, tools/sweep_trace.py): 100 MHz begin / end stamps of the kernels of
+// the LAST sweep, taken inside the kernels -- rocprofv3's kernel trace slows the host's launches down until the GPU starves,
+// so it cannot show how the streams of an overlapped sweep really interleave.  Slot map: 0 k_prep_xu (statistics), 1 k_prep_xu
+// (K_uu chain), 2 k_gram_uf, 3 k_gram_uu, 4 k_trmv_mu_scan, 5 / 6 k_gemm32 (Sigma launch / K_uu^-1), 7 k_scalars, 8 k_join_wait,
+// 16 + j Lambda-chain step j, 40 + j K_uu-chain step j, 64 + tile0 k_syrk_stream, 128 + row_lo k_assemble, 200 + j: the
+// moment step j of the Lambda chain had its statistics (end of its wait).
+constexpr int TRACE_SLOTS_N = 256;
+__device__ long long g_sweep_trace[TRACE_SLOTS_N * 65];
+#ifdef SGP_SWEEP_TRACE
+__device__ __forceinline__ void trace_begin(int slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && slot < TRACE_SLOTS_N) {
+        g_sweep_trace[slot * 65] = realtime_ticks();
+        for (int e = 1; e < 65; ++e) g_sweep_trace[slot * 65 + e] = 0;
+    }
+}
+__device__ __forceinline__ void trace_mark(int slot) {
+    if ((threadIdx.x & 255) == 0 && slot < TRACE_SLOTS_N) g_sweep_trace[slot * 65] = realtime_ticks();
+}
+__device__ __forceinline__ void trace_end(int slot) {
+    if (threadIdx.x == 0 && slot < TRACE_SLOTS_N)
+        atomicMax(&g_sweep_trace[slot * 65 + 1 + ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & 63)], (long long)realtime_ticks());
+}
+#else
+__device__ __forceinline__ void trace_begin(int) {}
+__device__ __forceinline__ void trace_mark(int) {}
+__device__ __forceinline__ void trace_end(int) {}
+#endif
+struct TraceScope {                     // begin at construction, end at every exit of the kernel (nothing in the product build)
+    int slot;
+    __device__ __forceinline__ explicit TraceScope(int s) : slot(s) { trace_begin(s); }
+    __device__ __forceinline__ ~TraceScope() { trace_end(slot); }
+};
+
 // deterministic workgroup sum (wave butterflies, then the waves in order); `red` = one double of LDS per wave
 __device__ __forceinline__ double block_sum(double v, double* red) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -132,6 +165,33 @@ __device__ __forceinline__ void stamp_accumulate(int64_t* stamps, int64_t* total
 }
 
 // ------------------------------------------------------------------------------------------------
+// Device words between streams.  Every wait on one is BOUNDED (a waiter that spins forever can hang the GPU for everyone on
+// the host) and a wait that gives up says so: it ORs its bit into the handle's sync-status word (dInfo[3]), which the
+// getters turn into SGP_ERR_HIP -- what the waiter was protecting is then not to be trusted.
+// ------------------------------------------------------------------------------------------------
+enum { SYNC_LATE_DONE = 1,        // the K_uu chain started before the previous sweep's done word (its outputs were still being read)
+       SYNC_LATE_GRAD_START = 2,  // the K_uu half of the theta gradient started before the sweep's done word
+       SYNC_LATE_KINV = 4,        // the Sigma launch gave up waiting for K_uu^-1 (the traces are NaN)
+       SYNC_LATE_GRAD_JOIN = 8,   // the gradient's finishing kernel gave up waiting for its K_uu half
+       SYNC_LATE_COLUMN = 16 };   // a Lambda-chain step gave up waiting for its tile column of the statistics
+constexpr int JOIN_SPIN_LIMIT = 1 << 21;    // default number of polls (>= ~0.5 us each) before a waiter gives up
+__device__ __forceinline__ bool join_ready(const long long* w, long long need) {
+    return __hip_atomic_load((const __attribute__((address_space(1))) long long*)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+}
+// one thread's bounded wait; false = gave up (and the bit is set)
+__device__ __forceinline__ bool spin_until(const long long* w, long long need, int limit, int* status, int bit) {
+    int it = 0;
+    while (!join_ready(w, need)) {
+        if (++it >= limit) {
+            if (status) atomicOr(status, bit);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Xu (D x M, AoS) -> Xus (SoA, scaled by 1/ell, padded to Mp with zeros)
 // ------------------------------------------------------------------------------------------------
 // `hP` is the handle's PINNED host copy of the parameters, read over the bus by this first kernel of a launch sequence
@@ -140,27 +200,19 @@ __device__ __forceinline__ void stamp_accumulate(int64_t* stamps, int64_t* total
 __global__ void k_prep_xu(const double* __restrict__ Xu, double* __restrict__ Xus, const Params* __restrict__ hP,
                           Params* __restrict__ dP, int* __restrict__ info_reset, int M, int Mp, int D, int64_t* stamps,
                           int nslots, int sweep_slot, const long long* wait_word, long long wait_need,
-                          const long long* gate_word, long long gate_need) {
+                          const long long* gate_word, long long gate_need, int spin_limit, int* sync_status) {
+    TraceScope trace(stamps ? 0 : 1);
     if (gate_word) {
         // ... and the chain's workgroups (each takes a whole CU's LDS) stay off the CUs until the sweep's streaming SYRK has
-        // its single resident round on them (its last workgroup sets the gate when it starts): that grid is sized for ALL CUs
-        if (threadIdx.x == 0) {
-            int it = 0;
-            while (__hip_atomic_load((const __attribute__((address_space(1))) long long*)gate_word, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT) < gate_need && ++it < (1 << 21))
-                __builtin_amdgcn_s_sleep(8);
-        }
+        // its single resident round on them (its last workgroup sets the gate when it starts): that grid is sized for ALL CUs.
+        // (Scheduling only: giving up here costs time, not correctness, so no status bit.)
+        if (threadIdx.x == 0) spin_until(gate_word, gate_need, spin_limit, nullptr, 0);
         __syncthreads();
     }
     if (wait_word) {
         // first kernel of the K_uu chain: the previous sweep's last kernel on the other stream still reads what this chain
-        // overwrites (see k_scalars).  Bounded; the buffers it protects are rewritten either way.
-        if (threadIdx.x == 0) {
-            int it = 0;
-            while (__hip_atomic_load((const __attribute__((address_space(1))) long long*)wait_word, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT) < wait_need && ++it < (1 << 21))
-                __builtin_amdgcn_s_sleep(8);
-        }
+        // overwrites (see k_scalars).  Giving up is reported (SYNC_LATE_DONE): the previous sweep's scalars may be wrong.
+        if (threadIdx.x == 0) spin_until(wait_word, wait_need, spin_limit, sync_status, SYNC_LATE_DONE);
         __syncthreads();
     }
     if (blockIdx.x == 0) {
@@ -189,6 +241,7 @@ __global__ void __launch_bounds__(256) k_gram_uu(const double* __restrict__ Xus,
                                                  const Params* __restrict__ P, int M, int Mp, int D) {
     __shared__ double ui[MAXD * TB];
     __shared__ double uj[MAXD * TB];
+    TraceScope trace(3);
     const int I = blockIdx.x * TB, J = blockIdx.y * TB;
     for (int t = threadIdx.x; t < D * TB; t += 256) {
         int d = t / TB, r = t % TB;
@@ -226,6 +279,7 @@ __global__ void __launch_bounds__(256) k_gram_uf(const double* __restrict__ Xus,
                                                  int M, int Mp, int D, int64_t N, int d_out, int64_t* stamps,
                                                  int64_t* sweep_begin) {
     __shared__ double us[DCAP * TB];
+    TraceScope trace(2);
     if (sweep_begin) {            // first kernel of a sweep whose parameters were already resident (no k_prep_xu in front)
         stamp_enter(sweep_begin + 0 * STAMP_STRIDE);          // SGP_T_SWEEP
         stamp_enter(sweep_begin + 7 * STAMP_STRIDE);          // SGP_T_LOCAL
@@ -396,14 +450,17 @@ __device__ __forceinline__ void tile_from_index(int t, int& I, int& J) {
     J = t - i * (i + 1) / 2;
 }
 
+// One launch covers the lower tiles [tile0, tile0 + ntiles) of the row-major triangle (a whole matrix: tile0 = 0, ntiles = all; the
+// overlapped sweep launches the tile rows in groups, last rows first, see sgp_api.hip); `slabs` is the group's own slab area.
 __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
                                                      double* __restrict__ slabs, int Mp, int64_t N, int chunk,
-                                                     int ntiles, int nchunks, int64_t* stamps, long long* gate,
+                                                     int tile0, int ntiles, int nchunks, int64_t* stamps, long long* gate,
                                                      long long gate_value) {
     __shared__ double lds[2 * 2 * KB * PS];           // [buf][panel A|B][KB][PS]
+    TraceScope trace(64 + tile0);
     stamp_enter(stamps);
-    // the last workgroup of this launch's single resident round is on a CU: whoever waited for that (k_chain_gate in front of
-    // the K_uu chain's persistent launch) may take the CUs that are left
+    // the last workgroup of this launch's single resident round is on a CU: whoever waited for that (the K_uu chain's first
+    // kernel) may take the CUs that are left
     if (gate && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
         __hip_atomic_store(gate, gate_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
@@ -422,7 +479,7 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
         tile_id = blockIdx.x % ntiles;
     }
     int I, J;
-    tile_from_index(tile_id, I, J);
+    tile_from_index(tile0 + tile_id, I, J);
     const bool diag = (I == J);
     const int64_t nbeg = (int64_t)chunk_id * chunk;
     int64_t nend = nbeg + chunk;
@@ -490,26 +547,52 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ slabs, const double* __restrict__ bpart,
                                                   const double* __restrict__ data_scalars, double* __restrict__ stats,
-                                                  int Mp, int ntiles, int nchunks, int nblk, int d_out, int nscal, int64_t* stamps,
-                                                  int* __restrict__ info_reset) {
-    // grid (T, T, 16): block z sums rows [4 z, 4 z + 4) of the slab tile (I, J), I >= J -- one entry per thread, up to 12
-    // chunk loads in flight (the kernel is latency-bound: the first version, 4 entries per thread in rounds of 4 chunks on a
-    // quarter of the workgroups, took 12 us for 28 MB) -- and writes both mirror images
-    __shared__ double tile[4 * LT];
-    const int I = blockIdx.x, J = blockIdx.y, z = blockIdx.z;
+                                                  int Mp, int T, int row_lo, int tile0, int ntiles, int nchunks, int nblk, int d_out,
+                                                  int nscal, int do_b, int64_t* stamps, int* __restrict__ info_reset,
+                                                  long long* start_word, long long start_value) {
+    // grid (rows, T + do_b, 16): blocks (x, y < T, z) sum rows [4 z, 4 z + 4) of the slab tile (I, J) = (row_lo + x, y), I >= J --
+    // one entry per thread, up to 12 chunk loads in flight (the kernel is latency-bound: the first version, 4 entries per
+    // thread in rounds of 4 chunks on a quarter of the workgroups, took 12 us for 28 MB) -- and write both mirror images.
+    // `slabs` / `tile0` / `ntiles`: the slab area of this launch's tile group (k_syrk_stream).  Blocks with y == T (do_b) sum the
+    // B partials and copy the data scalars.
+    // NO LDS on purpose: in the overlapped sweep this kernel runs while the NEXT group's SYRK already holds every byte of LDS on
+    // its CUs (4 x 40 KB); a block that needs none fits beside those workgroups.  Thread = (row il = tid >> 6, column j = tid & 63):
+    // a wave reads one 512-byte slab row per chunk and writes the mirror image (the upper triangle -- the part the Lambda chain
+    // and the trace epilogue read) as one 512-byte run; the tile itself goes out as 64 scattered 8-byte stores per wave, 0.5 MB
+    // in all at M = 512.  (Adjacent lanes down a column instead -- 32-byte runs both ways -- made the loads irregular across the
+    // wave and the kernel twice as slow: 15 instead of 7.7 us.)
+    // (Publishing the results to a kernel that is ALREADY running on another stream from inside this one was tried -- a counter
+    // bumped by every block: with __threadfence() each block writes the whole L2 back, which the next group's SYRK keeps filling
+    // with dirty slab lines (70 us for this kernel instead of 5); with write-through stores 13 us for 21 tiles.  The kernel
+    // boundary does it once: k_join_set behind this launch sets the group's word.)
+    TraceScope trace(128 + row_lo);
+    // start_word (may be nullptr): this launch has started, i.e. the SYRK in front of it on this stream has drained -- the masked
+    // statistics stream lets its next SYRK onto the chip at that moment (k_join_wait), not earlier (it would share the CUs with
+    // the SYRK this launch sums up) and not much later (the CUs it is sized for would be taken by the chains' workgroups)
+    if (start_word && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        __hip_atomic_store(start_word, start_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int I = row_lo + blockIdx.x, J = blockIdx.y, z = blockIdx.z;
     const int tid = threadIdx.x;
-    if (I >= J) {
-        const int t = I * (I + 1) / 2 + J;
-        const double* base = slabs + (size_t)t * (TB * TB) + z * 4 * TB + tid;
+    if (J < T && I >= J) {
+        const int il = tid >> 6, j = tid & 63;
+        const int t = I * (I + 1) / 2 + J - tile0;
+        const double* base = slabs + (size_t)t * (TB * TB) + (z * 4 + il) * TB + j;
         const size_t cstride = (size_t)ntiles * (TB * TB);
         double s = 0.0;
         int c = 0;
+        for (; c + 24 <= nchunks; c += 24) {                 // (24 loads in flight: the groups of the overlapped sweep have 48 - 72 chunks)
+            double v[24];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) v[u] = base[(size_t)(c + u) * cstride];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) s += v[u];          // fixed summation order: chunk 0, 1, 2, ...
+        }
         for (; c + 12 <= nchunks; c += 12) {
             double v[12];
 #pragma unroll
             for (int u = 0; u < 12; ++u) v[u] = base[(size_t)(c + u) * cstride];
 #pragma unroll
-            for (int u = 0; u < 12; ++u) s += v[u];          // fixed summation order: chunk 0, 1, 2, ...
+            for (int u = 0; u < 12; ++u) s += v[u];
         }
         for (; c + 4 <= nchunks; c += 4) {
             double v[4];
@@ -519,44 +602,37 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
             for (int u = 0; u < 4; ++u) s += v[u];
         }
         for (; c < nchunks; ++c) s += base[(size_t)c * cstride];
-        tile[(tid >> 6) * LT + (tid & 63)] = s;              // tid = i_local * 64 + j
-        __syncthreads();
-        {
-            const int j = tid >> 2, il = tid & 3;            // 4 consecutive i per column j
-            stats[(size_t)(J * TB + j) * Mp + I * TB + z * 4 + il] = tile[il * LT + j];
-        }
-        if (I != J) {
-            const int il = tid >> 6, j = tid & 63;           // mirror: 64 consecutive j per row i
-            stats[(size_t)(I * TB + z * 4 + il) * Mp + J * TB + j] = tile[il * LT + j];
-        }
+        stats[(size_t)(J * TB + j) * Mp + I * TB + z * 4 + il] = s;
+        if (I != J) stats[(size_t)(I * TB + z * 4 + il) * Mp + J * TB + j] = s;
     }
-    // B = sum of the per-block partials: blocks (I, 0, z) take outputs o = z, z + 16, ...; 4 threads per entry walk
-    // the partials with a stride of 4 (16 independent loads in flight), combined in a fixed order through LDS
-    if (J == 0) {
-        __shared__ double red[4 * TB];
+    // B = sum of the per-block partials: the blocks of the extra grid row take the (row block, output) pairs; 4 adjacent lanes
+    // per entry walk the partials with a stride of 4 (16 independent loads in flight) and are combined in a fixed order
+    if (do_b && J == T) {
         double* B = stats + (size_t)Mp * Mp;
-        const int m = tid & 63, part = tid >> 6;
-        for (int o = z; o < d_out; o += 16) {
+        const int m = tid >> 2, part = tid & 3;
+        const int bid = blockIdx.x * 16 + z, nb = gridDim.x * 16;
+        for (int pair = bid; pair < T * d_out; pair += nb) {
+            const int Ib = pair % T, o = pair / T;
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             int b = part;
             for (; b + 60 < nblk; b += 64) {
                 double v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + I * TB + m];
+                for (int u = 0; u < 16; ++u) v[u] = bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + Ib * TB + m];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) acc[u & 3] += v[u];
             }
             for (; b + 12 < nblk; b += 16) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] += bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + I * TB + m];
+                for (int u = 0; u < 4; ++u) acc[u] += bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + Ib * TB + m];
             }
-            for (; b < nblk; b += 4) acc[0] += bpart[((size_t)b * d_out + o) * Mp + I * TB + m];
-            __syncthreads();
-            red[part * TB + m] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            __syncthreads();
-            if (part == 0) B[(size_t)o * Mp + I * TB + m] = (red[m] + red[TB + m]) + (red[2 * TB + m] + red[3 * TB + m]);
+            for (; b < nblk; b += 4) acc[0] += bpart[((size_t)b * d_out + o) * Mp + Ib * TB + m];
+            double v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            v += __shfl_xor(v, 1);                           // (part 0 + part 1), (part 2 + part 3)
+            v += __shfl_xor(v, 2);
+            if (part == 0) B[(size_t)o * Mp + Ib * TB + m] = v;
         }
-        if (I == 0 && z == 0)
+        if (bid == 0)
             for (int e = tid; e < nscal; e += 256) B[(size_t)Mp * d_out + e] = data_scalars[e];
     }
     if (info_reset && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *info_reset = 0;
@@ -1054,6 +1130,14 @@ __device__ __forceinline__ void tile_g2r(TileRegs& t, const double* __restrict__
 // Lambda = Lambda0 + W (x) Psi2 in index-reversed order, evaluated on the fly: step 0 of the Lambda factorisation reads its
 // tiles through this instead of from memory, so that no separate k_form_lambda launch (and no round trip of Lambda through
 // HBM) sits in front of the chain.  stats == nullptr: the matrix is already in A.
+// Overlapped sweep (sgp_api.hip, sweep_overlapped): the statistics arrive in GROUPS of tile columns of P Lambda P (= tile rows of
+// Psi2, last rows first) while the factorisation is already running.  Tile column c is formed -- added into the matrix -- by the
+// workgroups of step form_step[c] <= c, which first wait (bounded) until col_words[col_group[c]] >= col_need (the sweep's number,
+// written by a k_join_set behind the group's k_assemble);
+// until then the tile in A holds only the (negative) rank-64 updates that steps 1 .. collected for it.  col_words == nullptr:
+// the statistics are complete before step 0, which forms every tile (form_step all zero).
+constexpr int LAM_MAX_GROUPS = 8;
+constexpr int LAM_MAX_COLS = 64;            // CU_MAXQ / TB
 struct LamForm {
     const double* stats;
     const double* Lambda0;
@@ -1062,17 +1146,28 @@ struct LamForm {
     const Params* P;
     int M, Mp, d_out, Q, prior_form;
     int64_t* stamps;
+    const long long* col_words;
+    long long col_need;
+    unsigned char form_step[LAM_MAX_COLS], col_group[LAM_MAX_COLS];      // col_group 0xff: in stream order, nothing to wait for
+    int spin_limit;
+    int* sync_status;
 };
 // Straight-line on purpose, with the two uniform choices (dense prior? several outputs?) made OUTSIDE the 16-entry loop:
 // any branch inside it splits the loop body into basic blocks, the compiler then waits for each load before the next is
 // issued, and step 0 was measured 13-15 us longer than a step that just loads its tiles.
-template <bool DENSE, bool MULTI>
+// BYPASS: the workgroup had to wait for its statistics (they were written while this kernel was already running): read them
+// past this XCD's L2, which was invalidated at kernel start, i.e. possibly before the producer's write-back
+__device__ __forceinline__ double load_agent(const double* p) {
+    return __hip_atomic_load((const __attribute__((address_space(1))) double*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool DENSE, bool MULTI, bool BYPASS = false>
 __device__ __forceinline__ double lambda_entry(const LamForm& f, int gi, int gj, int Qp, double prior_iso, double w00) {
     const bool inside = gi < f.Q && gj < f.Q;
     const int si = inside ? gi : 0, sj = inside ? gj : 0;              // safe indices for the pad entries
     int a = 0, i = si, b = 0, j = sj;
     if constexpr (MULTI) { a = si / f.M; i = si % f.M; b = sj / f.M; j = sj % f.M; }
-    const double psi = f.stats[(size_t)j * f.Mp + i];
+    double psi;
+    if constexpr (BYPASS) psi = load_agent(f.stats + (size_t)j * f.Mp + i); else psi = f.stats[(size_t)j * f.Mp + i];
     const double diag = (gi == gj) ? 1.0 : 0.0;
     double prior, w;
     if constexpr (DENSE) prior = f.Lambda0[(size_t)sj * Qp + si]; else prior = diag * prior_iso;
@@ -1083,19 +1178,23 @@ __device__ __forceinline__ double lambda_entry(const LamForm& f, int gi, int gj,
     return fma(m * w, psi, fma(m, prior, (1.0 - m) * diag));
 }
 // tile (row0.., col0..) of P Lambda P: entry (r, c) is Lambda[Qp-1-r][Qp-1-c]
-template <bool DENSE, bool MULTI>
+template <bool DENSE, bool MULTI, bool BYPASS>
 __device__ __forceinline__ void tile_form_r_impl(TileRegs& t, const LamForm& f, int Qp, int row0, int col0) {
-    const double prior_iso = f.P->prior_iso, w00 = f.P->W[0];
+    const double prior_iso = BYPASS ? load_agent(&f.P->prior_iso) : f.P->prior_iso, w00 = BYPASS ? load_agent(&f.P->W[0]) : f.P->W[0];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int e = (threadIdx.x & 255) + 256 * (u >> 1), c = e >> 5, r = (e & 31) * 2 + (u & 1);      // the layout of tile_g2r
-        t.v[u] = lambda_entry<DENSE, MULTI>(f, Qp - 1 - (row0 + r), Qp - 1 - (col0 + c), Qp, prior_iso, w00);
+        t.v[u] = lambda_entry<DENSE, MULTI, BYPASS>(f, Qp - 1 - (row0 + r), Qp - 1 - (col0 + c), Qp, prior_iso, w00);
     }
 }
-__device__ __forceinline__ void tile_form_r(TileRegs& t, const LamForm& f, int Qp, int row0, int col0) {
+__device__ __forceinline__ void tile_form_r(TileRegs& t, const LamForm& f, int Qp, int row0, int col0, bool bypass = false) {
     const bool dense = f.prior_form == 1, multi = f.d_out > 1;
-    if (dense) { if (multi) tile_form_r_impl<true, true>(t, f, Qp, row0, col0); else tile_form_r_impl<true, false>(t, f, Qp, row0, col0); }
-    else       { if (multi) tile_form_r_impl<false, true>(t, f, Qp, row0, col0); else tile_form_r_impl<false, false>(t, f, Qp, row0, col0); }
+    if (bypass && !multi) {                 // (the overlapped sweep is UniSGP only)
+        if (dense) tile_form_r_impl<true, false, true>(t, f, Qp, row0, col0); else tile_form_r_impl<false, false, true>(t, f, Qp, row0, col0);
+        return;
+    }
+    if (dense) { if (multi) tile_form_r_impl<true, true, false>(t, f, Qp, row0, col0); else tile_form_r_impl<true, false, false>(t, f, Qp, row0, col0); }
+    else       { if (multi) tile_form_r_impl<false, true, false>(t, f, Qp, row0, col0); else tile_form_r_impl<false, false, false>(t, f, Qp, row0, col0); }
 }
 __device__ __forceinline__ void tile_r2s(double* S, const TileRegs& t) {
 #pragma unroll
@@ -1108,6 +1207,25 @@ __device__ __forceinline__ void tile_g2s(double* S, const double* __restrict__ A
     TileRegs t;
     tile_g2r(t, A, ld, row0, col0);
     tile_r2s(S, t);
+}
+// The tile a Cholesky step starts from: what A holds for it (load_old) plus, in the step that forms it, Lambda's tile
+// (do_form) -- see LamForm.  Neither: the tile has not received anything yet (zeros).
+__device__ __forceinline__ void tile_fetch(TileRegs& t, bool do_form, bool load_old, const double* __restrict__ A, const LamForm& f,
+                                           int ld, int row0, int col0, bool bypass) {
+    if (do_form) {
+        tile_form_r(t, f, ld, row0, col0, bypass);
+        if (load_old) {
+            TileRegs o;
+            tile_g2r(o, A, ld, row0, col0);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t.v[u] += o.v[u];
+        }
+    } else if (load_old) {
+        tile_g2r(t, A, ld, row0, col0);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t.v[u] = 0.0;
+    }
 }
 __device__ __forceinline__ void tile_s2g(const double* S, double* __restrict__ A, size_t ld, int row0, int col0) {
     for (int e = threadIdx.x & 255; e < TB * TB; e += 256) {
@@ -1331,17 +1449,34 @@ __device__ __forceinline__ void tvec_role(const double* __restrict__ L, const do
 }
 
 // xi = xi0 + vec(B W) of the Lambda chain's step 0 (one workgroup, 256 threads)
-__device__ __forceinline__ void form_xi(const LamForm& form, int ld, int tid) {
+__device__ __forceinline__ void form_xi(const LamForm& form, int ld, int tid, bool bypass = false) {
     const double* B = form.stats + (size_t)form.Mp * form.Mp;
     for (int gi = tid; gi < ld; gi += 256) {
         double v = 0.0;
         if (gi < form.Q) {
             const int aa = gi / form.M, i = gi % form.M;
             v = (form.prior_form == 1) ? form.xi0[gi] : 0.0;
-            for (int e = 0; e < form.d_out; ++e) v = fma(B[(size_t)e * form.Mp + i], form.P->W[e + aa * form.d_out], v);
+            for (int e = 0; e < form.d_out; ++e) {
+                const double* bp = B + (size_t)e * form.Mp + i;
+                const double* wp = &form.P->W[e + aa * form.d_out];
+                v = fma(bypass ? load_agent(bp) : *bp, bypass ? load_agent(wp) : *wp, v);
+            }
         }
         form.xi[gi] = v;
     }
+}
+// wait (every wave's lane 0 polls; bounded) until tile-column group g of the statistics is complete; returns whether the
+// wave had to wait -- its reads of the statistics then go past the L2 (see load_agent)
+__device__ __forceinline__ bool wait_stat_group(const LamForm& f, int g) {
+    int late = 0;
+    if ((threadIdx.x & 63) == 0) {
+        const long long* w = f.col_words + g;
+        if (!join_ready(w, f.col_need)) {
+            late = 1;
+            spin_until(w, f.col_need, f.spin_limit, f.sync_status, SYNC_LATE_COLUMN);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(late) != 0;
 }
 
 // Diagnostics (build with -DSGP_STEP_TRACE): 100 MHz stamps of the workgroup that owns tile (j + 1, j) of the Lambda chain,
@@ -1368,6 +1503,7 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     __shared__ __attribute__((aligned(16))) double tiles[2 * TB * LT];
     __shared__ double dprep[4 * DPB];                     // the diagonal tile's 16 x 16 blocks as solve16 reads them
     __shared__ double rinv[TB];
+    TraceScope trace((form.stats ? 16 : 40) + j);
     const bool xgroup = threadIdx.x >= 256;               // the solve group
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     {
@@ -1401,6 +1537,24 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     acc_zero(accX);
     const bool panel = (b == 0);
     if (xgroup && !(panel && a != 0)) return;
+    // What this workgroup's tile column starts from (see LamForm): formed here (do_form), already in A (load_old), or neither yet
+    const bool lam = form.stats != nullptr;
+    const int fstep = lam ? (int)form.form_step[j + b] : -1;
+    const bool do_form = lam && fstep == j;
+    const bool load_old = !lam || fstep < j || j >= 2;
+    const bool xi_duty = lam && j == 0 && blockIdx.x == gridDim.x - 1;     // (step 0 has no extra workgroups)
+    if (!lam && j == 0 && !panel) return;       // step 0 of a matrix that is already in A: no update to apply to the trailing tiles
+    bool bypass = false;
+    if (lam && form.col_words) {
+        if (xi_duty && form.col_group[0] != 0xff) bypass = wait_stat_group(form, form.col_group[0]);   // B and the scalars arrive with the first group
+        if (do_form && form.col_group[j + b] != 0xff) bypass = wait_stat_group(form, form.col_group[j + b]) || bypass;
+        if (j == 0 && !do_form) {
+            // step 0 of an overlapped sweep: this tile column has no statistics yet and there is no update to collect
+            if (xi_duty) form_xi(form, ld, tid, bypass);
+            return;
+        }
+        if (blockIdx.x == 0 && !xgroup) trace_mark(200 + j);
+    }
     // scratch: tile 0 parks L_jj; tiles 1 and 2 (alternating with the step's parity: a late workgroup of step j + 1 may
     // still read one while step j + 1's owner of tile (j + 2, j + 1) writes the other) carry the next diagonal tile's
     // update L_{j+1,j} L_{j+1,j}^T from the workgroup that solved L_{j+1,j} to the next launch (trsm_tile_next)
@@ -1412,8 +1566,7 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     }
     // the tiles this block updates are fetched into registers now, so that their latency hides behind the MFMA phase
     TileRegs rX, rS, rD;
-    const bool form_now = (j == 0 && form.stats);
-    if (form_now) stamp_enter(form.stamps);
+    if (lam && j == 0) stamp_enter(form.stamps);
     STEP_TRACE(0);
     if (panel && a != 0) {
         // ---- a block of the panel column below the diagonal: two groups of four waves ----
@@ -1421,14 +1574,13 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             // factoring group: the diagonal tile A_jj (minus the rank-64 update the previous launch formed), factored here
             // redundantly -- no inter-block hand-off -- while the solve group works on the block's own tile
             __builtin_amdgcn_s_setprio(3);                // (the latency-bound group goes first where both want the same SIMD)
-            if (form_now) tile_form_r(rS, form, ld, j0, j0);
-            else tile_g2r(rS, A, ld, j0, j0);
+            tile_fetch(rS, do_form, load_old, A, form, ld, j0, j0, bypass);
             if (j > 0) {
                 tile_g2r(rD, Dn_in, TB, 0, 0);
 #pragma unroll
                 for (int u = 0; u < 16; ++u) rS.v[u] -= rD.v[u];
             }
-            if (form_now && blockIdx.x == gridDim.x - 1) form_xi(form, ld, tid);
+            if (xi_duty) form_xi(form, ld, tid, bypass);
             tile_r2s(S, rS);
             STEP_TRACE(1);
             __syncthreads();
@@ -1440,8 +1592,7 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         // solve group: the own tile (j + a, j).  Its rank-64 update L_{i,j-1} L_{j,j-1}^T takes the first four of the
         // factoring group's eight barrier intervals (one 16-deep K-slice each, 16 MFMAs per wave), the triangular solve
         // against L_jj the other four: column block cb of L_jj is final two intervals before it is needed here.
-        if (form_now) tile_form_r(rX, form, ld, i0, j0);
-        else tile_g2r(rX, A, ld, i0, j0);
+        tile_fetch(rX, do_form, load_old, A, form, ld, i0, j0, bypass);
         if (j > 0) {
             const int p0 = (j - 1) * TB;
             load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
@@ -1486,13 +1637,10 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         STEP_TRACE(12);
         return;
     }
-    if (form_now) {
-        // step 0 of the Lambda chain forms its tiles instead of loading them; the last workgroup also writes xi
-        if (!panel) tile_form_r(rX, form, ld, i0, k0);
-        else tile_form_r(rS, form, ld, j0, j0);
-        if (blockIdx.x == gridDim.x - 1) form_xi(form, ld, tid);
-    } else if (!panel) tile_g2r(rX, A, ld, i0, k0);
-    else tile_g2r(rS, A, ld, j0, j0);
+    // (the Lambda chain forms its tiles instead of loading them; step 0's last workgroup also writes xi)
+    if (!panel) tile_fetch(rX, do_form, load_old, A, form, ld, i0, k0, bypass);
+    else tile_fetch(rS, do_form, load_old, A, form, ld, j0, j0, bypass);
+    if (xi_duty) form_xi(form, ld, tid, bypass);
     if (panel && j > 0) tile_g2r(rD, Dn_in, TB, 0, 0);    // the diagonal tile's rank-64 update, formed by the previous launch
     if (!panel) {
         if (j > 0) {
@@ -1555,16 +1703,12 @@ struct UvArgs {
     // the streams with an event
     const long long* join;
     long long join_need;
+    int spin_limit;          // polls before a late join gives up (its trace shares become NaN and SYNC_LATE_KINV is set)
+    int* sync_status;
 };
-constexpr int JOIN_SPIN_LIMIT = 1 << 21;    // polls of >= ~0.5 us before a waiter gives up (its trace shares become NaN)
-__device__ __forceinline__ bool join_ready(const long long* w, long long need) {
-    return __hip_atomic_load((const __attribute__((address_space(1))) long long*)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
-}
-__global__ void k_join_wait(const long long* w, long long need) {           // bounded, like every wait on these words
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int it = 0;
-        while (!join_ready(w, need) && ++it < JOIN_SPIN_LIMIT) __builtin_amdgcn_s_sleep(8);
-    }
+__global__ void k_join_wait(const long long* w, long long need, int spin_limit, int* sync_status, int bit) {
+    TraceScope trace(8);
+    if (threadIdx.x == 0 && blockIdx.x == 0) spin_until(w, need, spin_limit, sync_status, bit);
 }
 __global__ void k_join_set(long long* w, long long v) {
     if (threadIdx.x == 0 && blockIdx.x == 0)
@@ -1627,6 +1771,7 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
     __shared__ double As[64 * PS32];
     __shared__ double Bs[64 * PS32];
     __shared__ double tred[4];
+    TraceScope trace(mode == 0 ? (mu ? 5 : 6) : 255);
     if (mode == 0 && uv.Wp) {                                            // extra workgroups: pass 2 of Uv (uv_cols_role)
         const int ngemm = Tn * (Tn + 1) / 2 * 4;
         if ((int)blockIdx.x >= ngemm) {
@@ -1718,9 +1863,7 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
             if (Psi2) {
                 tsum = fma(rv[0], p0.x, fma(rv[1], p0.y, fma(rv[2], p1.x, rv[3] * p1.y)));
                 if (kinv_late) {                                         // the K_uu chain was still running at entry
-                    int it = 0;
-                    while (!join_ready(uv.join, uv.join_need) && ++it < JOIN_SPIN_LIMIT) __builtin_amdgcn_s_sleep(8);
-                    if (it < JOIN_SPIN_LIMIT) {
+                    if (spin_until(uv.join, uv.join_need, uv.spin_limit, uv.sync_status, SYNC_LATE_KINV)) {
                         // (bypassing this XCD's L2: lines of the previous sweep's K_uu^-1 may sit there -- the kernel-start
                         // invalidate came before the chain's write-back)
                         const __attribute__((address_space(1))) double* kq = (const __attribute__((address_space(1))) double*)(Kinv + offA);
@@ -1802,6 +1945,7 @@ __global__ void __launch_bounds__(256) k_trmv_mu_scan(const double* __restrict__
                                                       double* __restrict__ ck, double* __restrict__ ak,
                                                       double* __restrict__ uvpart, int Qp) {
     __shared__ double ts[CU_MAXQ];
+    TraceScope trace(4);
     const int lane = threadIdx.x & 63;
     // mat-vec workgroups: the first eight entries of the wave's column of W' are requested before the LDS copy of t is
     // waited for -- one memory round trip for both instead of two (this launch sits alone on the critical path)
@@ -1924,6 +2068,7 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
     __shared__ double red[4];
     __shared__ double redn[4 * 5];
     __shared__ double tr[TRACE_SLOTS];
+    TraceScope trace(7);
     stamp_enter(stamps);
     const double* B = stats + (size_t)Mp * Mp;
     const double* sc = B + (size_t)Mp * d_out;
@@ -2403,14 +2548,12 @@ __global__ void __launch_bounds__(256) k_theta_grad_finish(const double* __restr
                                                            const double* __restrict__ part_uu, int n_uu,
                                                            const double* __restrict__ stats_scal, const Params* __restrict__ P,
                                                            double* __restrict__ grad, int D, int n_ell,
-                                                           const long long* wait_word, long long wait_need) {
+                                                           const long long* wait_word, long long wait_need, int spin_limit,
+                                                           int* sync_status) {
     // wait_word (may be nullptr): the K_uu half of the gradient (part_uu) was formed on the other stream; it is complete when
-    // the word reaches wait_need (bounded wait; the partials are then read past this XCD's L2)
+    // the word reaches wait_need (bounded wait, SYNC_LATE_GRAD_JOIN if it gives up; the partials are then read past this XCD's L2)
     if (wait_word) {
-        if (threadIdx.x == 0) {
-            int it = 0;
-            while (!join_ready(wait_word, wait_need) && ++it < JOIN_SPIN_LIMIT) __builtin_amdgcn_s_sleep(8);
-        }
+        if (threadIdx.x == 0) spin_until(wait_word, wait_need, spin_limit, sync_status, SYNC_LATE_GRAD_JOIN);
         __syncthreads();
     }
     // thread t sums the partial blocks t, t + 256, ... for ALL slots at once (independent loads; a first version walked the
@@ -2489,11 +2632,18 @@ __device__ __forceinline__ double softplus_dev(double x) { return fmax(x, 0.0) +
 // One thread: Flux's AdaMax (m = b1 m + (1 - b1) g; u = max(b2 u, |g|); theta -= eta / (1 - b1^t) m / (u + eps)) on the raw
 // parameters with the chain rule through softplus (d softplus = sigmoid), then the kernel parameters of the NEXT sweep
 // written where k_prep_xu reads them.  `update` = 0 only writes the parameters (first step of a run).
+// `update`: 1 = optimiser step (skipped and counted if a factorisation of this minibatch failed or a device-word wait gave up),
+// 2 = status only (a minibatch without a learning step: a failure is still counted), 0 = only write the parameters (first step
+// of a run).
 __global__ void k_train_adamax(TrainState* __restrict__ st, const double* __restrict__ grad, const double* __restrict__ out,
-                               Params* __restrict__ src, int D, int n_ell, int update) {
+                               Params* __restrict__ src, int D, int n_ell, int update, const int* __restrict__ sync_status) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (update) {
-        const bool ok = out[3] == 0.0 && out[4] == 0.0;           // SGP_R_INFO_KUU, SGP_R_INFO_LAMBDA
+        const bool ok = out[3] == 0.0 && out[4] == 0.0 && (!sync_status || *sync_status == 0);   // SGP_R_INFO_KUU, SGP_R_INFO_LAMBDA
+        if (update == 2) {
+            if (!ok) st->rejected += 1.0;
+            return;
+        }
         if (ok) {
             for (int i = 0; i <= n_ell; ++i) {
                 const double th = st->theta[i];

@@ -32,15 +32,19 @@ class SGPDevice:
 
     def __init__(self, n_max: int, m: int, d: int, d_out: int = 1, device: int = 0, use_graph: bool = False,
                  keep_kuf: bool = False, persistent_chain: bool = False):
-        self._lib = _lib.load()
+        # (the round-2 persistent factorisation launch lives in a variant library of the same ABI, see _build.VARIANTS)
+        self._lib = _lib.load(variant="chain" if persistent_chain else None)
         self._h = C.c_void_p()
         flags = ((_lib.SGP_FLAG_GRAPH if use_graph else 0) | (_lib.SGP_FLAG_KEEP_KUF if keep_kuf else 0)
                  | (_lib.SGP_FLAG_PERSISTENT_CHAIN if persistent_chain else 0))
         cfg = _lib.Config(n_max=int(n_max), m=int(m), d=int(d), d_out=int(d_out), device=int(device), flags=flags)
-        check(self._lib.sgp_create(C.byref(cfg), C.byref(self._h)), None, "sgp_create")
+        check(self._lib.sgp_create(C.byref(cfg), C.byref(self._h)), None, "sgp_create", lib=self._lib)
         self.n_max, self.M, self.D, self.d_out, self.device = int(n_max), int(m), int(d), int(d_out), int(device)
         self.Q = self.M * self.d_out
         self.n = 0
+
+    def _check(self, rc: int, what: str):
+        check(rc, self._h, what, lib=self._lib)
 
     # ---- lifetime
     def close(self):
@@ -63,7 +67,7 @@ class SGPDevice:
     # ---- inputs
     def set_inducing(self, Xu):
         Xu = as_f64(np.reshape(Xu, (self.M, self.D)))
-        check(self._lib.sgp_set_inducing(self._h, ptr(Xu)), self._h, "sgp_set_inducing")
+        self._check(self._lib.sgp_set_inducing(self._h, ptr(Xu)), "sgp_set_inducing")
 
     def set_data(self, X, y_mean, y_var=None, weights=None, n_nodes: Optional[float] = None):
         X = as_f64(np.reshape(X, (-1, self.D)))
@@ -73,53 +77,52 @@ class SGPDevice:
         y_cm = as_f64(y.T)
         yv = None if y_var is None else as_f64(np.reshape(y_var, (n,)))
         w = None if weights is None else as_f64(np.reshape(weights, (n,)))
-        check(self._lib.sgp_set_data(self._h, ptr(X), ptr(y_cm), ptr(yv), ptr(w), n,
-                                     float(-1.0 if n_nodes is None else n_nodes)), self._h, "sgp_set_data")
+        self._check(self._lib.sgp_set_data(self._h, ptr(X), ptr(y_cm), ptr(yv), ptr(w), n,
+                                     float(-1.0 if n_nodes is None else n_nodes)), "sgp_set_data")
         self.n = n
 
     def set_output_cov_sum(self, S):
         S = as_f64(np.reshape(S, (self.d_out, self.d_out)))
-        check(self._lib.sgp_set_output_cov_sum(self._h, ptr(as_f64(S.T))), self._h, "sgp_set_output_cov_sum")
+        self._check(self._lib.sgp_set_output_cov_sum(self._h, ptr(as_f64(S.T))), "sgp_set_output_cov_sum")
 
     def set_kernel(self, sigma2: float, ell, jitter: float = 0.0):
         ell = as_f64(np.atleast_1d(ell))
-        check(self._lib.sgp_set_kernel(self._h, float(sigma2), ptr(ell), int(ell.size), float(jitter)), self._h,
-              "sgp_set_kernel")
+        self._check(self._lib.sgp_set_kernel(self._h, float(sigma2), ptr(ell), int(ell.size), float(jitter)), "sgp_set_kernel")
         self._n_ell = int(ell.size)          # the C side writes 1 + n_ell gradient entries (sgp_theta_objective)
 
     def set_prior_meancov(self, mu0, Sigma0):
         mu0 = as_f64(np.reshape(mu0, (self.Q,)))
         S0 = as_f64(np.reshape(Sigma0, (self.Q, self.Q)))
-        check(self._lib.sgp_set_prior(self._h, ptr(mu0), ptr(S0), 0), self._h, "sgp_set_prior")
+        self._check(self._lib.sgp_set_prior(self._h, ptr(mu0), ptr(S0), 0), "sgp_set_prior")
 
     def set_prior_precision(self, xi0, Lambda0):
         xi0 = as_f64(np.reshape(xi0, (self.Q,)))
         L0 = as_f64(np.reshape(Lambda0, (self.Q, self.Q)))
-        check(self._lib.sgp_set_prior(self._h, ptr(xi0), ptr(L0), 1), self._h, "sgp_set_prior")
+        self._check(self._lib.sgp_set_prior(self._h, ptr(xi0), ptr(L0), 1), "sgp_set_prior")
 
     def set_prior_isotropic(self, variance: float):
         v = as_f64([variance])
-        check(self._lib.sgp_set_prior(self._h, None, ptr(v), 2), self._h, "sgp_set_prior")
+        self._check(self._lib.sgp_set_prior(self._h, None, ptr(v), 2), "sgp_set_prior")
 
     def set_noise(self, W, E_log_w: Optional[float] = None):
         W = as_f64(np.reshape(W, (self.d_out, self.d_out)))
         if E_log_w is None:
             E_log_w = float(np.log(W[0, 0])) if self.d_out == 1 else float(np.linalg.slogdet(W)[1])
-        check(self._lib.sgp_set_noise(self._h, ptr(as_f64(W.T)), float(E_log_w)), self._h, "sgp_set_noise")
+        self._check(self._lib.sgp_set_noise(self._h, ptr(as_f64(W.T)), float(E_log_w)), "sgp_set_noise")
 
     # ---- sweep
     def sweep_local(self, stream: int = 0):
-        check(self._lib.sgp_sweep_local(self._h, C.c_void_p(stream)), self._h, "sgp_sweep_local")
+        self._check(self._lib.sgp_sweep_local(self._h, C.c_void_p(stream)), "sgp_sweep_local")
 
     def sweep_finish(self, stream: int = 0):
-        check(self._lib.sgp_sweep_finish(self._h, C.c_void_p(stream)), self._h, "sgp_sweep_finish")
+        self._check(self._lib.sgp_sweep_finish(self._h, C.c_void_p(stream)), "sgp_sweep_finish")
 
     def set_allreduce(self, fn):
         """Install (fn = None: remove) the multi-GPU exchange step of `sweep`: fn(stats_dev_ptr, count, stream) must enqueue an
         in-place sum-all-reduce of `count` doubles on `stream` (include/sgp_hip.h, sgp_set_allreduce)."""
         if fn is None:
             self._allreduce_cb = None
-            check(self._lib.sgp_set_allreduce(self._h, _lib.ALLREDUCE_FN(0), None), self._h, "sgp_set_allreduce")
+            self._check(self._lib.sgp_set_allreduce(self._h, _lib.ALLREDUCE_FN(0), None), "sgp_set_allreduce")
             return
 
         def hook(ctx, buf, count, stream):
@@ -131,57 +134,57 @@ class SGPDevice:
                 traceback.print_exc()
                 return 1
         self._allreduce_cb = _lib.ALLREDUCE_FN(hook)        # keep the trampoline alive as long as it is installed
-        check(self._lib.sgp_set_allreduce(self._h, self._allreduce_cb, None), self._h, "sgp_set_allreduce")
+        self._check(self._lib.sgp_set_allreduce(self._h, self._allreduce_cb, None), "sgp_set_allreduce")
 
     def use_rccl(self, comm_ptr: int):
         """All-reduce with RCCL on an ncclComm_t the host program created (sgp_use_rccl)."""
-        check(self._lib.sgp_use_rccl(self._h, C.c_void_p(comm_ptr)), self._h, "sgp_use_rccl")
+        self._check(self._lib.sgp_use_rccl(self._h, C.c_void_p(comm_ptr)), "sgp_use_rccl")
 
     def sweep(self, stream: int = 0):
-        check(self._lib.sgp_sweep(self._h, C.c_void_p(stream)), self._h, "sgp_sweep")
+        self._check(self._lib.sgp_sweep(self._h, C.c_void_p(stream)), "sgp_sweep")
 
     def stats_layout(self):
         p, cnt, mp = C.c_void_p(), C.c_int64(), C.c_int32()
-        check(self._lib.sgp_stats_layout(self._h, C.byref(p), C.byref(cnt), C.byref(mp)), self._h, "sgp_stats_layout")
+        self._check(self._lib.sgp_stats_layout(self._h, C.byref(p), C.byref(cnt), C.byref(mp)), "sgp_stats_layout")
         return p.value, cnt.value, mp.value
 
     def bind_stats(self, dev_ptr: int):
-        check(self._lib.sgp_bind_stats(self._h, C.c_void_p(dev_ptr)), self._h, "sgp_bind_stats")
+        self._check(self._lib.sgp_bind_stats(self._h, C.c_void_p(dev_ptr)), "sgp_bind_stats")
 
     # ---- results
     def posterior(self, want_cov: bool = True, want_uv: bool = True):
         mu = np.empty(self.Q)
         Sig = np.empty((self.Q, self.Q)) if want_cov else None
         Uv = np.empty((self.Q, self.Q)) if want_uv else None
-        check(self._lib.sgp_get_posterior(self._h, ptr(mu), ptr(Sig), ptr(Uv)), self._h, "sgp_get_posterior")
+        self._check(self._lib.sgp_get_posterior(self._h, ptr(mu), ptr(Sig), ptr(Uv)), "sgp_get_posterior")
         # column-major upper-triangular Uv arrives as the C-order transpose
         return mu, Sig, (None if Uv is None else Uv.T.copy())
 
     def scalars(self) -> SweepScalars:
         out = np.empty(_lib.SGP_R_COUNT)
-        check(self._lib.sgp_get_scalars(self._h, ptr(out)), self._h, "sgp_get_scalars")
+        self._check(self._lib.sgp_get_scalars(self._h, ptr(out)), "sgp_get_scalars")
         return SweepScalars(out[0], out[1], out[2], int(out[3]), int(out[4]), out[6], out[7])
 
     def stats(self):
         Psi2 = np.empty((self.M, self.M))
         B = np.empty((self.d_out, self.M))
         sc = np.empty(_lib.SGP_S_COUNT)
-        check(self._lib.sgp_get_stats(self._h, ptr(Psi2), ptr(B), ptr(sc)), self._h, "sgp_get_stats")
+        self._check(self._lib.sgp_get_stats(self._h, ptr(Psi2), ptr(B), ptr(sc)), "sgp_get_stats")
         return Psi2, B.T.copy(), sc
 
     def kuu_chol(self):
         L = np.empty((self.M, self.M))
-        check(self._lib.sgp_get_kuu_chol(self._h, ptr(L)), self._h, "sgp_get_kuu_chol")
+        self._check(self._lib.sgp_get_kuu_chol(self._h, ptr(L)), "sgp_get_kuu_chol")
         return L.T.copy()          # column-major lower -> C-order array holding L
 
     def wishart_invscale(self):
         S = np.empty((self.d_out, self.d_out))
-        check(self._lib.sgp_get_wishart_invscale(self._h, ptr(S)), self._h, "sgp_get_wishart_invscale")
+        self._check(self._lib.sgp_get_wishart_invscale(self._h, ptr(S)), "sgp_get_wishart_invscale")
         return S.T.copy()
 
     def w_stats(self):
         I1, I2 = np.empty(self.n), np.empty(self.n)
-        check(self._lib.sgp_w_stats(self._h, ptr(I1), ptr(I2), None), self._h, "sgp_w_stats")
+        self._check(self._lib.sgp_w_stats(self._h, ptr(I1), ptr(I2), None), "sgp_w_stats")
         return I1, I2
 
     def predict(self, Xstar, mu_v=None):
@@ -189,18 +192,18 @@ class SGPDevice:
         ns = Xs.shape[0]
         out = np.empty((self.d_out, ns))
         mu = None if mu_v is None else as_f64(np.reshape(mu_v, (self.Q,)))
-        check(self._lib.sgp_predict(self._h, ptr(Xs), ns, ptr(mu), ptr(out)), self._h, "sgp_predict")
+        self._check(self._lib.sgp_predict(self._h, ptr(Xs), ns, ptr(mu), ptr(out)), "sgp_predict")
         return out[0] if self.d_out == 1 else out.T.copy()
 
     def set_posterior(self, mu_v, Uv):
         """Install an external q(v) (mean and Uv = chol(Sigma_v + mu mu').U) for the per-point outputs (`w_stats`)."""
         mu = as_f64(np.reshape(mu_v, (self.Q,)))
         U = as_f64(np.asarray(Uv, dtype=np.float64).reshape(self.Q, self.Q).T)     # row-major Uv^T == column-major Uv
-        check(self._lib.sgp_set_posterior(self._h, ptr(mu), ptr(U)), self._h, "sgp_set_posterior")
+        self._check(self._lib.sgp_set_posterior(self._h, ptr(mu), ptr(U)), "sgp_set_posterior")
 
     def carry_posterior(self, stream: int = 0):
         """prior <- posterior of the last sweep, on the device (the minibatch carry, regression_kin40k.ipynb:205-212)."""
-        check(self._lib.sgp_carry_posterior(self._h, C.c_void_p(stream)), self._h, "sgp_carry_posterior")
+        self._check(self._lib.sgp_carry_posterior(self._h, C.c_void_p(stream)), "sgp_carry_posterior")
 
     def theta_objective(self, want_grad: bool = False, n_ell: Optional[int] = None):
         """neg_log_backwardmess_fast at the current kernel with q(v) fixed at the last sweep; optionally its gradient
@@ -212,8 +215,7 @@ class SGPDevice:
         if n_ell is not None and have is not None and int(n_ell) != have:
             raise ValueError(f"theta_objective: n_ell={n_ell} but the kernel was set with {have} lengthscale(s)")
         g = np.empty(1 + have) if want_grad else None
-        check(self._lib.sgp_theta_objective(self._h, C.cast(C.byref(v), C.POINTER(C.c_double)), ptr(g)), self._h,
-              "sgp_theta_objective")
+        self._check(self._lib.sgp_theta_objective(self._h, C.cast(C.byref(v), C.POINTER(C.c_double)), ptr(g)), "sgp_theta_objective")
         return (v.value, g) if want_grad else v.value
 
     # -- device-paced minibatch training (sgp_train_*) -----------------------------------------------------------------
@@ -227,41 +229,54 @@ class SGPDevice:
             raise ValueError("train_begin: X and y disagree on the number of points")
         th = np.ascontiguousarray(np.asarray(theta_raw, dtype=np.float64).reshape(-1))
         n_ell = th.size - 1
-        check(self._lib.sgp_train_begin(self._h, ptr(X), ptr(y), len(y), ptr(th), n_ell, float(jitter), float(eta),
-                                        float(beta[0]), float(beta[1]), float(eps)), self._h, "sgp_train_begin")
+        self._check(self._lib.sgp_train_begin(self._h, ptr(X), ptr(y), len(y), ptr(th), n_ell, float(jitter), float(eta),
+                                        float(beta[0]), float(beta[1]), float(eps)), "sgp_train_begin")
         self._n_ell = n_ell
 
     def train_step(self, offset: int, n: int, learn: bool = True, reset_prior: bool = False):
         """One minibatch [offset, offset + n): sweep, carry, gradient, optimiser step.  Asynchronous.  reset_prior puts
         the isotropic prior of `set_prior_isotropic` back first (the per-epoch reset of the notebooks)."""
-        check(self._lib.sgp_train_step(self._h, int(offset), int(n), (1 if learn else 0) | (2 if reset_prior else 0)),
-              self._h, "sgp_train_step")
+        self._check(self._lib.sgp_train_step(self._h, int(offset), int(n), (1 if learn else 0) | (2 if reset_prior else 0)),
+                    "sgp_train_step")
 
     def train_end(self):
         """Wait for the queued steps; returns (theta_raw, optimiser steps taken, minibatches skipped)."""
         th = np.empty(1 + self._n_ell)
         counts = (C.c_int64 * 2)()
-        check(self._lib.sgp_train_end(self._h, ptr(th), counts), self._h, "sgp_train_end")
+        self._check(self._lib.sgp_train_end(self._h, ptr(th), counts), "sgp_train_end")
         return th, int(counts[0]), int(counts[1])
 
     def time_kernel(self, which: int, iters: int = 20, stream: int = 0) -> float:
         """Average launch duration (microseconds, HIP events) of the Gram or streaming-SYRK kernel."""
         v = C.c_double()
-        check(self._lib.sgp_time_kernel(self._h, int(which), int(iters), C.c_void_p(stream),
-                                        C.cast(C.byref(v), C.POINTER(C.c_double))), self._h, "sgp_time_kernel")
+        self._check(self._lib.sgp_time_kernel(self._h, int(which), int(iters), C.c_void_p(stream),
+                                        C.cast(C.byref(v), C.POINTER(C.c_double))), "sgp_time_kernel")
         return v.value
+
+    def overlap_plan(self):
+        """What the next `sweep()` will do (sgp_overlap_plan): [] = statistics first, then the Lambda chain; else one dict per
+        statistics group of the overlapped sweep."""
+        n = C.c_int32()
+        info = (C.c_int32 * 64)()
+        self._check(self._lib.sgp_overlap_plan(self._h, C.byref(n), info), "sgp_overlap_plan")
+        keys = ("col_begin", "col_end", "tiles", "chunks", "points_per_chunk", "masked", "cus", "form_step")
+        return [dict(zip(keys, info[8 * g:8 * g + 8])) for g in range(n.value)]
+
+    def time_group(self, g: int, iters: int = 20) -> float:
+        """Average duration (microseconds, HIP events on the group's own stream) of the SYRK launch of statistics group g."""
+        return self.time_kernel(_lib.SGP_TIME_GROUP0 + int(g), iters)
 
     def phase_totals(self, reset: bool = False):
         """(average microseconds per sweep for every phase slot, number of sweeps counted) since the last reset."""
         tot = (C.c_int64 * _lib.SGP_T_COUNT)()
         cnt = C.c_int64()
-        check(self._lib.sgp_get_phase_totals(self._h, tot, C.byref(cnt), int(reset)), self._h, "sgp_get_phase_totals")
+        self._check(self._lib.sgp_get_phase_totals(self._h, tot, C.byref(cnt), int(reset)), "sgp_get_phase_totals")
         n = max(cnt.value, 1)
         return np.array(tot[:], dtype=np.float64) / 100.0 / n, cnt.value
 
     def timestamps(self):
         out = (C.c_int64 * (2 * _lib.SGP_T_COUNT))()
-        check(self._lib.sgp_get_timestamps(self._h, out), self._h, "sgp_get_timestamps")
+        self._check(self._lib.sgp_get_timestamps(self._h, out), "sgp_get_timestamps")
         return np.array(out[:], dtype=np.int64).reshape(_lib.SGP_T_COUNT, 2)
 
 
@@ -278,21 +293,21 @@ def kernelmatrix(A, B, sigma2: float, ell, device: int = 0):
     return K.T.copy()
 
 
-def potrf(A, device: int = 0):
+def potrf(A, device: int = 0, variant=None):
     """Lower Cholesky factor on the device (fastcholesky(A).L)."""
-    lib = _lib.load()
+    lib = _lib.load(variant=variant)
     A = as_f64(A)
     n = A.shape[0]
     L = np.empty((n, n))
-    check(lib.sgp_potrf(device, ptr(as_f64(A.T)), n, ptr(L)), None, "sgp_potrf")
+    check(lib.sgp_potrf(device, ptr(as_f64(A.T)), n, ptr(L)), None, "sgp_potrf", lib=lib)
     return L.T.copy()
 
 
-def potri(A, device: int = 0):
+def potri(A, device: int = 0, variant=None):
     """Inverse of an SPD matrix through its Cholesky factor on the device (cholinv(A))."""
-    lib = _lib.load()
+    lib = _lib.load(variant=variant)
     A = as_f64(A)
     n = A.shape[0]
     out = np.empty((n, n))
-    check(lib.sgp_potri(device, ptr(as_f64(A.T)), n, ptr(out)), None, "sgp_potri")
+    check(lib.sgp_potri(device, ptr(as_f64(A.T)), n, ptr(out)), None, "sgp_potri", lib=lib)
     return out.T.copy()

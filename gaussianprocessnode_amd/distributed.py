@@ -86,6 +86,7 @@ class HipEngine:
         # One explicit (non-default) torch stream carries the sweep AND the collective: the C ABI treats a NULL stream as
         # "the library's own stream", which would not be ordered against torch's default stream or RCCL's.
         self.stream = torch.cuda.Stream(device=device)
+        self._hooked = False
         torch.cuda.synchronize(device)
 
     def stream_context(self):
@@ -106,10 +107,13 @@ class HipEngine:
             assert buf == ptr and count == self.stats.numel(), "the library reduces the buffer bound with bind_stats"
             reduce_fn()
         self.dev.set_allreduce(hook)
+        self._hooked = True
 
     def sweep(self):
-        """local statistics -> installed all-reduce hook -> replicated tail: ONE library call."""
-        self.dev.sweep(self.stream.cuda_stream)
+        """local statistics -> installed all-reduce hook -> replicated tail: ONE library call.  Without a hook (one rank)
+        nothing has to be ordered against a collective, so the sweep runs on the library's own streams (NULL stream) -- where
+        it may overlap the statistics with the Lambda chain (include/sgp_hip.h, sgp_overlap_plan); the getters wait for it."""
+        self.dev.sweep(self.stream.cuda_stream if self._hooked else 0)
 
     def synchronize(self):
         self.torch.cuda.synchronize()

@@ -29,7 +29,7 @@ extern "C" {
 #define SGP_ABI_VERSION 1
 
 #define SGP_ERR_ARG      (-1)   /* bad argument / state */
-#define SGP_ERR_HIP      (-2)   /* HIP runtime error */
+#define SGP_ERR_HIP      (-2)   /* HIP runtime error, or a bounded wait between the library's streams gave up (results refused) */
 #define SGP_ERR_NODEVICE (-3)   /* no gfx950 device visible */
 #define SGP_ERR_NOMEM    (-4)
 
@@ -38,7 +38,8 @@ extern "C" {
                                  * than hipGraph replay at every size (tools/graph_vs_eager.py); kept as a no-op */
 #define SGP_FLAG_KEEP_KUF   2   /* keep K_uf resident for the per-point outputs (sgp_w_stats per_point) */
 #define SGP_FLAG_GRAPH      4   /* replay the launch sequences as captured hipGraphs (opt-in; bitwise the same results) */
-#define SGP_FLAG_PERSISTENT_CHAIN 8   /* EXPERIMENTAL, opt-in (also: environment variable SGP_CHAIN=persistent): factor K_uu and
+#define SGP_FLAG_PERSISTENT_CHAIN 8   /* EXPERIMENTAL, only in the variant library built with -DSGP_WITH_PERSISTENT_CHAIN
+                                 * (libsgp_hip_chain.so; the default library returns SGP_ERR_ARG from sgp_create): factor K_uu and
                                  * Lambda with one persistent launch per factorisation (csrc/sgp_chain.hip.h) instead of one launch
                                  * per 64-column step.  Correct and deterministic (it differs from the default by rounding: right- vs
                                  * left-looking) but measured SLOWER on MI355X (24 vs 19.5 us per step at M = 512);
@@ -251,10 +252,28 @@ int sgp_get_phase_totals(sgp_handle* h, int64_t* totals /* SGP_T_COUNT */, int64
  * 100 MHz stamps of the workgroup that owns tile (j + 1, j) of the Lambda chain; slot 32 j + 16 g + e = event e of wave
  * group g (0 factoring, 1 solve) in step j. */
 int sgp_get_step_trace(int64_t* out /* 512 */);
+/* diagnostics of the variant library built with -DSGP_SWEEP_TRACE (all zeros otherwise): out[65 s] = begin, out[65 s + 1 .. 65 s + 64]
+ * = exit ticks (100 MHz; take the maximum) of trace slot s of the last sweep, 256 slots: 0 k_prep_xu, 2 k_gram_uf, 16 + j step j of the
+ * Lambda chain, 40 + j of the K_uu chain, 64 + first tile of a k_syrk_stream launch, 128 + first tile row of a k_assemble launch,
+ * 200 + j the moment step j had its statistics, ... (csrc/sgp_kernels.hip.h, g_sweep_trace; tools/sweep_trace.py prints them). */
+int sgp_get_sweep_trace(int64_t* out /* 256 * 65 */);
 int sgp_get_chain_trace(sgp_handle* h, int32_t which, int64_t* out /* 384 */);
 /* HIP-event timing of one data-sized kernel (which = SGP_T_GRAM or SGP_T_SYRK) launched eagerly `iters` times on
  * `stream` with the resident data of the last sweep; returns the average launch duration in microseconds. */
 int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void* stream, double* avg_us);
+/* ... which = SGP_TIME_GROUP0 + g: the SYRK launch of statistics group g of the overlapped sweep (sgp_overlap_plan), on the stream
+ * and the compute units it uses inside the sweep (`stream` is ignored). */
+#define SGP_TIME_GROUP0 100
+/* The overlapped sweep.  For UniSGP problems whose SYRK fills the chip, sgp_sweep(h, NULL) without an all-reduce hook produces the
+ * statistics in groups of tile rows of Psi2 -- group 0 on all compute units, the others on a CU-masked queue that leaves 2 CUs
+ * per shader engine to the factorisation chains -- and starts the Lambda chain (GPnode/UniSGPnode.jl:62-71: the N-fold product is
+ * a sum, so its Cholesky can begin on the tile columns that are complete) while the later groups are still being summed.
+ * Results are those of the plain order up to rounding (the tiles collect their rank-64 updates in a different order) and are
+ * bitwise reproducible.  sgp_overlap_plan reports what the next sgp_sweep will do: *ngroups = 0 (plain order) or the number
+ * of groups with, per group, info[8 g ..] = {first, past-the-last tile column of P Lambda P, lower tiles, point chunks, points
+ * per chunk, masked (0/1), CUs available, the Lambda-chain step that forms the group}.  Environment: SGP_OVERLAP=0 turns it
+ * off, SGP_OVERLAP=1 forces it wherever it is possible, SGP_OVERLAP_COLS="3" / "2,4" sets the group boundaries. */
+int sgp_overlap_plan(const sgp_handle* h, int32_t* ngroups, int32_t* info /* 8 per group, up to 8 groups; may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -707,10 +707,21 @@ def test_persistent_chain_potrf_potri(G, n, monkeypatch):
     A = rng.normal(size=(n, n))
     A = A @ A.T / n + np.eye(n)
     for _ in range(3):                               # (hand-off races show up as run-to-run differences)
-        L = G.potrf(A)
+        L = G.potrf(A, variant="chain")              # (the variant library built with -DSGP_WITH_PERSISTENT_CHAIN)
         np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-10, atol=1e-12)
-        Ai = G.potri(A)
+        Ai = G.potri(A, variant="chain")
         assert relF(Ai, np.linalg.inv(A)) < 1e-11
+
+
+def test_default_library_has_no_persistent_chain(G):
+    # the experiment is compiled into the variant library only: the product library refuses the flag instead of ignoring it
+    from gaussianprocessnode_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    cfg = _lib.Config(n_max=10, m=8, d=1, d_out=1, device=0, flags=_lib.SGP_FLAG_PERSISTENT_CHAIN)
+    h = C.c_void_p()
+    assert lib.sgp_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"persistent" in lib.sgp_last_error(None)
 
 
 def test_persistent_chain_sweep_matches_oracle_and_is_deterministic(G):
@@ -899,3 +910,132 @@ def test_torch_nccl_allreduce_inside_the_sweep_with_one_rank():
            "--master-port", "29531", os.path.join(os.path.dirname(__file__), "nccl_single_rank.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
     assert r.returncode == 0 and "nccl single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+# ------------------------------------------------------------------------------------------------
+# The overlapped sweep (sgp_api.hip: plan_overlap / sweep_overlapped): the statistics arrive in groups of tile rows on two more
+# streams (one of them CU-masked) while the Lambda chain already factors the tile columns it has.
+def _sweep_once(G, X, Xu, y, s2, ell, w, jitter=0.0, repeats=1, prior=None):
+    N, D = X.shape
+    with G.SGPDevice(N, len(Xu), D) as dev:
+        dev.set_inducing(Xu)
+        dev.set_data(X, y)
+        dev.set_kernel(s2, ell, jitter)
+        if prior is None:
+            dev.set_prior_isotropic(50.0)
+        else:
+            dev.set_prior_precision(*prior)
+        dev.set_noise([[w]])
+        plan = dev.overlap_plan()
+        outs = []
+        for _ in range(repeats):
+            dev.sweep()
+            outs.append(dev.posterior() + (dev.scalars(), dev.stats()))
+    return plan, outs
+
+
+@pytest.mark.parametrize("cols", [None, "1", "2", "3", "5", "7", "1,2", "2,4", "1,2,3,4,5,6,7"])
+def test_overlapped_sweep_matches_oracle_for_every_grouping(G, cols, monkeypatch):
+    # T-shaped problem (8 tile rows), every way of cutting the tile columns into groups -- also the ones the default never picks
+    N, M, D, w = 10000, 512, 8, 1e4
+    X, Xu, y, _ = synth(N, M, D, seed=7)
+    s2, ell = 0.176, np.array([2.99, 2.91, 1.74, 2.27, 2.01, 1.58, 1.53, 2.05])
+    monkeypatch.setenv("SGP_OVERLAP", "1")
+    if cols:
+        monkeypatch.setenv("SGP_OVERLAP_COLS", cols)
+    plan, outs = _sweep_once(G, X, Xu, y, s2, ell, w, repeats=3)
+    want = [int(c) for c in cols.split(",")] if cols else None
+    assert len(plan) >= 2 and plan[0]["col_begin"] == 0 and plan[-1]["col_end"] == 8 and plan[0]["masked"] == 0
+    if want:
+        assert [g["col_end"] for g in plan[:-1]] == want
+    assert sum(g["tiles"] for g in plan) == 36 and all(g["masked"] == 1 and g["cus"] == 192 for g in plan[1:])
+    ref = O.vmp_sweep(Xu, X, y, None, s2, ell, w, jitter=0.0, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
+    tol = post_tol(np.linalg.cond(np.eye(M) / 50.0 + w * ref.stats.Psi2))
+    mu, Sig, Uv, sc, (Psi2, B, scal) = outs[-1]
+    assert relF(Psi2, ref.stats.Psi2) < 1e-13 and relF(B, np.reshape(ref.stats.b, B.shape)) < 1e-13
+    assert relF(mu, ref.mu_v) < tol and relF(Sig, ref.Sigma_v) < tol and relF(Uv, ref.Uv) < tol
+    assert abs(sc.energy - ref.energy) <= max(1e-7, tol) * abs(ref.energy) + 1e-6
+    for a, b in zip(outs[0][:3], outs[-1][:3]):          # run-to-run bitwise identical
+        assert np.array_equal(a, b)
+    assert outs[0][3].energy == outs[-1][3].energy
+
+
+def test_overlapped_sweep_agrees_with_the_plain_order_and_with_a_dense_prior(G, monkeypatch):
+    # the same sweep with SGP_OVERLAP=0: the statistics agree to rounding (same kernels, other point chunks), the
+    # posterior agrees to rounding (the tiles collect their rank-64 updates in another order); dense prior = the minibatch carry
+    N, M, D, w = 6000, 320, 4, 300.0
+    X, Xu, y, _ = synth(N, M, D, seed=21)
+    s2, ell = 0.8, np.array([1.1, 2.0, 1.4, 0.9])
+    rng = np.random.default_rng(5)
+    Q = rng.normal(size=(M, M))
+    L0 = Q @ Q.T / M + 0.05 * np.eye(M)
+    xi0 = rng.normal(size=M)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SGP_OVERLAP", mode)
+        res[mode] = _sweep_once(G, X, Xu, y, s2, ell, w, jitter=1e-8, prior=(xi0, L0))
+    assert len(res["1"][0]) >= 2 and res["0"][0] == []
+    a, b = res["1"][1][0], res["0"][1][0]
+    assert relF(a[4][0], b[4][0]) < 1e-14 and relF(a[4][1], b[4][1]) < 1e-14       # Psi2, B: other point chunks, same sums
+    ref = O.vmp_sweep(Xu, X, y, None, s2, ell, w, jitter=1e-8, Lambda0=L0, xi0=xi0)
+    tol = post_tol(np.linalg.cond(L0 + w * ref.stats.Psi2))
+    for i, r in enumerate((ref.mu_v, ref.Sigma_v, ref.Uv)):
+        assert relF(a[i], r) < tol and relF(b[i], r) < tol and relF(a[i], b[i]) < tol
+    assert math.isclose(a[3].energy, b[3].energy, rel_tol=1e-6)     # (the energy cancels against s_kk: cond(K_uu) * eps)
+
+
+def test_overlapped_and_plain_sweeps_interleave_on_one_handle(G, monkeypatch):
+    # sweep() (overlapped) and sweep_local() + sweep_finish() (plain order, the two-phase entry points of the multi-GPU path)
+    # on the same handle, back to back without waiting in between: the done word / statistics words keep them apart
+    N, M, D, w = 5000, 256, 8, 1e3
+    X, Xu, y, _ = synth(N, M, D, seed=3)
+    monkeypatch.setenv("SGP_OVERLAP", "1")
+    with G.SGPDevice(N, M, D) as dev:
+        dev.set_inducing(Xu)
+        dev.set_data(X, y)
+        dev.set_kernel(1.0, np.full(D, 2.0), 0.0)
+        dev.set_prior_isotropic(50.0)
+        dev.set_noise([[w]])
+        assert len(dev.overlap_plan()) >= 2
+        for _ in range(4):
+            dev.sweep()
+            dev.sweep_local()
+            dev.sweep_finish()
+        plain = dev.posterior()
+        dev.sweep()
+        over = dev.posterior()
+        sc = dev.scalars()
+    ref = O.vmp_sweep(Xu, X, y, None, 1.0, np.full(D, 2.0), w, jitter=0.0, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
+    tol = post_tol(np.linalg.cond(np.eye(M) / 50.0 + w * ref.stats.Psi2))
+    for a, b, r in zip(plain, over, (ref.mu_v, ref.Sigma_v, ref.Uv)):
+        assert relF(a, r) < tol and relF(b, r) < tol
+    assert abs(sc.energy - ref.energy) <= max(1e-7, tol) * abs(ref.energy) + 1e-6
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_a_bounded_wait_that_gives_up_is_reported_not_swallowed(G, overlap, monkeypatch):
+    # SGP_SPIN_LIMIT=1 (test hook): every device-word wait gives up at its first unsuccessful poll.  The second of two sweeps
+    # queued back to back starts its K_uu chain / statistics before the first has finished -- exactly the hand-off the words
+    # protect -- so the getters must refuse the results (SGP_ERR_HIP naming the word); after that the handle is usable again.
+    from gaussianprocessnode_amd._lib import SGPError
+    N, M, D, w = 10000, 512, 8, 1e4
+    X, Xu, y, _ = synth(N, M, D, seed=9)
+    monkeypatch.setenv("SGP_OVERLAP", overlap)
+    monkeypatch.setenv("SGP_SPIN_LIMIT", "1")
+    with G.SGPDevice(N, M, D) as dev:
+        dev.set_inducing(Xu)
+        dev.set_data(X, y)
+        dev.set_kernel(1.0, np.full(D, 2.0), 0.0)
+        dev.set_prior_isotropic(50.0)
+        dev.set_noise([[w]])
+        for _ in range(3):
+            dev.sweep()
+        with pytest.raises(SGPError, match="bounded device-word wait gave up"):
+            dev.scalars()
+        # the status word was cleared by the report: the handle is usable again (with a one-poll limit a sweep's own hand-offs
+        # -- statistics groups -> Lambda chain, K_uu chain -> Sigma launch -- may give up too, which is reported the same way)
+        dev.sweep()
+        try:
+            assert np.isfinite(dev.scalars().energy)
+        except SGPError as e:
+            assert "bounded device-word wait gave up" in str(e)
