@@ -48,7 +48,7 @@ PIVOT_CYCLES = 127             # dependent cycles per pivot of the factorisation
 def pmc_traffic(workload, world):
     """HBM/fabric bytes per SYRK launch from this round's rocprofv3 --pmc passes (tools/measure_round.sh writes the file next to
     the raw summaries it was computed from; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane reads)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     try:
         rec = json.load(open(path))
     except Exception:
@@ -71,6 +71,63 @@ def synthetic(N, M, D, seed=1, n_test=2000):
     Xt = rng.uniform(-1.745, 1.745, (n_test, D))
     yt = (f(Xt) + 0.1 * rng.normal(size=n_test) - mean) / std
     return X, Xu, y, Xt, yt
+
+
+def _rate(dev, reps, per_point=False):
+    """Back-to-back sweeps per second on a prepared device (with the per-point :w quantities fetched every sweep if asked)."""
+    for _ in range(10):
+        dev.sweep()
+        if per_point:
+            dev.w_stats()
+    dev.scalars()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dev.sweep()
+        if per_point:
+            dev.w_stats()
+    dev.scalars()
+    return reps / (time.perf_counter() - t0)
+
+
+def extras(headline):
+    """After the timed region (rank 0, one GPU; a few tens of milliseconds each):
+    `configs`   sweeps/s of every BASELINE.json configuration on this box (tools/config_rates.py's shapes);
+    `per_point` what the drop-in calls through the real plugin API when q(w) is random: every :w message needs its own
+                I1_n / I2_n (GPnode/UniSGPnode.jl:196-238), i.e. sgp_w_stats after every sweep -- the rate with that call in
+                the loop, and the roofline entry of its dominant kernel k_quadform_cols."""
+    from gaussianprocessnode_amd import SGPDevice, _lib
+    shapes = [("C1 toy regression (GPT_regression.ipynb)", 50, 20, 1, 1), ("C2 kin40k M=256", 10000, 256, 8, 1),
+              ("T kin40k M=512", 10000, 512, 8, 1), ("C3 kin40k N=40000 on one GPU", 40000, 512, 8, 1),
+              ("C4 banana shape", 4000, 128, 2, 1), ("C5 pendulum MultiSGP (300 steps x 5 cubature points)", 1500, 48, 2, 2)]
+    out = {"configs": [], "per_point": []}
+    for name, N, M, D, Do in shapes:
+        rng = np.random.default_rng(0)
+        X = rng.uniform(-1.7, 1.7, (N, D))
+        Xu = rng.uniform(-1.7, 1.7, (M, D))
+        Y = np.sin(X.sum(1))[:, None] * np.ones((1, Do))
+        per_point = Do == 1 and (name.startswith("T ") or name.startswith("C4"))
+        with SGPDevice(N, M, D, d_out=Do, keep_kuf=per_point) as dev:
+            dev.set_inducing(Xu)
+            dev.set_data(X, Y if Do > 1 else Y[:, 0], None, np.full(N, 0.2) if Do > 1 else None, n_nodes=(N // 5 if Do > 1 else None))
+            dev.set_kernel(1.0, np.full(D, 1.5), 1e-6)
+            dev.set_prior_isotropic(50.0)
+            dev.set_noise(np.eye(Do) * 10.0)
+            reps = 200 if N <= 10000 else 60
+            rate = _rate(dev, reps)
+            out["configs"].append({"config": name, "N": N, "M": M, "D": D, "d_out": Do, "sweeps_per_s": rate,
+                                   "order": "overlapped" if dev.overlap_plan() else "plain"})
+            if per_point:
+                rate_pp = _rate(dev, reps, per_point=True)
+                q_us = [dev.time_kernel(_lib.SGP_TIME_QUADFORM + m, 10) for m in (0, 1)]
+                flops = float(N) * M * (M + 64)                  # lower-triangular factor, 64-wide tiles incl. the diagonal ones
+                tf = flops / (sum(q_us) / 2 * 1e-6) / 1e12
+                out["per_point"].append({
+                    "config": name, "sweeps_per_s_with_w_stats": rate_pp, "sweeps_per_s_without": rate,
+                    "what": "sgp_sweep + sgp_w_stats (k_quadform_cols x 2 + k_w_point_finish, then 2 n doubles to the host) per iteration",
+                    "roofline_quadform": {"kernel": "k_quadform_cols (|L^-1 k_n|^2 and |Uv k_n|^2 from the resident K_uf)", "bound": "mfma",
+                                          "launch_us": q_us, "algorithmic_flops_per_launch": flops, "achieved": tf,
+                                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS}})
+    return out
 
 
 def main():
@@ -152,14 +209,31 @@ def main():
     phase_us, n_counted = dev.phase_totals()
     tick_us = lambda i: float(phase_us[i])
     stream = eng.stream.cuda_stream
-    syrk_us_alone = dev.time_kernel(_lib.SGP_T_SYRK, 10, stream)
-    gram_us_alone = dev.time_kernel(_lib.SGP_T_GRAM, 10, stream)
-    syrk_us = tick_us(_lib.SGP_T_SYRK)
     n_loc = hi - lo
     syrk_flops = float(n_loc) * M * (M + 1)                     # SYRK lower half n M (M+1)
-    # `achieved` is priced at the HIP-event duration of the kernel launched alone (the clock rocprofv3 --kernel-trace --stats
-    # shows for it too: profiles/r02_bench_T_kernel_stats.csv); the in-sweep figure, with the K_uu chain beside it, rides along
-    achieved = syrk_flops / (syrk_us_alone * 1e-6) / 1e12
+    # The SYRK of the timed sweeps.  Plain order: ONE launch over all lower tiles.  Overlapped sweep (sgp_overlap_plan): one launch
+    # per statistics group, the first on all CUs, the others on the CU-masked stream -- each is timed alone with HIP events on
+    # the stream (and the CUs) it uses inside the sweep; `achieved` = the sweep's SYRK flops / the sum of its launches =
+    # (flops per launch) / (average launch duration), the quantity rocprofv3 --kernel-trace --stats shows for k_syrk_stream.
+    plan = dev.overlap_plan() if (world == 1 and not sweep.hooked) else []
+    ntiles_all = (M + 63) // 64 * ((M + 63) // 64 + 1) // 2
+    if plan:
+        group_us = [dev.time_group(g, 10) for g in range(len(plan))]
+        syrk_groups = [{"tile_columns": [g["col_begin"], g["col_end"]], "tiles": g["tiles"], "point_chunks": g["chunks"], "cus": g["cus"],
+                        "launch_us": us, "tflops": syrk_flops * g["tiles"] / ntiles_all / (us * 1e-6) / 1e12,
+                        "frac_of_peak_of_its_cus": syrk_flops * g["tiles"] / ntiles_all / (us * 1e-6) / 1e12
+                                                   / (FP64_MFMA_PEAK_TFLOPS * g["cus"] / 256.0)}
+                       for g, us in zip(plan, group_us)]
+        syrk_launches = len(plan)
+        syrk_us_alone = sum(group_us) / syrk_launches           # average launch duration
+    else:
+        syrk_groups = None
+        syrk_launches = 1
+        syrk_us_alone = dev.time_kernel(_lib.SGP_T_SYRK, 10, stream)
+    syrk_full_us = dev.time_kernel(_lib.SGP_T_SYRK, 10, stream) if plan else syrk_us_alone     # one launch, all tiles, all CUs
+    gram_us_alone = dev.time_kernel(_lib.SGP_T_GRAM, 10, stream)
+    syrk_us = tick_us(_lib.SGP_T_SYRK)
+    achieved = syrk_flops / syrk_launches / (syrk_us_alone * 1e-6) / 1e12
     traffic, traffic_src = pmc_traffic(args.workload, world)
     import ctypes as C
     sclk = C.c_double()
@@ -198,11 +272,16 @@ def main():
         "roofline": {"kernel": "k_syrk_stream (Psi2 = K_uf K_uf^T, v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "clock": "HIP events around 10 eager launches of the kernel alone on the sweep's stream (the duration "
-                              "rocprofv3 --kernel-trace --stats reports for it)",
-                     "launch_us": syrk_us_alone, "launch_us_in_timed_region": syrk_us, "launches_averaged": int(n_counted),
-                     "achieved_in_timed_region": syrk_flops / (syrk_us * 1e-6) / 1e12 if syrk_us > 0 else None,
-                     "algorithmic_flops_per_launch": syrk_flops,
+                     "clock": "HIP events around 10 eager launches of each of the sweep's SYRK launches alone, on the stream and the "
+                              "CUs it uses inside the sweep (the duration rocprofv3 --kernel-trace --stats reports for it)",
+                     "launches_per_sweep": syrk_launches, "launch_us": syrk_us_alone,
+                     "first_in_to_last_out_us_in_timed_region": syrk_us, "sweeps_averaged": int(n_counted),
+                     "algorithmic_flops_per_launch": syrk_flops / syrk_launches, "algorithmic_flops_per_sweep": syrk_flops,
+                     "groups": syrk_groups,
+                     "single_launch_all_tiles_all_cus": {"launch_us": syrk_full_us, "tflops": syrk_flops / (syrk_full_us * 1e-6) / 1e12,
+                                                         "frac": syrk_flops / (syrk_full_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                                         "note": "the same kernel as ONE launch (the plain order of the sweep: multi-GPU, "
+                                                                 "caller's stream, very large N); not what the timed sweeps ran when `groups` is set"},
                      "peak_at_measured_clock": peak_at_clock, "frac_of_peak_at_measured_clock": achieved / peak_at_clock if peak_at_clock > 0 else None,
                      "mfma_probe_tflops": mfma_probe_tflops,
                      "frac_of_mfma_probe": achieved / mfma_probe_tflops if mfma_probe_tflops > 0 else None,
@@ -213,6 +292,7 @@ def main():
         # the sweep's critical path is the Lambda factorisation chain: latency-bound, priced against its pivot floor
         "roofline_chain": {"kernel": "k_potrf_step x (M/64 + 1) + k_trmv_mu_scan (Lambda = L L^T, inverse factor, Sigma rows, t, mu)",
                            "bound": "latency (dependent pivot chain)", "achieved_us": f1_us, "floor_us": chain_floor_us,
+                           "overlapped_with_statistics": bool(plan),
                            "frac": chain_floor_us / f1_us if f1_us > 0 else None,
                            "model": f"{Qp} pivots x {PIVOT_CYCLES} dependent cycles at sclk"},
         # second data-sized kernel (SURVEY.md §8d asks for HBM GB/s on K_uf): k_gram_uf writes 8 n Mp bytes of K_uf once
@@ -222,6 +302,10 @@ def main():
                           "frac": 8.0 * n_loc * dev.stats_layout()[2] / (tick_us(_lib.SGP_T_GRAM) * 1e-6) / 1e9 / 8000.0,
                           "algorithmic_bytes_per_launch": 8.0 * n_loc * dev.stats_layout()[2],
                           "note": "41 MB at T: the write stays in the 256 MiB Infinity Cache; PMC WRITE_SIZE 41.6 MB"},
+        "sweep_order": ({"kind": "overlapped", "groups": plan,
+                         "note": "statistics in tile-row groups (first on all CUs, the others on a CU-masked queue) while the Lambda "
+                                 "chain factors the tile columns it has; `local` and `finish1_lambda_chain` overlap in time"}
+                        if plan else {"kind": "plain", "note": "statistics, then the Lambda chain"}),
         "phases_us": {"sweep_device": tick_us(_lib.SGP_T_SWEEP), "gram_uf": tick_us(_lib.SGP_T_GRAM),
                       "gram_uf_alone_hip_events": gram_us_alone, "syrk": syrk_us,
                       "local": tick_us(_lib.SGP_T_LOCAL), "gap_local_to_finish": tick_us(_lib.SGP_T_GAP_LOCAL_FINISH),
@@ -317,6 +401,11 @@ def main():
                                                              "reference's theta_opt; the reference reports 0.0834 with M=600"}
             except Exception as e:                                   # pragma: no cover
                 out["parity"]["smse_kin40k_real"] = {"error": repr(e)}
+            if N <= 100000:
+                try:
+                    out["extra"] = extras(args.workload)
+                except Exception as e:                               # pragma: no cover
+                    out["extra"] = {"error": repr(e)}
         if ctx:
             ctx.__exit__(None, None, None)
         print(json.dumps(out))

@@ -32,6 +32,7 @@ EXPORTS = [
     "sgp_get_sweep_trace",
 ]
 SGP_TIME_GROUP0 = 100
+SGP_TIME_QUADFORM = 120
 
 
 class SGPError(RuntimeError):

@@ -68,8 +68,8 @@ constexpr int RESERVED_CUS_PER_SE = 2;      // of 8: the masked statistics strea
 struct StatGroup {
     int c0, c1;            // tile columns of P Lambda P (index-reversed), formed by the Lambda chain's step `form_step`
     int row_lo, nrows;     // the same as tile rows of Psi2: [T - c1, T - c0)
-    int tile0, ntiles;     // their lower tiles in the row-major triangle
-    int nchunks, chunk;    // split of the point axis (one resident round of workgroups on the group's CUs)
+    int ntiles;            // their lower tiles
+    SyrkGeom geom;         // split of the point axis (one resident round of workgroups on the group's CUs)
     int form_step;
     bool masked;           // runs on statM
     size_t slab_off;       // doubles into dSlabs
@@ -157,7 +157,8 @@ struct sgp_handle {
     int env_overlap = -1;          // SGP_OVERLAP: 0 off, 1 on wherever it is possible; default: where the planner's model says it pays
     int env_g1_mode = 2;           // SGP_G1_AFTER (see enqueue_stats_overlapped)
     std::vector<int> env_overlap_cols;   // SGP_OVERLAP_COLS: group boundaries (tile columns of P Lambda P), e.g. "3" or "2,4"
-    int nchunks = 1, chunk = 0, nblk = 0, ntiles = 0, num_cus = 256;
+    int nblk = 0, ntiles = 0, num_cus = 256;
+    SyrkGeom geom{};               // the plain sweep's single SYRK launch over all tile rows (set_point_count)
     int64_t stats_count = 0;
     size_t slab_capacity = 0;
     Graph gLocal, gFinish, gFinish2, gKuu;
@@ -225,26 +226,41 @@ static int quiesce(sgp_handle* h) {
 // share a CU, i.e. 1024 slots on 256 CUs.  A grid just above that (the first version: 1152) leaves a straggler round in
 // which 128 workgroups run one to a CU at a fraction of the matrix-core rate -- PMC: the CUs were busy 71 % of the launch;
 // the largest chunk count with tiles x chunks <= slots (1008 at M = 512) keeps every CU at 4 workgroups from start to end.
-// `align`: chunk counts are rounded so that tiles x chunks is a multiple of the 8 XCDs (see k_syrk_stream's block map).
-// In a sweep the K_uu chain runs beside this kernel and each workgroup of its Cholesky steps takes the LDS of a whole CU.
-// SYRK_RESERVED_CUS are left out of the slot count for it.  Measured at T (sweeps/s, SYRK us): 40 reserved 3312 / 66.5,
-// 24 the same, 8: 3355 / 62.6, 0: 3202 / 76.7 (a second round).  The chain has ~45 us of slack at T since its steps got
-// short, so it can wait out most of this launch; with nothing reserved its resident workgroups push the round over.
+// Chunk counts are rounded down so that tiles x chunks is a multiple of the 8 XCDs (k_syrk_stream's block map) when that
+// costs at most one eighth of the chunks.
+// In a plain sweep the K_uu chain runs beside this kernel and each workgroup of its Cholesky steps takes the LDS of a whole
+// CU: SYRK_RESERVED_CUS are left out of the slot count for it unless the chain is gated behind this launch (set_point_count).
+// Measured at T with the round-1 grid (sweeps/s, SYRK us): 40 reserved 3312 / 66.5, 24 the same, 8: 3355 / 62.6, 0: 3202 /
+// 76.7 (a second round).
 #ifndef SYRK_BLOCKS_PER_CU
 #define SYRK_BLOCKS_PER_CU 4
 #endif
 #ifndef SYRK_RESERVED_CUS
 #define SYRK_RESERVED_CUS 8
 #endif
-static void syrk_chunking(int ntiles, int num_cus, int* want, int* align, int reserved = SYRK_RESERVED_CUS) {
+static SyrkGeom syrk_geometry(int row_lo, int nrows, int cus, int64_t n) {
+    SyrkGeom g;
+    g.row_lo = row_lo;
+    g.nrows = nrows;
+    g.tile0 = row_lo * (row_lo + 1) / 2;
+    g.ntiles = (row_lo + nrows) * (row_lo + nrows + 1) / 2 - g.tile0;
+    g.chunk = KB;
+    g.nchunks = 0;
+    if (n <= 0) return g;
+    const int slots = SYRK_BLOCKS_PER_CU * std::max(8, cus);
     int a = 8;
-    for (int g = 2; g <= 8; g *= 2)
-        if (ntiles % g == 0) a = 8 / g;                  // smallest a with (ntiles * a) % 8 == 0
-    int w = std::max(1, SYRK_BLOCKS_PER_CU * std::max(8, num_cus - reserved) / ntiles);
-    if (w > a) w = w / a * a;
-    *want = w;
-    *align = a;
+    for (int q = 2; q <= 8; q *= 2)
+        if (g.ntiles % q == 0) a = 8 / q;                 // smallest a with (ntiles * a) % 8 == 0
+    int want = std::max(1, slots / g.ntiles);
+    if (want >= 8 * a) want = want / a * a;
+    int64_t per = (n + want - 1) / want;
+    per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);
+    g.chunk = (int)per;
+    g.nchunks = (int)std::max<int64_t>(1, (n + per - 1) / per);
+    if (g.nchunks >= 8 * a) g.nchunks = std::min(want, (g.nchunks + a - 1) / a * a);   // trailing chunks may be empty (zero slabs)
+    return g;
 }
+static inline size_t syrk_items(const SyrkGeom& g) { return (size_t)g.ntiles * g.nchunks; }
 
 // ------------------------------------------------------------------------------------------------
 // dense building blocks (launch sequences)
@@ -382,10 +398,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         h->num_cus = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
                          ? prop.multiProcessorCount : 256;
     }
-    int want_chunks = 1, align_chunks = 1;
-    syrk_chunking(h->ntiles, h->num_cus, &want_chunks, &align_chunks, 0);      // (the larger of the two geometries, see set_point_count)
-    int max_chunks = want_chunks + align_chunks;
-    h->slab_capacity = (size_t)max_chunks * h->ntiles * TB * TB;
+    h->slab_capacity = (size_t)(SYRK_BLOCKS_PER_CU * std::max(8, h->num_cus)) * TB * TB;      // one slab per workgroup of the round
     const size_t nblk_max = (nmax + TB - 1) / TB;
 
 #define ALLOC(ptr, count)                                            \
@@ -531,8 +544,10 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     // is CU (i / 8 / 4) of shader engine (i / 8) % 4 of XCD i % 8 (measured with tools/cu_mask_probe.hip), so the first
     // 32 k bits are k CUs on every shader engine of every XCD -- a symmetric mask: an uneven one (e.g. 216 bits) leaves some
     // engines with fewer CUs than their equal share of the workgroups and costs a second round.
-    if (h->env_overlap != 0 && !(cfg->flags & SGP_FLAG_GRAPH) && h->dout == 1 && h->num_cus % 32 == 0 && h->num_cus / 32 > RESERVED_CUS_PER_SE) {
-        const int keep = h->num_cus - 32 * RESERVED_CUS_PER_SE;
+    int reserved_per_se = RESERVED_CUS_PER_SE;
+    if (const char* r = getenv("SGP_RESERVED_PER_SE")) reserved_per_se = std::max(1, atoi(r));     // (A/B switch)
+    if (h->env_overlap != 0 && !(cfg->flags & SGP_FLAG_GRAPH) && h->dout == 1 && h->num_cus % 32 == 0 && h->num_cus / 32 > reserved_per_se) {
+        const int keep = h->num_cus - 32 * reserved_per_se;
         uint32_t mask[16] = {0};
         for (int i = 0; i < keep && i < 512; ++i) mask[i / 32] |= 1u << (i % 32);
         // (Confining the K_uu chain's stream to the complement, the reserved CUs, was measured and dropped: an unmasked launch
@@ -606,17 +621,6 @@ extern "C" int sgp_set_inducing(sgp_handle* h, const double* Xu) {
     return 0;
 }
 
-// split n points into about `want` chunks (a multiple of the stage size each); the chunk count is rounded up to a multiple of
-// `align` (trailing chunks may then be empty: zero slabs)
-static void split_points(int64_t n, int want, int align, int* chunk, int* nchunks) {
-    int64_t per = (n + want - 1) / std::max(want, 1);
-    per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);
-    int nc = (int)std::max<int64_t>(1, (n + per - 1) / per);
-    if (nc > align) nc = (nc + align - 1) / align * align;
-    *chunk = (int)per;
-    *nchunks = nc;
-}
-
 // The overlapped sweep: does this problem qualify, and how are the tile columns of P Lambda P grouped?
 //   * UniSGP, eager launches, the masked statistics stream exists, at least 3 tile rows, a SYRK that fills the chip (the same
 //     bound as the K_uu chain's gate).
@@ -677,15 +681,12 @@ static void plan_overlap(sgp_handle* h, int64_t n) {
         G.c1 = (g < cuts.size()) ? cuts[g] : T;
         G.row_lo = T - G.c1;
         G.nrows = G.c1 - G.c0;
-        G.tile0 = G.row_lo * (G.row_lo + 1) / 2;
-        G.ntiles = (T - G.c0) * (T - G.c0 + 1) / 2 - G.tile0;
         G.masked = g > 0;
         G.form_step = G.c0;
-        int want = 1, align = 1;
-        syrk_chunking(G.ntiles, G.masked ? h->stat_cus_masked : h->num_cus, &want, &align, 0);
-        split_points(n, want, align, &G.chunk, &G.nchunks);
+        G.geom = syrk_geometry(G.row_lo, G.nrows, G.masked ? h->stat_cus_masked : h->num_cus, n);
+        G.ntiles = G.geom.ntiles;
         G.slab_off = off;
-        off += (size_t)G.nchunks * G.ntiles * TB * TB;
+        off += syrk_items(G.geom) * TB * TB;
         c0 = G.c1;
     }
     if (off > h->slab_capacity) {
@@ -705,16 +706,14 @@ static int set_point_count(sgp_handle* h, int64_t n) {
     h->n = n;
     h->nblk = (int)((n + TB - 1) / TB);
     // split the point axis into one resident round of workgroups (see syrk_chunking), chunk a multiple of the stage size
-    int want = 1, align = 1;
     // Eager launches with a SYRK big enough to fill the chip: the K_uu chain is held back until this launch is resident
     // (enqueue_kuu), so nothing is reserved for it and the grid is sized for all CUs (T: 25 -> 28 chunks, 62.7 -> 57.4 us; the
     // chain then runs after the SYRK and still ends ~9 us before its join).  Small problems keep the early chain: there the
     // two chains are the sweep, and a late K_uu chain is waited for (C1: -15 %, C5: -2 % with the gate).
     h->gate_side = n * (int64_t)h->ntiles >= 200000 && h->dJoin && !(h->cfg.flags & SGP_FLAG_GRAPH) && !h->use_chain &&
                    !h->env_no_gate;
-    syrk_chunking(h->ntiles, h->num_cus, &want, &align, h->gate_side ? 0 : SYRK_RESERVED_CUS);
-    split_points(n, want, align, &h->chunk, &h->nchunks);
-    if ((size_t)h->nchunks * h->ntiles * TB * TB > h->slab_capacity)
+    h->geom = syrk_geometry(0, h->T, h->num_cus - (h->gate_side ? 0 : SYRK_RESERVED_CUS), n);
+    if (syrk_items(h->geom) * TB * TB > h->slab_capacity)
         return fail(h, SGP_ERR_ARG, "sgp_set_data: internal slab capacity exceeded");
     plan_overlap(h, n);
     return 0;
@@ -968,12 +967,14 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
 #ifdef SGP_WITH_PERSISTENT_CHAIN
         if (h->use_chain) gate = h->dChainFlags[0] + CH_F_GATE;
 #endif
-        hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
-                           h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->chunk, 0, h->ntiles, h->nchunks,
+        hipLaunchKernelGGL(k_syrk_stream, dim3((unsigned)syrk_items(h->geom)), dim3(256), 0, s, h->dKuf,
+                           h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->geom,
                            h->dStamps + STAMP_STRIDE * SGP_T_SYRK, gate, h->gate_epoch);
     }
-    hipLaunchKernelGGL(k_assemble, dim3(T, T + 1, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp, T, 0, 0,
-                       h->ntiles, h->n > 0 ? h->nchunks : 0, h->n > 0 ? h->nblk : 0, h->dout,
+    SyrkGeom ga = h->geom;
+    if (h->n <= 0) { ga = syrk_geometry(0, T, h->num_cus, 0); }       // no data: zero chunks, the statistics are zero
+    hipLaunchKernelGGL(k_assemble, dim3(T, T + 1, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp, T, ga,
+                       h->n > 0 ? h->nblk : 0, h->dout,
                        SGP_S_COUNT + h->dout * h->dout, 1, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL, h->dInfo + 1, (long long*)nullptr, 0LL);
 }
 
@@ -1008,11 +1009,11 @@ static void enqueue_stats_overlapped(sgp_handle* h, hipStream_t own) {
     for (int g = 0; g < h->ngroups; ++g) {
         const StatGroup& G = h->grp[g];
         hipStream_t s = G.masked ? h->statM : own;
-        hipLaunchKernelGGL(k_syrk_stream, dim3(G.ntiles * G.nchunks), dim3(256), 0, s, h->dKuf, h->has_omega ? h->dOmega : nullptr,
-                           h->dSlabs + G.slab_off, Mp, h->n, G.chunk, G.tile0, G.ntiles, G.nchunks,
+        hipLaunchKernelGGL(k_syrk_stream, dim3((unsigned)syrk_items(G.geom)), dim3(256), 0, s, h->dKuf, h->has_omega ? h->dOmega : nullptr,
+                           h->dSlabs + G.slab_off, Mp, h->n, G.geom,
                            h->dStamps + STAMP_STRIDE * SGP_T_SYRK, g == 0 ? h->dJoin + WORD_GATE : (long long*)nullptr, h->gate_epoch);
         hipLaunchKernelGGL(k_assemble, dim3(G.nrows, T + (g == 0 ? 1 : 0), 16), dim3(256), 0, s, h->dSlabs + G.slab_off, h->dBpart,
-                           h->dDataScal, h->dStats, Mp, T, G.row_lo, G.tile0, G.ntiles, G.nchunks, h->nblk, h->dout,
+                           h->dDataScal, h->dStats, Mp, T, G.geom, h->nblk, h->dout,
                            SGP_S_COUNT + h->dout * h->dout, g == 0 ? 1 : 0, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL,
                            g == 0 ? h->dInfo + 1 : (int*)nullptr, g == 0 ? h->dJoin + WORD_ASM0 : (long long*)nullptr, h->stat_epoch);
         if (G.masked || g1_mode == 1) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_GROUP0 + g, h->stat_epoch);
@@ -1555,14 +1556,20 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
         G = &h->grp[which - SGP_TIME_GROUP0];
         s = G->masked ? h->statM : h->own;
     }
+    // which = SGP_TIME_QUADFORM + mode: k_quadform_cols of sgp_w_stats (mode 0: |L^-1 k_n|^2 with W_K, mode 1: |Uv k_n|^2)
+    const int qmode = (which == SGP_TIME_QUADFORM || which == SGP_TIME_QUADFORM + 1) ? which - SGP_TIME_QUADFORM : -1;
+    if (qmode >= 0 && (!(h->cfg.flags & SGP_FLAG_KEEP_KUF) || !h->swept))
+        return fail(h, SGP_ERR_ARG, "sgp_time_kernel: the per-point kernels need SGP_FLAG_KEEP_KUF and a finished sweep");
     EventPair ev;
     HIPCHK(h, ev.create());
     hipEvent_t e0 = ev.a, e1 = ev.b;
     auto launch = [&]() {
-        if (G)
-            hipLaunchKernelGGL(k_syrk_stream, dim3(G->ntiles * G->nchunks), dim3(256), 0, s, h->dKuf, h->has_omega ? h->dOmega : nullptr,
-                               h->dSlabs + G->slab_off, h->Mp, h->n, G->chunk, G->tile0, G->ntiles, G->nchunks, (int64_t*)nullptr,
-                               (long long*)nullptr, 0LL);
+        if (qmode >= 0)
+            hipLaunchKernelGGL(k_quadform_cols, dim3(h->nblk, h->T), dim3(256), 0, s, qmode == 0 ? h->dWk : h->dUvT, h->dKuf,
+                               qmode == 0 ? h->dPa : h->dPb, h->Mp, h->T, h->n, qmode);
+        else if (G)
+            hipLaunchKernelGGL(k_syrk_stream, dim3((unsigned)syrk_items(G->geom)), dim3(256), 0, s, h->dKuf, h->has_omega ? h->dOmega : nullptr,
+                               h->dSlabs + G->slab_off, h->Mp, h->n, G->geom, (int64_t*)nullptr, (long long*)nullptr, 0LL);
         else if (which == SGP_T_GRAM && h->D <= 8)
             hipLaunchKernelGGL(k_gram_uf<8>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr, (int64_t*)nullptr);
@@ -1570,11 +1577,11 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
             hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr, (int64_t*)nullptr);
         else
-            hipLaunchKernelGGL(k_syrk_stream, dim3(h->ntiles * h->nchunks), dim3(256), 0, s, h->dKuf,
-                               h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->chunk, 0, h->ntiles, h->nchunks,
+            hipLaunchKernelGGL(k_syrk_stream, dim3((unsigned)syrk_items(h->geom)), dim3(256), 0, s, h->dKuf,
+                               h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->geom,
                                (int64_t*)nullptr, (long long*)nullptr, 0LL);
     };
-    if (!G && which != SGP_T_GRAM && which != SGP_T_SYRK)
+    if (!G && qmode < 0 && which != SGP_T_GRAM && which != SGP_T_SYRK)
         return fail(h, SGP_ERR_ARG, "sgp_time_kernel: which must be SGP_T_GRAM, SGP_T_SYRK or SGP_TIME_GROUP0 + g");
     launch();
     HIPCHK(h, hipEventRecord(e0, s));
@@ -1598,7 +1605,7 @@ extern "C" int sgp_overlap_plan(const sgp_handle* h, int32_t* ngroups, int32_t* 
     for (int g = 0; g < h->ngroups; ++g) {
         const StatGroup& G = h->grp[g];
         int32_t* o = info + 8 * g;
-        o[0] = G.c0; o[1] = G.c1; o[2] = G.ntiles; o[3] = G.nchunks; o[4] = G.chunk; o[5] = G.masked ? 1 : 0;
+        o[0] = G.c0; o[1] = G.c1; o[2] = G.ntiles; o[3] = G.geom.nchunks; o[4] = G.geom.chunk; o[5] = G.masked ? 1 : 0;
         o[6] = G.masked ? h->stat_cus_masked : h->num_cus; o[7] = G.form_step;
     }
     return 0;

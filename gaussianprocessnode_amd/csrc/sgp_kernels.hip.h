@@ -387,6 +387,40 @@ __device__ __forceinline__ void tile_mma(Acc4& acc, const double* As, const doub
     }
 }
 
+// The same for a DIAGONAL tile of a symmetric product (As and Bs hold the same rows, Bs weighted): only the 10 sub-tiles (R, C),
+// R >= C, of the 4 x 4 grid of 16 x 16 blocks are formed, dealt 3 : 2 : 2 : 3 over the waves --
+//   wave 0: (0,0) (1,0) (1,1)   wave 1: (2,0) (2,1)   wave 2: (3,0) (3,1)   wave 3: (2,2) (3,2) (3,3)
+// (accumulators t[0][0], t[1][0], t[1][1] for waves 0 / 3, t[0][0], t[0][1] for waves 1 / 2): 3 instead of 4 MFMAs per wave and
+// k-step, and no flop on the upper halves, which the algorithm does not contain.
+__device__ __forceinline__ void tile_mma_diag(Acc4& acc, const double* As, const double* Bs, int kcount, int lane, int wave) {
+    const int li = lane & 15, lk = lane >> 4;
+    if (wave == 0 || wave == 3) {
+        const int base = (wave == 3) ? 32 : 0;
+        const double* ap = As + lk * PS + base + li;
+        const double* bp = Bs + lk * PS + base + li;
+#pragma unroll 4
+        for (int k = 0; k < kcount; k += 4) {
+            const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
+            acc.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.t[0][0], 0, 0, 0);
+            acc.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.t[1][0], 0, 0, 0);
+            acc.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.t[1][1], 0, 0, 0);
+            ap += 4 * PS;
+            bp += 4 * PS;
+        }
+    } else {
+        const double* ap = As + lk * PS + 16 * (wave + 1) + li;
+        const double* bp = Bs + lk * PS + li;
+#pragma unroll 4
+        for (int k = 0; k < kcount; k += 4) {
+            const double a0 = ap[0], b0 = bp[0], b1 = bp[16];
+            acc.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.t[0][0], 0, 0, 0);
+            acc.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.t[0][1], 0, 0, 0);
+            ap += 4 * PS;
+            bp += 4 * PS;
+        }
+    }
+}
+
 // element (i, j) of the 64 x 64 tile owned by (lane, wave, ti, tj, r)
 __device__ __forceinline__ int acc_row(int lane, int wr, int ti, int r) { return wr * 32 + ti * 16 + (lane >> 4) + 4 * r; }
 __device__ __forceinline__ int acc_col(int lane, int wc, int tj) { return wc * 32 + tj * 16 + (lane & 15); }
@@ -450,41 +484,16 @@ __device__ __forceinline__ void tile_from_index(int t, int& I, int& J) {
     J = t - i * (i + 1) / 2;
 }
 
-// One launch covers the lower tiles [tile0, tile0 + ntiles) of the row-major triangle (a whole matrix: tile0 = 0, ntiles = all; the
-// overlapped sweep launches the tile rows in groups, last rows first, see sgp_api.hip); `slabs` is the group's own slab area.
-__global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
-                                                     double* __restrict__ slabs, int Mp, int64_t N, int chunk,
-                                                     int tile0, int ntiles, int nchunks, int64_t* stamps, long long* gate,
-                                                     long long gate_value) {
-    __shared__ double lds[2 * 2 * KB * PS];           // [buf][panel A|B][KB][PS]
-    TraceScope trace(64 + tile0);
-    stamp_enter(stamps);
-    // the last workgroup of this launch's single resident round is on a CU: whoever waited for that (the K_uu chain's first
-    // kernel) may take the CUs that are left
-    if (gate && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-        __hip_atomic_store(gate, gate_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// One work item of the streaming SYRK: the 64 x 64 tile (I, J) summed over the points of chunk `chunk_id`, into `out` ([i][j]
+// row-major; a diagonal tile as the full symmetric tile).
+template <bool DIAG>
+__device__ __forceinline__ void syrk_item(const double* __restrict__ Kuf, const double* __restrict__ omega, double* __restrict__ out,
+                                          double* lds, int Mp, int64_t N, int I, int J, int chunk_id, int chunk) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    // XCD-aware block -> (tile, chunk) map: workgroups are dealt round-robin over the 8 XCDs, so ids congruent mod 8
-    // share an L2.  All tiles of one point-chunk read the same K_uf columns: the work items, ordered chunk-major, are cut
-    // into 8 contiguous runs, one per XCD, so that a chunk's columns are fetched into (at most two) L2s once.  Needs the
-    // item count to be a multiple of 8 (the host picks nchunks accordingly whenever there is enough work; speed only).
-    int tile_id, chunk_id;
-    const int nitems = ntiles * nchunks;
-    if ((nitems & 7) == 0) {
-        const int item = (blockIdx.x & 7) * (nitems >> 3) + (blockIdx.x >> 3);
-        chunk_id = item / ntiles;
-        tile_id = item % ntiles;
-    } else {
-        chunk_id = blockIdx.x / ntiles;
-        tile_id = blockIdx.x % ntiles;
-    }
-    int I, J;
-    tile_from_index(tile0 + tile_id, I, J);
-    const bool diag = (I == J);
     const int64_t nbeg = (int64_t)chunk_id * chunk;
     int64_t nend = nbeg + chunk;
     if (nend > N) nend = N;
-    const int stages = (int)((nend - nbeg + KB - 1) / KB);
+    const int stages = nend > nbeg ? (int)((nend - nbeg + KB - 1) / KB) : 0;
     // staging map: thread -> (point p = tid >> 4, row quad rq = tid & 15): 32 B of one K_uf column
     const int p = tid >> 4, rq = tid & 15;
     Acc4 acc;
@@ -498,7 +507,7 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
             double2 v1 = *reinterpret_cast<const double2*>(src + 2);
             ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
             double w = omega ? omega[n] : 1.0;
-            if (!diag) {
+            if (DIAG ? false : (I != J)) {                // (a diagonal tile reads its rows once)
                 const double* sb = Kuf + (size_t)n * Mp + J * TB + rq * 4;
                 double2 u0 = *reinterpret_cast<const double2*>(sb);
                 double2 u1 = *reinterpret_cast<const double2*>(sb + 2);
@@ -526,18 +535,82 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
         const int buf = s & 1;
         if (s + 1 < stages) gload(s + 1);
         const double* A = lds + buf * (2 * KB * PS);
-        tile_mma(acc, A, A + KB * PS, KB, lane, wr, wc);
+        if constexpr (DIAG) tile_mma_diag(acc, A, A + KB * PS, KB, lane, wave);
+        else tile_mma(acc, A, A + KB * PS, KB, lane, wr, wc);
         if (s + 1 < stages) lstore(buf ^ 1);
         __syncthreads();
     }
-    double* out = slabs + ((size_t)chunk_id * ntiles + tile_id) * (TB * TB);
+    if constexpr (!DIAG) {
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
+            for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                out[acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj)] = acc.t[ti][tj][r];
+                for (int r = 0; r < 4; ++r)
+                    out[acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj)] = acc.t[ti][tj][r];
+    } else {
+        // the wave's sub-tiles (tile_mma_diag), each also at its mirror position: the slab is the full symmetric tile.
+        // Accumulator slot s of the wave holds sub-tile (R0 + (s > 0), C0 + (s > 1)) for waves 0 / 3, (wave + 1, s) for waves 1 / 2
+        const int row = lane >> 4, col = lane & 15;
+        const bool corner = (wave == 0 || wave == 3);
+        const int b = (wave == 3) ? 2 : 0;
+#pragma unroll
+        for (int slot = 0; slot < 3; ++slot) {
+            if (!corner && slot == 2) break;
+            const d4 v = corner ? (slot == 0 ? acc.t[0][0] : (slot == 1 ? acc.t[1][0] : acc.t[1][1])) : (slot == 0 ? acc.t[0][0] : acc.t[0][1]);
+            const int R = corner ? b + (slot > 0) : wave + 1, C = corner ? b + (slot > 1) : slot;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                out[(16 * R + row + 4 * r) * TB + 16 * C + col] = v[r];
+                if (R != C) out[(16 * C + col) * TB + 16 * R + row + 4 * r] = v[r];
+            }
+        }
+    }
+}
+
+// One launch covers the lower tiles of the tile rows [row_lo, row_lo + nrows) of Psi2 (a whole matrix: row_lo = 0, nrows = T; the
+// overlapped sweep launches the rows in groups, last rows first, see sgp_api.hip): tiles [tile0, tile0 + ntiles) of the row-major
+// triangle, the point axis split into `nchunks` chunks of `chunk` points.  `slabs` is the launch's own slab area
+// [nchunks][ntiles] of 64 x 64.  Diagonal tiles form 10 of their 16 sub-tiles (tile_mma_diag): no flop on the halves the
+// algorithm does not contain.  (Their workgroups finish a quarter earlier; giving them 4/3 longer chunks to rebalance the round
+// was measured -- 30 x 336 points off the diagonal, 23 x 448 on it -- and lost, 69 vs 61 us: the items of one point range then
+// no longer sit next to each other in the XCD map below, and the diagonal items' K_uf reads miss the L2 their chunk-mates filled.)
+struct SyrkGeom {
+    int row_lo, nrows;              // tile rows
+    int tile0, ntiles;              // their lower tiles
+    int chunk, nchunks;             // split of the point axis
+};
+__global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
+                                                     double* __restrict__ slabs, int Mp, int64_t N, SyrkGeom g, int64_t* stamps,
+                                                     long long* gate, long long gate_value) {
+    __shared__ double lds[2 * 2 * KB * PS];           // [buf][panel A|B][KB][PS]
+    TraceScope trace(64 + g.tile0);
+    stamp_enter(stamps);
+    // the last workgroup of this launch's single resident round is on a CU: whoever waited for that (the K_uu chain's first
+    // kernel) may take the CUs that are left
+    if (gate && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        __hip_atomic_store(gate, gate_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // XCD-aware block -> (tile, chunk) map: workgroups are dealt round-robin over the 8 XCDs, so ids congruent mod 8
+    // share an L2.  All tiles of one point-chunk read the same K_uf columns: the work items, ordered chunk-major, are cut
+    // into 8 contiguous runs, one per XCD, so that a chunk's columns are fetched into (at most two) L2s once.  Needs the
+    // item count to be a multiple of 8 (the host picks nchunks accordingly whenever there is enough work; speed only).
+    const int nitems = g.ntiles * g.nchunks;
+    int item = blockIdx.x;
+    if ((nitems & 7) == 0) item = (blockIdx.x & 7) * (nitems >> 3) + (blockIdx.x >> 3);
+    const int chunk_id = item / g.ntiles, tile_id = item % g.ntiles;
+    int I, J;
+    tile_from_index(g.tile0 + tile_id, I, J);
+    const int chunk = g.chunk;
+    const size_t slab = (size_t)chunk_id * g.ntiles + tile_id;
+    double* out = slabs + slab * (TB * TB);
+#ifdef SGP_SYRK_DIAG_SKIP
+    // two specialisations of the whole stage loop: with the choice inside the loop the kernel needed 148 VGPRs (2 waves per
+    // SIMD, i.e. two workgroups per CU and a second round: 95 instead of 58 us)
+    if (I == J) syrk_item<true>(Kuf, omega, out, lds, Mp, N, I, J, chunk_id, chunk);
+    else syrk_item<false>(Kuf, omega, out, lds, Mp, N, I, J, chunk_id, chunk);
+#else
+    syrk_item<false>(Kuf, omega, out, lds, Mp, N, I, J, chunk_id, chunk);
+#endif
     stamp_exit(stamps);
 }
 
@@ -547,13 +620,13 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ slabs, const double* __restrict__ bpart,
                                                   const double* __restrict__ data_scalars, double* __restrict__ stats,
-                                                  int Mp, int T, int row_lo, int tile0, int ntiles, int nchunks, int nblk, int d_out,
+                                                  int Mp, int T, SyrkGeom g, int nblk, int d_out,
                                                   int nscal, int do_b, int64_t* stamps, int* __restrict__ info_reset,
                                                   long long* start_word, long long start_value) {
     // grid (rows, T + do_b, 16): blocks (x, y < T, z) sum rows [4 z, 4 z + 4) of the slab tile (I, J) = (row_lo + x, y), I >= J --
     // one entry per thread, up to 12 chunk loads in flight (the kernel is latency-bound: the first version, 4 entries per
     // thread in rounds of 4 chunks on a quarter of the workgroups, took 12 us for 28 MB) -- and write both mirror images.
-    // `slabs` / `tile0` / `ntiles`: the slab area of this launch's tile group (k_syrk_stream).  Blocks with y == T (do_b) sum the
+    // `slabs` / `g`: the slab area and geometry of this launch's tile rows (k_syrk_stream).  Blocks with y == T (do_b) sum the
     // B partials and copy the data scalars.
     // NO LDS on purpose: in the overlapped sweep this kernel runs while the NEXT group's SYRK already holds every byte of LDS on
     // its CUs (4 x 40 KB); a block that needs none fits beside those workgroups.  Thread = (row il = tid >> 6, column j = tid & 63):
@@ -565,7 +638,8 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
     // bumped by every block: with __threadfence() each block writes the whole L2 back, which the next group's SYRK keeps filling
     // with dirty slab lines (70 us for this kernel instead of 5); with write-through stores 13 us for 21 tiles.  The kernel
     // boundary does it once: k_join_set behind this launch sets the group's word.)
-    TraceScope trace(128 + row_lo);
+    TraceScope trace(128 + g.row_lo);
+    const int row_lo = g.row_lo;
     // start_word (may be nullptr): this launch has started, i.e. the SYRK in front of it on this stream has drained -- the masked
     // statistics stream lets its next SYRK onto the chip at that moment (k_join_wait), not earlier (it would share the CUs with
     // the SYRK this launch sums up) and not much later (the CUs it is sized for would be taken by the chains' workgroups)
@@ -575,9 +649,10 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
     const int tid = threadIdx.x;
     if (J < T && I >= J) {
         const int il = tid >> 6, j = tid & 63;
-        const int t = I * (I + 1) / 2 + J - tile0;
+        const int t = I * (I + 1) / 2 + J - g.tile0;
         const double* base = slabs + (size_t)t * (TB * TB) + (z * 4 + il) * TB + j;
-        const size_t cstride = (size_t)ntiles * (TB * TB);
+        const size_t cstride = (size_t)g.ntiles * (TB * TB);
+        const int nchunks = g.nchunks;
         double s = 0.0;
         int c = 0;
         for (; c + 24 <= nchunks; c += 24) {                 // (24 loads in flight: the groups of the overlapped sweep have 48 - 72 chunks)
