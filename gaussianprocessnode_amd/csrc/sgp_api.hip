@@ -1707,7 +1707,7 @@ static int enqueue_theta_grad(sgp_handle* h, hipStream_t s) {
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGradM), sizeof(double) * 3 * (size_t)Mp * Mp));
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGradPart),
                             sizeof(double) * ((size_t)std::max(std::max(nblk_max, 1) * T, 512 + T) + (size_t)T * T) * GRAD_SLOTS));
-        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGrad), sizeof(double) * GRAD_SLOTS));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dGrad), sizeof(double) * 2 * GRAD_SLOTS));
     }
     double* dG = h->dGradM;
     double* dT1 = dG + (size_t)Mp * Mp;
@@ -1737,7 +1737,19 @@ static int enqueue_theta_grad(sgp_handle* h, hipStream_t s) {
     if (h->n > 0)
         hipLaunchKernelGGL(k_theta_grad_uf, dim3(h->nblk, T, KS), dim3(256), 0, s, dG, h->dKuf, h->dX, h->dXus, h->dYw,
                            h->has_omega ? h->dOmega : nullptr, h->dMu, h->dParams, part_uf, Mp, T, h->D, h->n);
-    hipLaunchKernelGGL(k_theta_grad_finish, dim3(1), dim3(256), 0, s, part_uf, n_uf, part_uu, T * T,
+    // Data-sharded run (an all-reduce hook is installed; the statistics in dStats are the reduced ones): the data half above used
+    // this rank's K_uf, X and y -- its fixed-order total (1 + D doubles) is summed over the ranks through the same hook; the
+    // K_uu half and the s_w term come from the reduced statistics and are replicated.  Every rank ends with the whole gradient.
+    const double* uf_src = part_uf;
+    int uf_blocks = n_uf;
+    if (h->allreduce) {
+        double* tot = h->dGrad + GRAD_SLOTS;
+        hipLaunchKernelGGL(k_theta_grad_fold, dim3(1), dim3(256), 0, s, (const double*)part_uf, n_uf, tot, h->D);
+        if (h->allreduce(h->allreduce_ctx, tot, GRAD_SLOTS, s)) return fail(h, SGP_ERR_HIP, "the all-reduce hook failed (theta gradient)");
+        uf_src = tot;
+        uf_blocks = 1;
+    }
+    hipLaunchKernelGGL(k_theta_grad_finish, dim3(1), dim3(256), 0, s, uf_src, uf_blocks, part_uu, T * T,
                        h->dStats + (size_t)Mp * Mp + (size_t)Mp * h->dout, h->dParams, h->dGrad, h->D, h->n_ell,
                        split ? (const long long*)(h->dJoin + WORD_GRAD) : (const long long*)nullptr, h->grad_epoch, h->spin_limit,
                        h->dInfo + 3);
@@ -1747,6 +1759,9 @@ static int enqueue_theta_grad(sgp_handle* h, hipStream_t s) {
 static int theta_objective_eval(sgp_handle* h, hipStream_t s, double* value) {
     enqueue_kuu(h, s);
     enqueue_local(h, s);
+    // (data-sharded run: the statistics re-formed at the new theta are this rank's -- sum them like a sweep's)
+    if (h->allreduce && h->allreduce(h->allreduce_ctx, h->dStats, h->stats_count, s))
+        return fail(h, SGP_ERR_HIP, "the all-reduce hook failed (theta objective)");
     h->main_prep_gen = 0;       // this evaluation opens phase stamps that no closing kernel folds: let the next sweep's k_prep_xu reset them
     const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
     hipLaunchKernelGGL(k_trace_kinv, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dTrace, M, Mp);
@@ -1777,9 +1792,11 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     hipStream_t s = h->own;
     // Same theta, data and noise as the sweep that produced q(v) -- the notebooks' call pattern
     // (experiments/regression_kin40k.ipynb:205-221 evaluates the gradient at the theta the sweep just used): K_uf, Psi2, b,
-    // K_uu^-1 and the traces are still on the device, nothing is recomputed.  (Not with externally reduced statistics:
-    // the objective is additive over shards only with each rank's LOCAL Psi2.)
-    bool fresh = !h->stats_dirty && h->swept_data_gen == h->data_gen && h->dStats == h->dStatsOwn &&
+    // K_uu^-1 and the traces are still on the device, nothing is recomputed.  With an all-reduce hook installed the statistics
+    // are the reduced ones and value and gradient are those of ALL shards (enqueue_theta_grad sums the data half through the
+    // hook).  A caller-bound buffer WITHOUT a hook may have been reduced outside the library: then the statistics are
+    // re-formed locally, as before.
+    bool fresh = !h->stats_dirty && h->swept_data_gen == h->data_gen && (h->dStats == h->dStatsOwn || h->allreduce) &&
                  h->swept_params.sigma2 == h->hParams->sigma2 && h->swept_params.jitter == h->hParams->jitter;
     // the objective is linear in w: a new mean(q_w) (classification_banana.ipynb passes the UPDATED q(w)) only rescales it
     const double wscale = fresh ? h->hParams->W[0] / h->swept_params.W[0] : 1.0;
@@ -1819,8 +1836,8 @@ extern "C" int sgp_train_begin(sgp_handle* h, const double* X, const double* y, 
     if (int qrc = quiesce(h)) return qrc;
     if (h->dout != 1) return fail(h, SGP_ERR_ARG, "sgp_train_begin: the theta objective is defined for UniSGP (d_out = 1)");
     if (h->cfg.flags & SGP_FLAG_GRAPH) return fail(h, SGP_ERR_ARG, "sgp_train_begin: not with SGP_FLAG_GRAPH (the window moves every step)");
-    if (h->allreduce || h->dStats != h->dStatsOwn)
-        return fail(h, SGP_ERR_ARG, "sgp_train_begin: the objective is additive over shards only with local statistics (no all-reduce hook, no bound buffer)");
+    // (a caller-bound statistics buffer is fine here: inside sgp_train_step nobody but the library -- through the all-reduce hook,
+    // if one is installed -- touches the statistics between the two halves of the sweep)
     if (!h->have_inducing) return fail(h, SGP_ERR_ARG, "sgp_train_begin: call sgp_set_inducing first");
     if (n_total < 1) return fail(h, SGP_ERR_ARG, "sgp_train_begin: empty training set");
     if (n_ell != 1 && n_ell != h->D) return fail(h, SGP_ERR_ARG, "sgp_train_begin: n_ell must be 1 or D");
@@ -1869,7 +1886,7 @@ extern "C" int sgp_train_begin(sgp_handle* h, const double* X, const double* y, 
 extern "C" int sgp_train_step(sgp_handle* h, int64_t offset, int64_t n, int32_t flags) {
     if (!h) return SGP_ERR_ARG;
     if (!h->training) return fail(h, SGP_ERR_ARG, "sgp_train_step: call sgp_train_begin first");
-    if (offset < 0 || n < 1 || offset + n > h->train_N || n > h->n_max)
+    if (offset < 0 || n < (h->allreduce ? 0 : 1) || offset + n > h->train_N || n > h->n_max)
         return fail(h, SGP_ERR_ARG, "sgp_train_step: window outside the resident set or larger than n_max");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = h->own;
@@ -1886,8 +1903,9 @@ extern "C" int sgp_train_step(sgp_handle* h, int64_t offset, int64_t n, int32_t 
     int rc = set_point_count(h, n);
     if (!rc) {
         hipLaunchKernelGGL(k_train_window, dim3(1), dim3(256), 0, s, (const double*)h->dY, n, h->dDataScal, (int)SGP_S_COUNT + 1);
-        rc = sgp_sweep_local(h, nullptr);                      // (the sweep's own entry points: the product path here too)
-        if (!rc) rc = sgp_sweep_finish(h, nullptr);
+        // (the sweep's own entry point: the product path here too.  Data-sharded: the window is this rank's slice of the
+        // minibatch, sgp_sweep sums the statistics -- the window's data scalars ride in the same buffer -- through the hook)
+        rc = sgp_sweep(h, nullptr);
         if (!rc) rc = sgp_carry_posterior(h, nullptr);
         if (!rc && learn) rc = enqueue_theta_grad(h, s);
         // (without a learning step the kernel only keeps the books: a failed factorisation is counted either way)

@@ -2618,6 +2618,28 @@ __global__ void __launch_bounds__(256) k_theta_grad_uu(const double* __restrict_
     }
 }
 
+// tot[slot] = fixed-order sum of the data half's block partials: in a data-sharded run this small vector (not the partials) is
+// what the ranks sum-all-reduce before k_theta_grad_finish -- the K_uu half and the s_w term come from the REDUCED statistics
+// and are the same on every rank already (helper_functions/derivative_helper.jl:29-38 is a sum over points)
+__global__ void __launch_bounds__(256) k_theta_grad_fold(const double* __restrict__ part_uf, int n_uf, double* __restrict__ tot, int D) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    double acc[GRAD_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < GRAD_SLOTS; ++sl) acc[sl] = 0.0;
+    for (int b = tid; b < n_uf; b += 256) {
+#pragma unroll
+        for (int sl = 0; sl < GRAD_SLOTS; ++sl)
+            if (sl <= D) acc[sl] += part_uf[(size_t)b * GRAD_SLOTS + sl];
+    }
+#pragma unroll
+    for (int sl = 0; sl < GRAD_SLOTS; ++sl) {
+        double v = 0.0;
+        if (sl <= D) v = block_sum(acc[sl], red);        // (uniform)
+        if (tid == 0) tot[sl] = v;
+    }
+}
+
 // grad[0] = df/dsigma2, grad[1 ..] = df/dell (n_ell = 1: one shared lengthscale, else one per dimension)
 __global__ void __launch_bounds__(256) k_theta_grad_finish(const double* __restrict__ part_uf, int n_uf,
                                                            const double* __restrict__ part_uu, int n_uu,

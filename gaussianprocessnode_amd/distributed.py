@@ -98,14 +98,28 @@ class HipEngine:
     def sweep_finish(self):
         self.dev.sweep_finish(self.stream.cuda_stream)
 
-    def install_allreduce(self, reduce_fn):
-        """Make the exchange step part of the library's `sgp_sweep` (include/sgp_hip.h, sgp_set_allreduce): `reduce_fn()` must
-        all-reduce `self.stats` in place, ordered on `self.stream`."""
-        ptr = self.stats.data_ptr()
+    def device_view(self, ptr: int, count: int):
+        """A float64 torch tensor over `count` doubles of device memory at `ptr` (no copy; __cuda_array_interface__)."""
+        if ptr == self.stats.data_ptr() and count == self.stats.numel():
+            return self.stats
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 3,
+                                        "strides": None}
+        return self.torch.as_tensor(_View(), device=self.stats.device)
+
+    def install_allreduce(self, reduce_tensor):
+        """Make the exchange step part of the library's calls (include/sgp_hip.h, sgp_set_allreduce): `reduce_tensor(t)` must
+        sum-all-reduce the torch tensor `t` in place on the CURRENT torch stream.  The library hands the hook a device buffer
+        and the stream it wants the collective on: the packed statistics inside `sgp_sweep` / `sgp_train_step`, the data
+        half of the theta gradient (33 doubles) inside `sgp_theta_objective` / `sgp_train_step`."""
+        torch = self.torch
 
         def hook(buf, count, stream):
-            assert buf == ptr and count == self.stats.numel(), "the library reduces the buffer bound with bind_stats"
-            reduce_fn()
+            t = self.device_view(buf, count)
+            ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=t.device)) if stream else self.stream_context()
+            with ctx:
+                reduce_tensor(t)
         self.dev.set_allreduce(hook)
         self._hooked = True
 
@@ -118,9 +132,11 @@ class HipEngine:
     def synchronize(self):
         self.torch.cuda.synchronize()
 
+    reduces_theta_objective = True       # with the hook installed sgp_theta_objective returns the sum over all shards
+
     def theta_objective_local(self, n_ell=None):
-        """This shard's part of the hyper-parameter objective and of its gradient (both are additive over shards).  The
-        device re-evaluates its LOCAL statistics for this: the bound buffer holds the all-reduced ones after a sweep."""
+        """The hyper-parameter objective and its gradient at the last sweep's q(v): with the all-reduce hook installed the
+        value and the gradient of ALL shards (summed inside the library), without it this shard's alone."""
         return self.dev.theta_objective(want_grad=True, n_ell=n_ell)
 
 
@@ -144,16 +160,29 @@ class ShardedSweep:
         # collective installed once; the others are driven half by half.
         self.hooked = (self.world > 1 or force_hook) and hasattr(engine, "install_allreduce")
         if self.hooked:
-            engine.install_allreduce(self._reduce)
+            engine.install_allreduce(self._reduce_tensor)
+
+    def _reduce_tensor(self, t):
+        """The collective of the library's hook: sum `t` over the ranks in place, on the current stream (HipEngine enters the
+        stream the library named before it calls this)."""
+        if self.backend == "gloo" and t.is_cuda:
+            # (rehearsal on a one-GPU box: gloo carries host tensors)
+            import torch
+            torch.cuda.current_stream().synchronize()
+            host = t.cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+            return
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def _reduce(self):
-        # issued inside the engine's stream context: the collective is ordered after the local kernels and before the
-        # replicated tail on that stream
+        # engines that are driven half by half (sweep_local / sweep_finish): the statistics tensor, inside the engine's stream
+        # context -- the collective is ordered after the local kernels and before the replicated tail on that stream
         ctx = self.engine.stream_context() if hasattr(self.engine, "stream_context") else None
         if ctx is not None:
             ctx.__enter__()
         try:
-            self.dist.all_reduce(self.engine.stats, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._reduce_tensor(self.engine.stats)
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
@@ -169,9 +198,14 @@ class ShardedSweep:
 
     def theta_objective(self, n_ell=None):
         """neg_log_backwardmess_fast and its gradient over ALL shards (helper_functions/derivative_helper.jl:23-39,55-63):
-        each rank contributes its points' terms at the replicated q(v); one small all-reduce (2 + n_ell doubles)."""
+        each rank contributes its points' terms at the replicated q(v).  With the library's hook installed the sum happens
+        inside `sgp_theta_objective` (the data half of the gradient through the hook; value, K_uu half and s_w term from the
+        reduced statistics), nothing is recomputed and every rank gets the whole result; engines without it add one small
+        all-reduce here."""
         import numpy as np
         value, grad = self.engine.theta_objective_local(n_ell)
+        if self.hooked and getattr(self.engine, "reduces_theta_objective", False):
+            return float(value), np.asarray(grad, dtype=np.float64).copy()
         packed = np.concatenate([[value], np.asarray(grad, dtype=np.float64)])
         if self.world > 1:
             import torch
@@ -181,3 +215,36 @@ class ShardedSweep:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
             packed = t.cpu().numpy()
         return float(packed[0]), packed[1:].copy()
+
+
+class ShardedDevice:
+    """One rank of a data-sharded run behind the `SGPDevice` interface the drivers use (`train.perform_inference`, host- or
+    device-paced): the caller hands every rank the SAME minibatches; this wrapper keeps the rank's slice of each and lets the
+    library sum statistics and gradients over the ranks through its all-reduce hook, so that every rank ends a step with the
+    same q(v) and the same theta.  The reference has no counterpart (single process); the additivity it relies on is the
+    N-fold product of GPnode/UniSGPnode.jl:62-63 and the sum over points of helper_functions/derivative_helper.jl:29-38.
+
+    `dev`: the rank's device (an `SGPDevice`, or a test double with the same methods); `rank`, `world`: the partition.
+    The hook is the caller's business (`HipEngine.install_allreduce` / `ShardedSweep` for torch.distributed, `sgp_use_rccl`
+    for a bare communicator, a test double)."""
+
+    def __init__(self, dev, rank: int, world: int):
+        self.dev, self.rank, self.world = dev, int(rank), int(world)
+
+    def __getattr__(self, name):            # everything that is replicated (setters of theta, prior, noise; getters) passes through
+        return getattr(self.dev, name)
+
+    def _slice(self, n):
+        return shard_bounds(n, self.world, self.rank)
+
+    def set_data(self, X, y_mean, y_var=None, weights=None, n_nodes=None):
+        X = np.asarray(X, dtype=np.float64)
+        n = len(X) if X.ndim > 1 else len(np.atleast_1d(y_mean))
+        lo, hi = self._slice(n)
+        cut = lambda a: None if a is None else np.asarray(a)[lo:hi]
+        nn = None if n_nodes is None else float(n_nodes) * (hi - lo) / max(n, 1)
+        self.dev.set_data(X.reshape(n, -1)[lo:hi], cut(y_mean), cut(y_var), cut(weights), nn)
+
+    def train_step(self, offset, n, learn=True, reset_prior=False):
+        lo, hi = self._slice(n)
+        self.dev.train_step(offset + lo, hi - lo, learn, reset_prior)

@@ -48,10 +48,49 @@ class OracleDevice:
         self.w = float(np.asarray(W).ravel()[0])
         self.E_logw = math.log(self.w) if E_log_w is None else E_log_w
 
+    def set_allreduce_array(self, fn):
+        """Test double of the C ABI's all-reduce hook (include/sgp_hip.h, sgp_set_allreduce): fn(array) sums a float64 NumPy array
+        over the ranks in place.  With it the sweep reduces the packed statistics and `theta_objective` its value and gradient."""
+        self._reduce = fn
+
     def sweep(self, stream=0):
         self.calls.append(("sweep", self.n))
-        self.res = O.vmp_sweep(self.Xu, self.X, self.y, self.vy, self.s2, self.ell, self.w, E_logw=self.E_logw,
-                               jitter=self.jitter, Lambda0=self.Lambda0, xi0=self.xi0)
+        if getattr(self, "_reduce", None) is None:
+            self.res = O.vmp_sweep(self.Xu, self.X, self.y, self.vy, self.s2, self.ell, self.w, E_logw=self.E_logw,
+                                   jitter=self.jitter, Lambda0=self.Lambda0, xi0=self.xi0)
+            return
+        # data-sharded: local statistics in the device's packed layout -> hook -> replicated tail (sgp_sweep with a hook)
+        if self.n > 0:
+            st = O.suff_stats(self.Xu, self.X, self.y, self.vy, self.s2, self.ell)
+            buf = pack_stats(st.Psi2, st.b, float(st.s_yy[0, 0]), st.s_kk / self.s2, st.n)
+        else:
+            buf = np.zeros(stats_count(self.M, 1))
+        self._reduce(buf)
+        Psi2, B, s_yy, s_w, n, _ = unpack_stats(buf, self.M, 1)
+        st = O.SuffStats(Psi2, B, np.array([[s_yy]]), self.s2 * s_w, n)
+        self.res = O.vmp_sweep(self.Xu, None, None, None, self.s2, self.ell, self.w, E_logw=self.E_logw, jitter=self.jitter,
+                               Lambda0=self.Lambda0, xi0=self.xi0, stats=st)
+
+    def carry_posterior(self, stream=0):
+        """prior <- posterior in natural form (sgp_carry_posterior)"""
+        self.Lambda0 = self.Lambda0 + self.w * self.res.stats.Psi2
+        self.xi0 = self.xi0 + self.w * np.ravel(self.res.stats.b)
+
+    def theta_objective(self, want_grad=False, n_ell=None):
+        """neg_log_backwardmess_fast at the current kernel with q(v) of the last sweep (helper_functions/derivative_helper.jl:23-39);
+        gradient by central differences of this shard's terms, summed over the ranks when a hook is installed."""
+        r = self.res
+        ell = np.atleast_1d(self.ell).astype(np.float64)
+
+        def f(p):
+            if self.n == 0:
+                return 0.0
+            return O.theta_objective(self.Xu, self.X, self.y, p[0], p[1:], r.mu_v, r.Uv, self.w, jitter=self.jitter)
+        p0 = np.concatenate([[self.s2], ell])
+        out = np.array([f(p0)] + ([(f(p0 + 1e-6 * e) - f(p0 - 1e-6 * e)) / 2e-6 for e in np.eye(len(p0))] if want_grad else []))
+        if getattr(self, "_reduce", None) is not None:
+            self._reduce(out)
+        return (float(out[0]), out[1:].copy()) if want_grad else float(out[0])
 
     def posterior(self, want_cov=True, want_uv=True):
         return self.res.mu_v, self.res.Sigma_v, self.res.Uv
@@ -102,7 +141,7 @@ class OracleShardEngine:
     def sweep(self):
         self.sweep_local()
         if getattr(self, "_hook", None) is not None:
-            self._hook()
+            self._hook(self.stats)             # (HipEngine's form: the hook is handed the tensor to reduce)
             self.hook_calls += 1
         self.sweep_finish()
 

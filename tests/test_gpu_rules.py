@@ -518,3 +518,47 @@ def test_pointmass_rules_stand_alone(standalone):
         I2 = mu_y ** 2 + extra - 2.0 * mu_y * (B @ mu_v).item() + (B @ s["R_v"] @ B.T).item()
         nu = U.rule_w(q_out, PointMass(1.0), s["q_v"], s["q_theta"], s["meta"])
         assert nu.shape() == 1.5 and math.isclose(nu.rate(), 0.5 * (I1 + I2), rel_tol=1e-9)
+
+
+@pytest.mark.parametrize("device_paced", [True, False])
+def test_sharded_training_step_through_the_allreduce_hook(device_paced):
+    """The data-sharded training step on ONE GPU: the hook stands in for a second rank that holds the same slice of every
+    minibatch -- it doubles whatever the library hands it (the packed statistics inside the sweep, the data half of the theta
+    gradient), which is what a sum-all-reduce over two such ranks leaves.  Reference: the same loop on a single rank whose
+    minibatches hold every point twice.  Both pacings (sgp_train_* with the hook inside sgp_train_step; setters +
+    sgp_theta_objective with the hook inside it).  Loop: experiments/regression_kin40k.ipynb:196-230; additivity:
+    GPnode/UniSGPnode.jl:62-63, helper_functions/derivative_helper.jl:29-38."""
+    import torch
+    import gaussianprocessnode_amd as G
+    from gaussianprocessnode_amd.distributed import HipEngine, ShardedDevice
+    from gaussianprocessnode_amd.train import AdaMax, perform_inference
+    rng = np.random.default_rng(5)
+    N, M, D, bs = 240, 20, 3, 60
+    X = rng.uniform(-1.7, 1.7, (N, D))
+    Xu = X[rng.permutation(N)[:M]].copy()
+    y = np.sin(X.sum(axis=1)) + 0.1 * rng.normal(size=N)
+    theta0 = O.invsoftplus(np.array([1.0, 1.5, 1.2, 0.8]))
+    # single rank, every minibatch = its points twice
+    Xd = np.concatenate([np.concatenate([X[o:o + bs], X[o:o + bs]]) for o in range(0, N, bs)])
+    yd = np.concatenate([np.concatenate([y[o:o + bs], y[o:o + bs]]) for o in range(0, N, bs)])
+    with G.SGPDevice(2 * bs, M, D) as one:
+        qv1, th1 = perform_inference(theta0, Xd, yd, Xu, one, batch_size=2 * bs, epochs=2, w_val=40.0, jitter=1e-8,
+                                     optimizer=AdaMax(eta=0.01), device_paced=device_paced)
+    # "rank 0 of 2" with the doubling hook
+    eng = HipEngine(bs, M, D, 1, device=0)
+    calls = []
+
+    def double(t):
+        calls.append(t.numel())
+        t.mul_(2.0)
+    eng.install_allreduce(double)
+    qv2, th2 = perform_inference(theta0, X, y, Xu, ShardedDevice(eng.dev, 0, 1), batch_size=bs, epochs=2, w_val=40.0, jitter=1e-8,
+                                 optimizer=AdaMax(eta=0.01), device_paced=device_paced)
+    torch.cuda.synchronize()
+    eng.dev.close()
+    steps = 2 * (N // bs)
+    assert calls.count(eng.stats.numel()) == steps and len(calls) == 2 * steps        # statistics + gradient, once per minibatch each
+    assert np.max(np.abs(th2 - th1)) < 1e-10 * np.max(np.abs(th1)), (th1, th2)
+    assert not np.allclose(th1, theta0)
+    assert np.linalg.norm(qv2.m - qv1.m) < 1e-8 * np.linalg.norm(qv1.m)
+    assert np.linalg.norm(qv2.S - qv1.S) < 1e-8 * np.linalg.norm(qv1.S)

@@ -183,6 +183,62 @@ def test_sharded_sweep_world_size_2_gloo(tmp_path):
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 
 
+TRAIN_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["REPO_ROOT"])
+import torch
+import torch.distributed as dist
+from gaussianprocessnode_amd.distributed import ShardedDevice
+from gaussianprocessnode_amd.train import perform_inference
+from tests.cpu_engine import OracleDevice
+
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(11)
+N, M, D, B = 96, 10, 2, 24
+X = rng.uniform(-1.7, 1.7, (N, D)); Xu = X[rng.permutation(N)[:M]].copy(); y = np.sin(X.sum(1)) + 0.1 * rng.normal(size=N)
+theta0 = np.array([0.3, 0.6, 0.2])
+
+def reduce(a):                      # the hook's collective: every rank hands in its part, every rank gets the sum
+    t = torch.from_numpy(a)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+dev = OracleDevice(B, M, D)
+dev.set_allreduce_array(reduce)
+sharded = ShardedDevice(dev, rank, world)
+qv, theta = perform_inference(theta0, X, y, Xu, sharded, batch_size=B, epochs=2, w_val=50.0, jitter=1e-8, device_paced=False)
+# every rank swept only its slice of every minibatch ...
+assert [c for c in dev.calls if c[0] == "set_data"][0][1] == B // world
+# ... and all ranks end with the same theta and q(v)
+both = [None] * world
+dist.all_gather_object(both, (theta, qv.m))
+assert all(np.array_equal(both[0][0], b[0]) and np.array_equal(both[0][1], b[1]) for b in both)
+if rank == 0:
+    one = OracleDevice(B, M, D)
+    qv1, theta1 = perform_inference(theta0, X, y, Xu, one, batch_size=B, epochs=2, w_val=50.0, jitter=1e-8, device_paced=False)
+    assert np.max(np.abs(theta - theta1)) < 1e-10 * np.max(np.abs(theta1)), (theta, theta1)
+    assert np.linalg.norm(qv.m - qv1.m) < 1e-8 * np.linalg.norm(qv1.m)
+    assert not np.array_equal(theta1, theta0)
+print(f"rank {rank} ok", flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_training_world_size_2_gloo(tmp_path):
+    """The training loop of experiments/regression_kin40k.ipynb:196-230 data-sharded over two processes: every rank sweeps its
+    slice of each minibatch, the statistics and the theta gradient are summed through the all-reduce hook, AdaMax runs
+    replicated -- theta must come out as in the single-rank loop."""
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER)
+    env = dict(os.environ, REPO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
 # ------------------------------------------------------------------------------------------------
 # the reference's toy experiments on its own saved data (tests/golden/toy*_fixture.npz), host loops over the CPU engine
 # ------------------------------------------------------------------------------------------------
