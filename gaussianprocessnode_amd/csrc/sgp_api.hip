@@ -162,6 +162,9 @@ struct sgp_handle {
     int64_t stats_count = 0;
     size_t slab_capacity = 0;
     Graph gLocal, gFinish, gFinish2, gKuu;
+    double* dPack = nullptr;       // exchange buffer of data-sharded sweeps: [lower tiles | B | scalars] (allocated with the hook)
+    int64_t pack_count = 0;
+    bool pack_now = false;         // the statistics being enqueued go to dPack (exchange_stats follows)
     sgp_allreduce_fn allreduce = nullptr;   // the multi-GPU exchange step of sgp_sweep (see include/sgp_hip.h)
     void* allreduce_ctx = nullptr;
     void* rccl_comm = nullptr;
@@ -587,7 +590,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
                     h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
                     h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals, h->dUvWork,
                     h->dGradM, h->dGradPart, h->dGrad, h->dCall, h->dSaccK,
-                    h->dTrainX, h->dTrainY, h->dTrain, h->dTrainParams, h->dJoin};
+                    h->dTrainX, h->dTrainY, h->dTrain, h->dTrainParams, h->dJoin, h->dPack};
     for (void* b : bufs) if (b) hipFree(b);
 #ifdef SGP_WITH_PERSISTENT_CHAIN
     void* cbufs[] = {h->dChainFlags[0], h->dChainFlags[1],
@@ -973,9 +976,11 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     }
     SyrkGeom ga = h->geom;
     if (h->n <= 0) { ga = syrk_geometry(0, T, h->num_cus, 0); }       // no data: zero chunks, the statistics are zero
-    hipLaunchKernelGGL(k_assemble, dim3(T, T + 1, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal, h->dStats, Mp, T, ga,
-                       h->n > 0 ? h->nblk : 0, h->dout,
-                       SGP_S_COUNT + h->dout * h->dout, 1, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL, h->dInfo + 1, (long long*)nullptr, 0LL);
+    // (data-sharded sweeps write the exchange buffer instead: lower tiles only, see exchange_stats)
+    hipLaunchKernelGGL(k_assemble, dim3(T, T + 1, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal,
+                       h->pack_now ? h->dPack : h->dStats, Mp, T, ga, h->n > 0 ? h->nblk : 0, h->dout,
+                       SGP_S_COUNT + h->dout * h->dout, 1, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL, h->dInfo + 1, (long long*)nullptr, 0LL,
+                       h->pack_now ? 1 : 0);
 }
 
 // The statistics of an overlapped sweep (see plan_overlap): the same kernels, the SYRK and the assembly once per tile-row group.
@@ -1015,7 +1020,7 @@ static void enqueue_stats_overlapped(sgp_handle* h, hipStream_t own) {
         hipLaunchKernelGGL(k_assemble, dim3(G.nrows, T + (g == 0 ? 1 : 0), 16), dim3(256), 0, s, h->dSlabs + G.slab_off, h->dBpart,
                            h->dDataScal, h->dStats, Mp, T, G.geom, h->nblk, h->dout,
                            SGP_S_COUNT + h->dout * h->dout, g == 0 ? 1 : 0, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL,
-                           g == 0 ? h->dInfo + 1 : (int*)nullptr, g == 0 ? h->dJoin + WORD_ASM0 : (long long*)nullptr, h->stat_epoch);
+                           g == 0 ? h->dInfo + 1 : (int*)nullptr, g == 0 ? h->dJoin + WORD_ASM0 : (long long*)nullptr, h->stat_epoch, 0);
         if (G.masked || g1_mode == 1) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_GROUP0 + g, h->stat_epoch);
     }
 }
@@ -1241,25 +1246,44 @@ extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
     return 0;
 }
 
+// The one exchange step of a data-sharded sweep: the ranks sum the exchange buffer k_assemble just wrote -- the LOWER tiles of
+// Psi2, B and the scalars: 1.18 MB at M = 512 where the full symmetric statistics are 2.10 MB -- through the hook, on the sweep's
+// stream (the K_uu chain keeps running on the side stream meanwhile); one more launch expands the sum into the statistics buffer.
+static int exchange_stats(sgp_handle* h, hipStream_t s) {
+    if (h->allreduce(h->allreduce_ctx, h->dPack, h->pack_count, s)) return fail(h, SGP_ERR_HIP, "the all-reduce hook failed (statistics)");
+    hipLaunchKernelGGL(k_unpack_stats, dim3(h->ntiles + 1), dim3(256), 0, s, (const double*)h->dPack, h->dStats, h->Mp, h->T,
+                       (int)(h->Mp * h->dout + SGP_S_COUNT + h->dout * h->dout));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 extern "C" int sgp_sweep(sgp_handle* h, void* stream) {
     if (!h) return SGP_ERR_ARG;
     // single GPU, the library's own streams, a problem that qualifies: statistics and Lambda chain overlapped
     const bool overlapped = h->overlap && !h->allreduce && !stream && h->n > 0 && !h->training;
+    h->pack_now = h->allreduce != nullptr;
     int rc = sweep_local_impl(h, stream, overlapped);
+    h->pack_now = false;
     if (rc) return rc;
     if (h->allreduce) {
-        // the one exchange step: sum the packed statistics over the ranks, on the sweep's stream (the K_uu chain keeps
-        // running on the side stream meanwhile)
-        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
-        rc = h->allreduce(h->allreduce_ctx, h->dStats, h->stats_count, s);
-        if (rc) return fail(h, SGP_ERR_HIP, "sgp_sweep: the all-reduce hook failed");
+        rc = exchange_stats(h, stream ? static_cast<hipStream_t>(stream) : h->own);
+        if (rc) return rc;
     }
     return sgp_sweep_finish(h, stream);
+}
+
+static int ensure_pack(sgp_handle* h) {
+    if (h->dPack) return 0;
+    h->pack_count = (int64_t)h->ntiles * TB * TB + (int64_t)h->Mp * h->dout + SGP_S_COUNT + (int64_t)h->dout * h->dout;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->dPack), sizeof(double) * (size_t)h->pack_count));
+    return 0;
 }
 
 extern "C" int sgp_set_allreduce(sgp_handle* h, sgp_allreduce_fn fn, void* ctx) {
     if (!h) return SGP_ERR_ARG;
     if (int qrc = quiesce(h)) return qrc;
+    if (int prc = ensure_pack(h)) return prc;
     h->allreduce = fn;
     h->allreduce_ctx = ctx;
     return 0;
@@ -1277,6 +1301,7 @@ extern "C" int sgp_use_rccl(sgp_handle* h, void* nccl_comm) {
     if (!g_nccl_allreduce) g_nccl_allreduce = reinterpret_cast<nccl_allreduce_t>(dlsym(RTLD_DEFAULT, "ncclAllReduce"));
     if (!g_nccl_allreduce) return fail(h, SGP_ERR_ARG, "sgp_use_rccl: no ncclAllReduce in this process (load librccl first)");
     if (int qrc = quiesce(h)) return qrc;
+    if (int prc = ensure_pack(h)) return prc;
     h->rccl_comm = nccl_comm;
     h->allreduce = rccl_hook;
     h->allreduce_ctx = h;
@@ -1758,10 +1783,12 @@ static int enqueue_theta_grad(sgp_handle* h, hipStream_t s) {
 
 static int theta_objective_eval(sgp_handle* h, hipStream_t s, double* value) {
     enqueue_kuu(h, s);
+    h->pack_now = h->allreduce != nullptr;
     enqueue_local(h, s);
+    h->pack_now = false;
     // (data-sharded run: the statistics re-formed at the new theta are this rank's -- sum them like a sweep's)
-    if (h->allreduce && h->allreduce(h->allreduce_ctx, h->dStats, h->stats_count, s))
-        return fail(h, SGP_ERR_HIP, "the all-reduce hook failed (theta objective)");
+    if (h->allreduce)
+        if (int xrc = exchange_stats(h, s)) return xrc;
     h->main_prep_gen = 0;       // this evaluation opens phase stamps that no closing kernel folds: let the next sweep's k_prep_xu reset them
     const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp;
     hipLaunchKernelGGL(k_trace_kinv, dim3(TRACE_BLOCKS), dim3(256), 0, s, h->dStats, h->dKinv, h->dTrace, M, Mp);

@@ -622,12 +622,15 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
                                                   const double* __restrict__ data_scalars, double* __restrict__ stats,
                                                   int Mp, int T, SyrkGeom g, int nblk, int d_out,
                                                   int nscal, int do_b, int64_t* stamps, int* __restrict__ info_reset,
-                                                  long long* start_word, long long start_value) {
+                                                  long long* start_word, long long start_value, int packed) {
     // grid (rows, T + do_b, 16): blocks (x, y < T, z) sum rows [4 z, 4 z + 4) of the slab tile (I, J) = (row_lo + x, y), I >= J --
     // one entry per thread, up to 12 chunk loads in flight (the kernel is latency-bound: the first version, 4 entries per
     // thread in rounds of 4 chunks on a quarter of the workgroups, took 12 us for 28 MB) -- and write both mirror images.
     // `slabs` / `g`: the slab area and geometry of this launch's tile rows (k_syrk_stream).  Blocks with y == T (do_b) sum the
     // B partials and copy the data scalars.
+    // packed (data-sharded sweeps): `stats` is the exchange buffer [lower tiles, row-major triangle, 64 x 64 column-major each |
+    // B | scalars] -- what the ranks sum-all-reduce (1.18 MB at M = 512 instead of the 2.10 MB of the full symmetric matrix);
+    // k_unpack_stats expands the reduced buffer into the layout the rest of the sweep reads.
     // NO LDS on purpose: in the overlapped sweep this kernel runs while the NEXT group's SYRK already holds every byte of LDS on
     // its CUs (4 x 40 KB); a block that needs none fits beside those workgroups.  Thread = (row il = tid >> 6, column j = tid & 63):
     // a wave reads one 512-byte slab row per chunk and writes the mirror image (the upper triangle -- the part the Lambda chain
@@ -677,13 +680,16 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
             for (int u = 0; u < 4; ++u) s += v[u];
         }
         for (; c < nchunks; ++c) s += base[(size_t)c * cstride];
-        stats[(size_t)(J * TB + j) * Mp + I * TB + z * 4 + il] = s;
-        if (I != J) stats[(size_t)(I * TB + z * 4 + il) * Mp + J * TB + j] = s;
+        if (packed) stats[(size_t)(I * (I + 1) / 2 + J) * (TB * TB) + j * TB + z * 4 + il] = s;
+        else {
+            stats[(size_t)(J * TB + j) * Mp + I * TB + z * 4 + il] = s;
+            if (I != J) stats[(size_t)(I * TB + z * 4 + il) * Mp + J * TB + j] = s;
+        }
     }
     // B = sum of the per-block partials: the blocks of the extra grid row take the (row block, output) pairs; 4 adjacent lanes
     // per entry walk the partials with a stride of 4 (16 independent loads in flight) and are combined in a fixed order
     if (do_b && J == T) {
-        double* B = stats + (size_t)Mp * Mp;
+        double* B = stats + (packed ? (size_t)(T * (T + 1) / 2) * (TB * TB) : (size_t)Mp * Mp);
         const int m = tid >> 2, part = tid & 3;
         const int bid = blockIdx.x * 16 + z, nb = gridDim.x * 16;
         for (int pair = bid; pair < T * d_out; pair += nb) {
@@ -712,6 +718,33 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
     }
     if (info_reset && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *info_reset = 0;
     stamp_exit(stamps);
+}
+
+// the reduced exchange buffer (k_assemble, packed) -> the packed statistics layout [Psi2 full symmetric | B | scalars]
+__global__ void __launch_bounds__(256) k_unpack_stats(const double* __restrict__ pack, double* __restrict__ stats, int Mp, int T,
+                                                      int tail) {
+    // grid (T (T + 1) / 2 + 1): block t < ntiles copies lower tile t to both mirror positions; the last block copies B and the scalars
+    const int ntiles = T * (T + 1) / 2, tid = threadIdx.x;
+    if ((int)blockIdx.x == ntiles) {
+        for (int e = tid; e < tail; e += 256) stats[(size_t)Mp * Mp + e] = pack[(size_t)ntiles * (TB * TB) + e];
+        return;
+    }
+    int I, J;
+    tile_from_index(blockIdx.x, I, J);
+    __shared__ double tile[TB * LT];
+    const double* src = pack + (size_t)blockIdx.x * (TB * TB);
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int j = e >> 6, i = e & 63;                    // element (i, j) of the tile: column-major in the exchange buffer
+        const double v = src[e];
+        stats[(size_t)(J * TB + j) * Mp + I * TB + i] = v;
+        tile[i * LT + j] = v;
+    }
+    if (I == J) return;
+    __syncthreads();
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int i = e >> 6, j = e & 63;                    // the mirror image: 64 consecutive j per row i
+        stats[(size_t)(I * TB + i) * Mp + J * TB + j] = tile[i * LT + j];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

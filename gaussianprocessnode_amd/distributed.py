@@ -70,6 +70,16 @@ def unpack_stats(buf, m: int, d_out: int = 1):
     return Psi2, B, float(sc[0]), float(sc[1]), float(sc[2]), Ryy
 
 
+def device_tensor(ptr: int, count: int, device="cuda"):
+    """A float64 torch tensor over `count` doubles of device memory at `ptr` (no copy; __cuda_array_interface__) -- how a Python
+    all-reduce hook looks at the buffer the library hands it."""
+    import torch
+
+    class _View:
+        __cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 3, "strides": None}
+    return torch.as_tensor(_View(), device=device)
+
+
 class HipEngine:
     """This rank's shard on its MI355X: local statistics and the replicated tail through the C ABI."""
 
@@ -99,14 +109,9 @@ class HipEngine:
         self.dev.sweep_finish(self.stream.cuda_stream)
 
     def device_view(self, ptr: int, count: int):
-        """A float64 torch tensor over `count` doubles of device memory at `ptr` (no copy; __cuda_array_interface__)."""
         if ptr == self.stats.data_ptr() and count == self.stats.numel():
             return self.stats
-
-        class _View:
-            __cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 3,
-                                        "strides": None}
-        return self.torch.as_tensor(_View(), device=self.stats.device)
+        return device_tensor(ptr, count, self.stats.device)
 
     def install_allreduce(self, reduce_tensor):
         """Make the exchange step part of the library's calls (include/sgp_hip.h, sgp_set_allreduce): `reduce_tensor(t)` must

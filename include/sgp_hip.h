@@ -132,7 +132,14 @@ int sgp_sweep(sgp_handle* h, void* stream);                 /* local + [all-redu
  * inside the library, on `stream`; the K_uu chain runs beside all three on the library's side stream.
  * The hook must enqueue an in-place sum-all-reduce of `count` doubles at `stats_dev` on `stream` and return 0; it may be
  * RCCL's ncclAllReduce (sgp_use_rccl), MPI on device buffers, torch.distributed through a ctypes callback, or a test double.
- * fn = NULL removes the hook (single GPU). */
+ * fn = NULL removes the hook (single GPU).
+ * What the hook is handed (always a buffer owned by the library, never the one of sgp_bind_stats):
+ *   - inside sgp_sweep / sgp_train_step: the EXCHANGE buffer [lower 64 x 64 tiles of Psi2 | B | scalars] -- T (T + 1) / 2 tiles with
+ *     T = ceil(M / 64): 1.18 MB at M = 512 where the full symmetric statistics are 2.10 MB; the sum is expanded into the
+ *     statistics layout of sgp_stats_layout afterwards;
+ *   - inside sgp_theta_objective / sgp_train_step: the data half of the theta gradient, 33 doubles (the K_uu half and the s_w
+ *     term come from the reduced statistics).  With a hook installed value and gradient are those of ALL shards on every
+ *     rank and nothing is recomputed. */
 typedef int (*sgp_allreduce_fn)(void* ctx, void* stats_dev, int64_t count, void* stream);
 int sgp_set_allreduce(sgp_handle* h, sgp_allreduce_fn fn, void* ctx);
 /* Convenience: all-reduce with RCCL on the communicator `nccl_comm` (an ncclComm_t created by the host program, e.g. with

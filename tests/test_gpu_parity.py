@@ -820,9 +820,11 @@ def test_theta_objective_gradient_length_follows_the_kernel(G):
 
 def test_sweep_with_the_allreduce_hook_inside_the_library(G):
     """The C ABI's multi-GPU form (sgp_set_allreduce): ONE sgp_sweep call = local statistics -> hook -> replicated tail.  On one GPU
-    the hook adds the statistics of the other shard (computed beforehand by a second handle) -- what a sum-all-reduce over two
-    ranks leaves in the buffer -- on the sweep's own stream."""
+    the hook adds the exchange buffer of the other shard (captured beforehand from a second handle's sweep) -- what a
+    sum-all-reduce over two ranks leaves in the buffer -- on the sweep's own stream.  The buffer the hook sees is the library's
+    exchange buffer: lower tiles of Psi2, B, scalars (include/sgp_hip.h)."""
     torch = pytest.importorskip("torch")
+    from gaussianprocessnode_amd.distributed import device_tensor
     N, M, D = 900, 80, 2
     X, Xu, y, _ = synth(N, M, D, seed=22)
     s2, ell, w = 1.0, np.array([1.3, 0.8]), 50.0
@@ -835,35 +837,46 @@ def test_sweep_with_the_allreduce_hook_inside_the_library(G):
         d.set_prior_isotropic(50.0); d.set_noise([[w]])
         return d
     other, mine = make(slice(cut, N)), make(slice(0, cut))
-    _, count, _ = mine.stats_layout()
-    buf_other = torch.zeros(count, dtype=torch.float64, device="cuda")
-    buf_mine = torch.zeros(count, dtype=torch.float64, device="cuda")
     tstream = torch.cuda.Stream()
     torch.cuda.synchronize()
-    other.bind_stats(buf_other.data_ptr())
-    other.sweep_local(tstream.cuda_stream)
+    T = (M + 63) // 64
+    packed = T * (T + 1) // 2 * 4096 + T * 64 + 8 + 1            # lower tiles | B (Mp) | scalars (8) | Ryy (1)
+    captured = []
+
+    def capture(ptr, n, stream):
+        assert n == packed and stream == tstream.cuda_stream
+        with torch.cuda.stream(tstream):
+            captured.append(device_tensor(ptr, n).clone())
+    other.set_allreduce(capture)
+    other.sweep(tstream.cuda_stream)
     torch.cuda.synchronize()
-    mine.bind_stats(buf_mine.data_ptr())
     calls = []
 
     def hook(ptr, n, stream):
-        assert ptr == buf_mine.data_ptr() and n == count and stream == tstream.cuda_stream
         calls.append(n)
+        if n != packed:
+            return                               # (the theta gradient's data half below: left as this shard's)
+        assert stream == tstream.cuda_stream
         with torch.cuda.stream(tstream):
-            buf_mine.add_(buf_other)             # ordered on the sweep's stream, like ncclAllReduce would be
+            device_tensor(ptr, n).add_(captured[0])             # ordered on the sweep's stream, like ncclAllReduce would be
     mine.set_allreduce(hook)
     for _ in range(3):                           # the buffer is rebuilt by every sweep: no accumulation across sweeps
         mine.sweep(tstream.cuda_stream)
     torch.cuda.synchronize()
-    assert calls == [count] * 3
+    assert calls == [packed] * 3
     mu, Sig, _ = mine.posterior(want_uv=False)
     sc = mine.scalars()
+    Psi2, B, scal = mine.stats()
+    assert relF(Psi2, ref.stats.Psi2) < 1e-13 and np.array_equal(Psi2, Psi2.T)      # expanded to the full symmetric matrix
+    assert relF(B, np.reshape(ref.stats.b, B.shape)) < 1e-13 and scal[2] == N
     assert relF(mu, ref.mu_v) < 1e-8 and relF(Sig, ref.Sigma_v) < 1e-8
     assert math.isclose(sc.sum_I2, ref.sum_I2, rel_tol=1e-8)
+    val, grad = mine.theta_objective(want_grad=True)         # the data half of the gradient goes through the hook too (33 doubles)
+    assert calls[3:] == [33]
     mine.set_allreduce(None)                     # hook removed: the sweep is single-GPU again (this shard alone)
     mine.sweep(tstream.cuda_stream)
     torch.cuda.synchronize()
-    assert calls == [count] * 3
+    assert len(calls) == 4
     ref1 = O.vmp_sweep(Xu, X[:cut], y[:cut], None, s2, ell, w, jitter=1e-8, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
     assert relF(mine.posterior(want_uv=False)[0], ref1.mu_v) < 1e-8
     other.close(); mine.close()
