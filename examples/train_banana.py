@@ -6,7 +6,8 @@ every minibatch without reset), then the 1300-point test prediction.
 The reference reports 125 errors (rate 0.0961538) after 2965.757395 s.  Data and inducing inputs are the committed
 golden fixtures (tests/golden/banana_fixture.npz).  The final theta and q(w) rate differ from the reference's saved ones
 (softplus(theta) = [0.986, 1.028, 1.022], rate 1.72e6): the q(w) / theta dynamics of this model are neutrally stable and
-end where the message schedule puts them (--w-schedule shows five).  Prints one JSON line.
+end where the message schedule puts them (tests/scripts/banana_schedules.py measures seven).  Prints one
+JSON line.  --host-paced runs the same loop through the setters instead of sgp_train_*.
 """
 import argparse
 import json
@@ -20,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(epochs=500, batch=200, w_schedule="after_v", grad_jitter=None, reset_v=False):
+def run(epochs=500, batch=200, device_paced=True):
     import gaussianprocessnode_amd as G
     from gaussianprocessnode_amd.meta import softplus
     from gaussianprocessnode_amd.train import perform_inference_classification
@@ -33,10 +34,10 @@ def run(epochs=500, batch=200, w_schedule="after_v", grad_jitter=None, reset_v=F
     Xu = fix["Xu"]
     M, D = Xu.shape
     theta_init = np.log(np.expm1(np.ones(D + 1)))
-    with G.SGPDevice(batch, M, D, keep_kuf=(w_schedule != "after_v")) as dev:
+    with G.SGPDevice(batch, M, D) as dev:
         t0 = time.perf_counter()
         qv, (a, b), theta = perform_inference_classification(theta_init, xtrain, ytrain, Xu, dev, batch_size=batch,
-                                                             epochs=epochs, w_schedule=w_schedule, grad_jitter=grad_jitter, reset_v_each_epoch=reset_v)
+                                                             epochs=epochs, device_paced=device_paced)
         t_train = time.perf_counter() - t0
         p = softplus(theta)
         dev.set_kernel(float(p[0]), p[1:], 1e-8)
@@ -44,7 +45,7 @@ def run(epochs=500, batch=200, w_schedule="after_v", grad_jitter=None, reset_v=F
     errors = float(np.sum(np.abs((pred >= 0).astype(float) - ytest)))      # mean(Probit(:out)) >= 0.5  <=>  mean f >= 0
     return {
         "experiment": "banana PerformInference (experiments/classification_banana.ipynb)",
-        "epochs": epochs, "minibatch": batch, "M": int(M), "w_schedule": w_schedule, "grad_jitter": grad_jitter, "reset_v_each_epoch": reset_v, "train_seconds": t_train,
+        "epochs": epochs, "minibatch": batch, "M": int(M), "pacing": "device" if device_paced else "host", "train_seconds": t_train,
         "ms_per_minibatch": 1e3 * t_train / (epochs * (Ntrain // batch)),
         "errors": errors, "error_rate": errors / len(ytest), "theta_softplus": [float(v) for v in p], "qw": [a, b],
         "reference": {"errors": 125.0, "error_rate": 0.09615384615384616, "train_seconds": 2965.757395,
@@ -56,9 +57,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=500)
     ap.add_argument("--batch", type=int, default=200)
-    ap.add_argument("--w-schedule", choices=["after_v", "before_v", "w_then_v", "f_again", "f_again_w"], default="after_v",
-                    help="q(w) from the minibatch's new q(v) (after_v) or from the q(v) the iteration started with (before_v)")
-    ap.add_argument("--grad-jitter", type=float, default=None, help="K_uu jitter used in the theta gradient only (default: the sweep's 1e-8)")
-    ap.add_argument("--reset-v", action="store_true", help="q(v) back to its prior at every epoch (q(w) kept): the notebook's commented-out lines")
+    ap.add_argument("--host-paced", action="store_true", help="setters + sgp_theta_objective + AdaMax in NumPy per minibatch")
     args = ap.parse_args()
-    print(json.dumps(run(args.epochs, args.batch, args.w_schedule, args.grad_jitter, args.reset_v)))
+    print(json.dumps(run(args.epochs, args.batch, not args.host_paced)))

@@ -142,6 +142,7 @@ struct sgp_handle {
     TrainState* dTrain = nullptr;
     Params* dTrainParams = nullptr;
     bool training = false;
+    bool train_probit = false;     // the open run is a classification run (sgp_train_likelihood)
     double* dXusK = nullptr;
     hipStream_t own = nullptr, side = nullptr;
     hipEvent_t evSide = nullptr, evDone = nullptr;
@@ -1676,6 +1677,13 @@ static void launch_predict(sgp_handle* h, const double* dXs, const double* dMu, 
                        dMean, h->dParamsK, h->M, h->Mp, h->D, ns, h->dout);
 }
 
+// (the same on the MAIN stream's copies of the scaled inducing inputs / parameters: the classification training step's forward message)
+template <int DT>
+static void launch_predict_main(sgp_handle* h, const double* dXs, const double* dMu, double* dMean, int64_t ns, hipStream_t s) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_predict<DT>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, h->dXus, dXs, dMu,
+                       dMean, h->dParams, h->M, h->Mp, h->D, ns, h->dout);
+}
+
 extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const double* mu_v, double* mean) {
     if (!h || !Xstar || !mean || ns < 0) return fail(h, SGP_ERR_ARG, "sgp_predict: bad argument");
     if (!h->have_inducing || !h->have_kernel) return fail(h, SGP_ERR_ARG, "sgp_predict: set_inducing and set_kernel first");
@@ -1897,12 +1905,55 @@ extern "C" int sgp_train_begin(sgp_handle* h, const double* X, const double* y, 
     HIPCHK(h, hipMemcpy(h->dTrainParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice));
     h->n_ell = n_ell;
     hipLaunchKernelGGL(k_train_adamax, dim3(1), dim3(64), 0, h->own, h->dTrain, (const double*)nullptr, (const double*)nullptr,
-                       h->dTrainParams, h->D, n_ell, 0, (const int*)nullptr);
+                       h->dTrainParams, h->D, n_ell, 0, (const int*)nullptr, (const Params*)nullptr, 0.0);
     HIPCHK(h, hipStreamSynchronize(h->own));
     h->params_src = h->dTrainParams;
     h->have_kernel = true;
     h->training = true;
+    h->train_probit = false;
     h->swept = h->swept_local = false;
+    return 0;
+}
+
+// Classification run: call right after sgp_train_begin.  From then on the labels given there (0 / 1) are Probit observations of
+// f (experiments/classification_banana.ipynb cell 7), q(w) = Gamma(shape, rate) is carried over the minibatches, and every
+// sgp_train_step forms q(f) for its window on the device first (k_predict with the carried posterior mean -- zero before the
+// first step --, k_probit_window), updates q(w) after the sweep and takes the optimiser step at the new mean(q_w).
+extern "C" int sgp_train_likelihood(sgp_handle* h, int32_t kind, double shape, double rate) {
+    if (!h) return SGP_ERR_ARG;
+    if (!h->training) return fail(h, SGP_ERR_ARG, "sgp_train_likelihood: call sgp_train_begin first");
+    if (kind != SGP_LIKELIHOOD_GAUSSIAN && kind != SGP_LIKELIHOOD_PROBIT) return fail(h, SGP_ERR_ARG, "sgp_train_likelihood: unknown kind");
+    if (kind == SGP_LIKELIHOOD_PROBIT && (!(shape > 0.0) || !(rate > 0.0)))
+        return fail(h, SGP_ERR_ARG, "sgp_train_likelihood: shape and rate of q(w) must be > 0");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    TrainState st;
+    HIPCHK(h, hipMemcpy(&st, h->dTrain, sizeof st, hipMemcpyDeviceToHost));
+    st.kind = kind == SGP_LIKELIHOOD_PROBIT ? 1.0 : 0.0;
+    st.ga = shape; st.gb = rate;
+    HIPCHK(h, hipMemcpy(h->dTrain, &st, sizeof st, hipMemcpyHostToDevice));
+    h->train_probit = kind == SGP_LIKELIHOOD_PROBIT;
+    if (h->train_probit) {
+        Params P;
+        HIPCHK(h, hipMemcpy(&P, h->dTrainParams, sizeof P, hipMemcpyDeviceToHost));
+        P.W[0] = shape / rate;
+        P.E_logw = std::log(shape / rate);
+        HIPCHK(h, hipMemcpy(h->dTrainParams, &P, sizeof P, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemset(h->dMu, 0, sizeof(double) * h->Qp));           // the forward message of the first minibatch: k' 0
+        double* scratch = nullptr;
+        if (int crc = call_scratch(h, (size_t)h->n_max, &scratch)) return crc;   // mz of a window (sized now: the steps only enqueue)
+    }
+    return 0;
+}
+
+extern "C" int sgp_train_get_gamma(sgp_handle* h, double* shape_rate) {
+    if (!h || !shape_rate) return SGP_ERR_ARG;
+    if (!h->dTrain) return fail(h, SGP_ERR_ARG, "sgp_train_get_gamma: no training run on this handle");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    TrainState st;
+    HIPCHK(h, hipMemcpy(&st, h->dTrain, sizeof st, hipMemcpyDeviceToHost));
+    shape_rate[0] = st.ga; shape_rate[1] = st.gb;
     return 0;
 }
 
@@ -1921,15 +1972,37 @@ extern "C" int sgp_train_step(sgp_handle* h, int64_t offset, int64_t n, int32_t 
     if (flags & SGP_TRAIN_RESET_PRIOR) h->prior_form = 2;
     double *ownX = h->dX, *ownYw = h->dYw, *ownY = h->dY;
     h->dX = h->dTrainX + (size_t)offset * h->D;
-    h->dYw = h->dY = h->dTrainY + offset;
-    h->has_omega = h->has_yv = false;
+    if (!h->train_probit) h->dYw = h->dY = h->dTrainY + offset;      // (classification: the window's q(f) goes to the handle's own buffers)
+    h->has_omega = false;
+    h->has_yv = h->train_probit;
     h->have_data = true;
     h->n_nodes = (double)n;
     h->data_gen++;
     h->params_gen++;                                           // theta moved: k_prep_xu mirrors the parameters again
     int rc = set_point_count(h, n);
+    if (!rc && h->train_probit) {
+        // q(f) of the window: forward message from the carried posterior mean at the current theta, then the Probit moments
+        hipLaunchKernelGGL(k_prep_xu, dim3((h->Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXus, h->params_src, h->dParams, (int*)nullptr,
+                           h->M, h->Mp, h->D, h->dStamps, (int)SGP_T_COUNT, (int)SGP_T_SWEEP, (const long long*)nullptr, 0LL,
+                           (const long long*)nullptr, 0LL, h->spin_limit, (int*)nullptr);
+        h->main_prep_gen = h->params_gen;                      // (the sweep below starts with its Gram kernel)
+        double* mz = h->dCall;
+        if (n > 0) {
+            switch (h->D) {
+                case 1: launch_predict_main<1>(h, h->dX, h->dMu, mz, n, s); break;
+                case 2: launch_predict_main<2>(h, h->dX, h->dMu, mz, n, s); break;
+                case 3: launch_predict_main<3>(h, h->dX, h->dMu, mz, n, s); break;
+                case 4: launch_predict_main<4>(h, h->dX, h->dMu, mz, n, s); break;
+                case 8: launch_predict_main<8>(h, h->dX, h->dMu, mz, n, s); break;
+                default: launch_predict_main<0>(h, h->dX, h->dMu, mz, n, s); break;
+            }
+        }
+        hipLaunchKernelGGL(k_probit_window, dim3(1), dim3(256), 0, s, (const double*)(h->dTrainY + offset), (const double*)mz, n,
+                           (const TrainState*)h->dTrain, h->dY, h->dYw, h->dYv, h->dDataScal, (int)SGP_S_COUNT + 1);
+    }
     if (!rc) {
-        hipLaunchKernelGGL(k_train_window, dim3(1), dim3(256), 0, s, (const double*)h->dY, n, h->dDataScal, (int)SGP_S_COUNT + 1);
+        if (!h->train_probit)
+            hipLaunchKernelGGL(k_train_window, dim3(1), dim3(256), 0, s, (const double*)h->dY, n, h->dDataScal, (int)SGP_S_COUNT + 1);
         // (the sweep's own entry point: the product path here too.  Data-sharded: the window is this rank's slice of the
         // minibatch, sgp_sweep sums the statistics -- the window's data scalars ride in the same buffer -- through the hook)
         rc = sgp_sweep(h, nullptr);
@@ -1938,11 +2011,14 @@ extern "C" int sgp_train_step(sgp_handle* h, int64_t offset, int64_t n, int32_t 
         // (without a learning step the kernel only keeps the books: a failed factorisation is counted either way)
         if (!rc)
             hipLaunchKernelGGL(k_train_adamax, dim3(1), dim3(64), 0, s, h->dTrain, (const double*)h->dGrad, (const double*)h->dOut,
-                               h->dTrainParams, h->D, h->n_ell, learn ? 1 : 2, (const int*)(h->dInfo + 3));
+                               h->dTrainParams, h->D, h->n_ell, learn ? 1 : 2, (const int*)(h->dInfo + 3), (const Params*)h->dParams,
+                               (double)n);
         // the next K_uu chain (side stream) reads the parameters this step wrote and overwrites the K_uu^-1 its gradient read
         if (!rc) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_DONE, ++h->done_epoch);
+        if (!rc && h->use_events) HIPCHK(h, hipEventRecord(h->evDone, s));   // (hooked run: the next K_uu chain waits on this, see sweep_local_impl)
     }
     h->dX = ownX; h->dYw = ownYw; h->dY = ownY;
+    h->has_yv = false;
     h->have_data = false;                                      // the window is not the handle's data: set_data again after the run
     if (rc) return rc;
     if (hipGetLastError() != hipSuccess) return fail(h, SGP_ERR_HIP, "sgp_train_step: launch failed");
@@ -1967,6 +2043,8 @@ extern "C" int sgp_train_end(sgp_handle* h, double* theta_raw, int64_t* counts) 
     HIPCHK(h, hipMemcpy(&P, h->dTrainParams, sizeof P, hipMemcpyDeviceToHost));
     h->hParams->sigma2 = P.sigma2;
     for (int d = 0; d < h->D; ++d) h->hParams->inv_ell[d] = P.inv_ell[d];
+    if (h->train_probit) { h->hParams->W[0] = P.W[0]; h->hParams->E_logw = P.E_logw; }      // mean(q_w) after the last minibatch
+    h->train_probit = false;
     h->params_gen++;
     h->stats_dirty = true;                                     // the resident statistics belong to the previous theta
     h->swept_local = false;

@@ -2755,9 +2755,50 @@ struct TrainState {
     double bp[2];               // running powers of beta
     double eta, beta1, beta2, eps;
     double steps, rejected;     // optimiser steps taken / minibatches whose factorisations failed (theta left alone)
+    // classification (SGP_LIKELIHOOD_PROBIT): q(w) = Gamma(ga, gb), carried over the minibatches and never reset
+    // (experiments/classification_banana.ipynb cell 9: `shape, rate = params(qw)`)
+    double ga, gb;
+    double kind;                // 0 Gaussian likelihood with a fixed w (regression), 1 Probit with a Gamma q(w)
 };
 
 __device__ __forceinline__ double softplus_dev(double x) { return fmax(x, 0.0) + log1p(exp(-fabs(x))); }
+
+// Classification minibatch (experiments/classification_banana.ipynb cell 7: `f[i] ~ UniSGP(x[i], v, w, theta); y[i] ~ Probit(f[i])`):
+// q(f_i) = the moment-matched product of the UniSGP :out message N(mz_i, 1 / mean(q_w)) (GPnode/UniSGPnode.jl:96-104; mz = k_i' mu_v
+// from k_predict on the window) with the Probit likelihood of the label y_i in {0, 1}:
+//     s = 2 y - 1,  vz = 1 / w,  g = s mz / sqrt(1 + vz),  r = phi(g) / Phi(g),
+//     mean = mz + s vz r / sqrt(1 + vz),   var = vz - vz^2 / (1 + vz) r (g + r).
+// r through erfcx for g < 0 (phi / Phi = sqrt(2 / pi) / erfcx(-g / sqrt 2): no cancellation, no underflow in the tail).
+// Writes the window's data as the sweep reads it -- mean (twice: y and omega y), variance -- and its data scalars
+// (sum mean^2 + var, n, n: what sgp_set_data computes on the host).  One workgroup, fixed summation order.
+__global__ void __launch_bounds__(256) k_probit_window(const double* __restrict__ label, const double* __restrict__ mz, int64_t n,
+                                                       const TrainState* __restrict__ st, double* __restrict__ ymean,
+                                                       double* __restrict__ yw, double* __restrict__ yvar, double* __restrict__ scal,
+                                                       int count) {
+    __shared__ double red[4];
+    const double vz = st->gb / st->ga, q = 1.0 / sqrt(1.0 + vz);
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double sgn = 2.0 * label[i] - 1.0, m = mz[i];
+        const double g = sgn * m * q;
+        double r;
+        if (g < 0.0) r = 0.79788456080286535588 / erfcx(-g * 0.70710678118654752440);
+        else r = exp(-0.5 * g * g) * 0.39894228040143267794 / (0.5 * erfc(-g * 0.70710678118654752440));
+        const double mf = m + sgn * vz * r * q;
+        const double vf = vz - vz * vz / (1.0 + vz) * r * (g + r);
+        ymean[i] = mf;
+        yw[i] = mf;
+        yvar[i] = vf;
+        acc += mf * mf + vf;
+    }
+    const double syy = block_sum(acc, red);
+    for (int e = threadIdx.x; e < count; e += 256) {
+        double v = 0.0;
+        if (e == 0 /* SGP_S_YY */ || e == 8 /* Ryy[0] of d_out = 1 */) v = syy;
+        if (e == 1 /* SGP_S_W */ || e == 2 /* SGP_S_N */) v = (double)n;
+        scal[e] = v;
+    }
+}
 
 // One thread: Flux's AdaMax (m = b1 m + (1 - b1) g; u = max(b2 u, |g|); theta -= eta / (1 - b1^t) m / (u + eps)) on the raw
 // parameters with the chain rule through softplus (d softplus = sigmoid), then the kernel parameters of the NEXT sweep
@@ -2765,19 +2806,32 @@ __device__ __forceinline__ double softplus_dev(double x) { return fmax(x, 0.0) +
 // `update`: 1 = optimiser step (skipped and counted if a factorisation of this minibatch failed or a device-word wait gave up),
 // 2 = status only (a minibatch without a learning step: a failure is still counted), 0 = only write the parameters (first step
 // of a run).
+// Probit runs (st->kind = 1) first update q(w) = Gamma(a + n / 2, b + (sum I1 + sum I2) / 2) from the sweep's scalars
+// (GPnode/UniSGPnode.jl:219-238 summed over the window); the gradient was formed at the sweep's mean(q_w) and the objective is
+// linear in it, so it is rescaled to the NEW mean (`grad_llh_new!(...; w = mean(qw))`, classification_banana.ipynb cell 9), and
+// the next sweep's noise precision is written with the kernel parameters.
 __global__ void k_train_adamax(TrainState* __restrict__ st, const double* __restrict__ grad, const double* __restrict__ out,
-                               Params* __restrict__ src, int D, int n_ell, int update, const int* __restrict__ sync_status) {
+                               Params* __restrict__ src, int D, int n_ell, int update, const int* __restrict__ sync_status,
+                               const Params* __restrict__ swept, double n_window) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool probit = st->kind == 1.0;
     if (update) {
         const bool ok = out[3] == 0.0 && out[4] == 0.0 && (!sync_status || *sync_status == 0);   // SGP_R_INFO_KUU, SGP_R_INFO_LAMBDA
+        double gscale = 1.0;
+        if (probit && ok) {
+            st->ga += 0.5 * n_window;
+            st->gb += 0.5 * (out[0] + out[1]);
+            gscale = (st->ga / st->gb) / swept->W[0];
+        }
         if (update == 2) {
             if (!ok) st->rejected += 1.0;
+            if (probit) { src->W[0] = st->ga / st->gb; src->E_logw = log(st->ga / st->gb); }
             return;
         }
         if (ok) {
             for (int i = 0; i <= n_ell; ++i) {
                 const double th = st->theta[i];
-                const double g = grad[i] / (1.0 + exp(-th));
+                const double g = gscale * grad[i] / (1.0 + exp(-th));
                 const double m = st->beta1 * st->m[i] + (1.0 - st->beta1) * g;
                 const double u = fmax(st->beta2 * st->u[i], fabs(g));
                 st->m[i] = m;
@@ -2792,6 +2846,7 @@ __global__ void k_train_adamax(TrainState* __restrict__ st, const double* __rest
     }
     src->sigma2 = softplus_dev(st->theta[0]);
     for (int d = 0; d < D; ++d) src->inv_ell[d] = 1.0 / softplus_dev(st->theta[1 + (n_ell == 1 ? 0 : d)]);
+    if (probit) { src->W[0] = st->ga / st->gb; src->E_logw = log(st->ga / st->gb); }
 }
 
 }  // namespace sgp

@@ -219,7 +219,8 @@ class SGPDevice:
         return (v.value, g) if want_grad else v.value
 
     # -- device-paced minibatch training (sgp_train_*) -----------------------------------------------------------------
-    def train_begin(self, X, y, theta_raw, *, jitter: float = 0.0, eta: float = 1e-3, beta=(0.9, 0.999), eps: float = 1e-8):
+    def train_begin(self, X, y, theta_raw, *, jitter: float = 0.0, eta: float = 1e-3, beta=(0.9, 0.999), eps: float = 1e-8,
+                    likelihood=None, gamma=(0.01, 0.01)):
         """Upload the training set (X: N x D, one point per row; y: N) and the raw (pre-softplus) parameters, reset the
         AdaMax state: the loop of `PerformInference` (experiments/regression_kin40k.ipynb:196-230) then runs as
         `train_step` calls that only enqueue."""
@@ -232,6 +233,17 @@ class SGPDevice:
         self._check(self._lib.sgp_train_begin(self._h, ptr(X), ptr(y), len(y), ptr(th), n_ell, float(jitter), float(eta),
                                         float(beta[0]), float(beta[1]), float(eps)), "sgp_train_begin")
         self._n_ell = n_ell
+        if likelihood == "probit":
+            # classification: y are labels in {0, 1}, q(w) = Gamma(*gamma) carried over the minibatches (sgp_train_likelihood)
+            self._check(self._lib.sgp_train_likelihood(self._h, 1, float(gamma[0]), float(gamma[1])), "sgp_train_likelihood")
+        elif likelihood not in (None, "gaussian"):
+            raise ValueError(f"train_begin: unknown likelihood {likelihood!r}")
+
+    def train_gamma(self):
+        """(shape, rate) of q(w) after a classification run (sgp_train_get_gamma)."""
+        ab = np.empty(2)
+        self._check(self._lib.sgp_train_get_gamma(self._h, ptr(ab)), "sgp_train_get_gamma")
+        return float(ab[0]), float(ab[1])
 
     def train_step(self, offset: int, n: int, learn: bool = True, reset_prior: bool = False):
         """One minibatch [offset, offset + n): sweep, carry, gradient, optimiser step.  Asynchronous.  reset_prior puts

@@ -41,16 +41,20 @@ def perform_inference(theta, xtrain, ytrain, Xu, engine, *, batch_size=500, epoc
     """Returns (q_v of the last minibatch, theta) like `PerformInference` (:196-230).  `theta` is the raw
     (pre-softplus) parameter vector of `kernel_gp` (:108); `engine` an SGPDevice sized for `batch_size` points.
 
-    device_paced (default: whenever the engine offers `train_begin`): the training set, theta and the optimiser state
-    stay on the device and the loop below only enqueues (sgp_train_* in include/sgp_hip.h); otherwise every minibatch
-    goes through the setters, `theta_objective` and the host-side `AdaMax` (the same arithmetic, host-paced)."""
+    device_paced (default: whenever the engine offers `train_begin` and the optimizer is fresh): the training set, theta and
+    the optimiser state stay on the device and the loop below only enqueues (sgp_train_* in include/sgp_hip.h); otherwise
+    every minibatch goes through the setters, `theta_objective` and the host-side `AdaMax` (the same arithmetic,
+    host-paced).  Device-paced, a minibatch whose K_uu or Lambda is not positive definite is skipped and counted; the
+    LinAlgError is raised after the run, not at the failing minibatch."""
     theta = np.array(theta, dtype=np.float64)
     xtrain = np.asarray(xtrain, dtype=np.float64).reshape(len(ytrain), -1)
     Xu = np.asarray(Xu, dtype=np.float64).reshape(-1, xtrain.shape[1])
     M = Xu.shape[0]
     optimizer = optimizer or AdaMax()
     if device_paced is None:
-        device_paced = hasattr(engine, "train_begin")
+        # (the device-paced run starts AdaMax from zero state and does not write the moments back: an optimizer that has
+        # already taken steps keeps to the host-paced loop, which continues where it left off)
+        device_paced = hasattr(engine, "train_begin") and not optimizer._state
     if device_paced:
         return _perform_inference_device(theta, xtrain, ytrain, Xu, engine, batch_size, epochs, w_val, prior_var, jitter,
                                          optimizer, learn_theta)
@@ -167,8 +171,7 @@ def vmp_classification(p, xtrain, ytrain, Xu, engine, *, iterations=30, prior_va
 
 
 def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch_size=200, epochs=1, prior_var=50.0,
-                                     shape=0.01, rate=0.01, jitter=1e-8, optimizer=None, w_schedule="after_v",
-                                     grad_jitter=None, reset_v_each_epoch=False):
+                                     shape=0.01, rate=0.01, jitter=1e-8, optimizer=None, device_paced=None):
     """`PerformInference` of experiments/classification_banana.ipynb (model `f[i] ~ UniSGP(x[i], v, w, theta);
     y[i] ~ Probit(f[i])`, mean-field q(f) q(v) q(w), one VMP iteration per minibatch, q(v) and q(w) carried over every
     minibatch and never reset).  Per minibatch:
@@ -179,35 +182,31 @@ def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch
       theta   one optimiser step on neg_log_backwardmess_fast with y_data = mean(q_f), w = mean(new q_w).
     Returns (q_v, (shape, rate), theta).
 
-    w_schedule: the order of the updates inside the single VMP iteration -- "after_v" (default: q(w) from the minibatch's
-    new q(v) and the `meta.Uv` its product hook just stored), "before_v" (from the q(v) the iteration started with),
-    "w_then_v" (as before_v, and the sweep already uses the new mean(q_w)), "f_again_w" (q(f) recomputed from the new q(v)
-    before q(w)), "f_again" (only the gradient sees the recomputed q(f)).  None reproduces the reference's end point
-    (softplus(theta) = [0.986, 1.028, 1.022], q(w) rate 1.72e6): rates 5.9e5 / 3.6e9 / 2.5e9 / 7.2e5 / 5.9e5
-    (profiles/r02_train_banana_schedules.jsonl).  mean(q_w) is neutrally stable (b/a = mean(I1 + I2) ~ 1/mean(q_w) holds
-    for any value), so it follows the update order; the K_uu treatment of the reference's gradient (no jitter,
-    derivative_helper.jl:24-25) is not the lever: tools/banana_gradient_probe.py bounds its effect on the first gradient at
-    7e-5 .. 6e-3, and `grad_jitter` (a different jitter in the gradient only) from 1e-11 to 1e-4 leaves the end point where
-    it is.  `reset_v_each_epoch` (the notebook's commented-out lines) does not reproduce it either.  DESIGN.md section 2."""
+    The order of the updates inside the single VMP iteration is the reference scheduler's business (RxInfer / ReactiveMP, no
+    pinned version); this is the order in which `meta.Uv` is refreshed by the product hook before the :w messages read it.
+    Other orders were measured (tests/scripts/banana_schedules.py, profiles/*_train_banana_schedules.jsonl): none reproduces the
+    reference's saved end point, see DESIGN.md section 2.
+
+    device_paced (default: whenever the engine offers `train_begin`): the whole loop -- Probit moment matching, the Gamma
+    update and AdaMax included -- runs on the device (sgp_train_begin with SGP_LIKELIHOOD_PROBIT); the host only enqueues."""
     theta = np.array(theta, dtype=np.float64)
     xtrain = np.asarray(xtrain, dtype=np.float64).reshape(len(ytrain), -1)
     ytrain = np.asarray(ytrain, dtype=np.float64)
     Xu = np.asarray(Xu, dtype=np.float64).reshape(-1, xtrain.shape[1])
     M = Xu.shape[0]
     optimizer = optimizer or AdaMax()
+    if device_paced is None:
+        device_paced = hasattr(engine, "train_begin") and not optimizer._state
+    if device_paced:
+        return _perform_inference_classification_device(theta, xtrain, ytrain, Xu, engine, batch_size, epochs, prior_var, shape,
+                                                        rate, jitter, optimizer)
     xb, yb = split2batch((xtrain, ytrain), batch_size)
     a, b = float(shape), float(rate)
     engine.set_inducing(Xu)
     engine.set_prior_precision(np.zeros(M), np.eye(M) / prior_var)
     mu = np.zeros(M)
-    Uv_old = np.sqrt(prior_var) * np.eye(M)
     first = True
     for _ in range(epochs):
-        if reset_v_each_epoch and not first:                               # (experiment: q(v) back to its prior every epoch, q(w) kept)
-            engine.set_prior_precision(np.zeros(M), np.eye(M) / prior_var)
-            mu = np.zeros(M)
-            Uv_old = np.sqrt(prior_var) * np.eye(M)
-            first = True
         for xi, yi in zip(xb, yb):
             p = softplus(theta)
             w0 = a / b
@@ -216,48 +215,33 @@ def perform_inference_classification(theta, xtrain, ytrain, Xu, engine, *, batch
             mf, vf = probit_marginal(yi, mz, 1.0 / w0)
             engine.set_data(xi, mf, vf)
             engine.set_noise([[w0]])
-            if w_schedule in ("before_v", "w_then_v"):
-                # q(w) from the q(v) this iteration STARTED with: the per-point I1 / I2 at the carried posterior, before the
-                # sweep replaces it ("w_then_v": the sweep then already uses the new mean(q_w))
-                engine.sweep_local()
-                engine.set_posterior(mu, Uv_old)
-                I1, I2 = engine.w_stats()
-                s_I = float(np.sum(I1) + np.sum(I2))
-                if w_schedule == "w_then_v":
-                    engine.set_noise([[(a + 0.5 * len(yi)) / (b + 0.5 * s_I)]])
             engine.sweep()
-            if w_schedule in ("after_v", "f_again", "f_again_w"):
-                sc = engine.scalars()
-                s_I = sc.sum_I1 + sc.sum_I2
-            else:
-                mu, _, Uv_old = engine.posterior(want_cov=False)
-            if w_schedule == "f_again_w":
-                # q(f) once more from the NEW q(v) (still at the old mean(q_w)), and q(w) from that q(f) and the new q(v)
-                mu_n, _, Uv_n = engine.posterior(want_cov=False)
-                mf, vf = probit_marginal(yi, engine.predict(xi, None), 1.0 / w0)
-                engine.carry_posterior()
-                engine.set_data(xi, mf, vf)
-                engine.sweep_local()
-                engine.set_posterior(mu_n, Uv_n)
-                I1, I2 = engine.w_stats()
-                s_I = float(np.sum(I1) + np.sum(I2))
-                a, b = a + 0.5 * len(yi), b + 0.5 * s_I
-            else:
-                a, b = a + 0.5 * len(yi), b + 0.5 * s_I
-                engine.carry_posterior()
-                if w_schedule == "f_again":
-                    # the q(f) the iteration ENDS with: recomputed from the new q(v) and the new mean(q_w); it is what the
-                    # gradient then sees as y_data (the statistics are re-formed with it, q(v) re-installed unchanged)
-                    mu_n, _, Uv_n = engine.posterior(want_cov=False)
-                    mf, vf = probit_marginal(yi, engine.predict(xi, None), b / a)
-                    engine.set_data(xi, mf, vf)
-                    engine.sweep_local()
-                    engine.set_posterior(mu_n, Uv_n)
+            sc = engine.scalars()
+            a, b = a + 0.5 * len(yi), b + 0.5 * (sc.sum_I1 + sc.sum_I2)
+            engine.carry_posterior()
             engine.set_noise([[a / b]])                                # grad_llh_new!(...; w = mean(qw))
-            if grad_jitter is not None:                                # (experiment: a different K_uu jitter in the gradient only)
-                engine.set_kernel(float(p[0]), p[1:], grad_jitter)
             _, g = engine.theta_objective(want_grad=True, n_ell=len(p) - 1)
             optimizer.update(theta, g * sigmoid(theta))
             first = False
     mu, Sigma, _ = engine.posterior(want_uv=False)
     return MvNormalMeanCovariance(mu, Sigma), (a, b), theta
+
+
+def _perform_inference_classification_device(theta, xtrain, ytrain, Xu, engine, batch_size, epochs, prior_var, shape, rate, jitter,
+                                             optimizer):
+    """The same loop paced by the device: one `train_step` per minibatch (window of the resident set; the forward message, the
+    Probit moments, the Gamma update and AdaMax are kernels between the sweep's own), the host waits once, at the end."""
+    N = len(ytrain)
+    engine.set_inducing(Xu)
+    engine.set_prior_isotropic(prior_var)                                  # q(v) starts at its prior and is never reset
+    engine.train_begin(xtrain, ytrain, theta, jitter=jitter, eta=optimizer.eta, beta=optimizer.beta, eps=optimizer.eps,
+                       likelihood="probit", gamma=(shape, rate))
+    for _ in range(epochs):
+        for o in range(0, N, batch_size):
+            engine.train_step(o, min(batch_size, N - o), True, reset_prior=False)
+    theta, _, skipped = engine.train_end()
+    if skipped:
+        raise np.linalg.LinAlgError(f"{skipped} minibatch(es) had a K_uu or Lambda that is not positive definite")
+    a, b = engine.train_gamma()
+    mu, Sigma, _ = engine.posterior(want_uv=False)
+    return MvNormalMeanCovariance(mu, Sigma), (a, b), np.asarray(theta)

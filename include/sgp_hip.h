@@ -224,6 +224,17 @@ int sgp_train_begin(sgp_handle* h, const double* X, const double* y, int64_t n_t
                     int32_t n_ell, double jitter, double eta, double beta1, double beta2, double eps);
 enum { SGP_TRAIN_LEARN = 1, SGP_TRAIN_RESET_PRIOR = 2 };
 int sgp_train_step(sgp_handle* h, int64_t offset, int64_t n, int32_t flags);
+/* Classification runs -- `PerformInference` of experiments/classification_banana.ipynb (cell 9; model cell 7:
+ * `f[i] ~ UniSGP(x[i], v, w, theta); y[i] ~ Probit(f[i])`, mean-field q(f) q(v) q(w)).  sgp_train_likelihood, called right after
+ * sgp_train_begin with kind = SGP_LIKELIHOOD_PROBIT, declares the y given there to be labels in {0, 1} and q(w) =
+ * GammaShapeRate(shape, rate).  Every sgp_train_step then does, on the device: q(f_i) of its window from the :out message
+ * N(k_i' mu_v, 1 / mean(q_w)) (GPnode/UniSGPnode.jl:96-104) with the carried posterior mean and the Probit likelihood; the sweep
+ * with q_out = q(f) (the classification :v / :w rules, :161-173, :219-238); q(w) <- Gamma(shape + n / 2, rate + (sum I1 + sum I2) / 2);
+ * the posterior carry; the optimiser step at the NEW mean(q_w).  q(v) and q(w) are never reset (no SGP_TRAIN_RESET_PRIOR).
+ * sgp_train_get_gamma (after sgp_train_end): the final (shape, rate). */
+enum { SGP_LIKELIHOOD_GAUSSIAN = 0, SGP_LIKELIHOOD_PROBIT = 1 };
+int sgp_train_likelihood(sgp_handle* h, int32_t kind, double shape, double rate);
+int sgp_train_get_gamma(sgp_handle* h, double* shape_rate /* 2 */);
 int sgp_train_end(sgp_handle* h, double* theta_raw, int64_t* counts /* 2 */);
 
 /* ---- building blocks exposed for tests / other callers (host pointers, blocking) ------------
