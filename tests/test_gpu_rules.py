@@ -451,7 +451,7 @@ def test_device_paced_classification_steps_match_the_host_loop_to_rounding():
     X, lab = data[:, :2], np.where(data[:, 2] < 0, 0.0, data[:, 2])
     Xu = fix["Xu"][:128]
     th0 = np.log(np.expm1(np.ones(3)))
-    for nb, tol_t, tol_q in ((1, 0.0, 1e-13), (5, 3e-8, 1e-8)):
+    for nb, tol_t, tol_q in ((1, 0.0, 1e-13), (5, 3e-8, 1e-6)):
         out = []
         for paced in (True, False):
             with G.SGPDevice(200, len(Xu), 2) as dev:
