@@ -217,7 +217,12 @@ def main():
     # (flops per launch) / (average launch duration), the quantity rocprofv3 --kernel-trace --stats shows for k_syrk_stream.
     plan = dev.overlap_plan() if (world == 1 and not sweep.hooked) else []
     ntiles_all = (M + 63) // 64 * ((M + 63) // 64 + 1) // 2
-    if plan:
+    # (SGP_BENCH_SKIP_ALONE: the rocprofv3 --pmc passes of tools/measure_round.sh -- every k_syrk_stream launch in their output is
+    # then one of the timed sweeps' own; the stand-alone timings are skipped and the roofline block is not meaningful)
+    skip_alone = os.environ.get("SGP_BENCH_SKIP_ALONE") is not None
+    if skip_alone:
+        syrk_groups, syrk_launches, syrk_us_alone = None, max(len(plan), 1), float("nan")
+    elif plan:
         group_us = [dev.time_group(g, 10) for g in range(len(plan))]
         syrk_groups = [{"tile_columns": [g["col_begin"], g["col_end"]], "tiles": g["tiles"], "point_chunks": g["chunks"], "cus": g["cus"],
                         "launch_us": us, "tflops": syrk_flops * g["tiles"] / ntiles_all / (us * 1e-6) / 1e12,
@@ -230,8 +235,8 @@ def main():
         syrk_groups = None
         syrk_launches = 1
         syrk_us_alone = dev.time_kernel(_lib.SGP_T_SYRK, 10, stream)
-    syrk_full_us = dev.time_kernel(_lib.SGP_T_SYRK, 10, stream) if plan else syrk_us_alone     # one launch, all tiles, all CUs
-    gram_us_alone = dev.time_kernel(_lib.SGP_T_GRAM, 10, stream)
+    syrk_full_us = (dev.time_kernel(_lib.SGP_T_SYRK, 10, stream) if plan else syrk_us_alone) if not skip_alone else float("nan")
+    gram_us_alone = dev.time_kernel(_lib.SGP_T_GRAM, 10, stream) if not skip_alone else float("nan")
     syrk_us = tick_us(_lib.SGP_T_SYRK)
     achieved = syrk_flops / syrk_launches / (syrk_us_alone * 1e-6) / 1e12
     traffic, traffic_src = pmc_traffic(args.workload, world)

@@ -256,12 +256,12 @@ static SyrkGeom syrk_geometry(int row_lo, int nrows, int cus, int64_t n) {
     for (int q = 2; q <= 8; q *= 2)
         if (g.ntiles % q == 0) a = 8 / q;                 // smallest a with (ntiles * a) % 8 == 0
     int want = std::max(1, slots / g.ntiles);
-    if (want >= 8 * a) want = want / a * a;
+    if (want > a) want = want / a * a;
     int64_t per = (n + want - 1) / want;
     per = std::max<int64_t>(KB, (per + KB - 1) / KB * KB);
     g.chunk = (int)per;
     g.nchunks = (int)std::max<int64_t>(1, (n + per - 1) / per);
-    if (g.nchunks >= 8 * a) g.nchunks = std::min(want, (g.nchunks + a - 1) / a * a);   // trailing chunks may be empty (zero slabs)
+    if (g.nchunks > a) g.nchunks = (g.nchunks + a - 1) / a * a;      // (<= want: trailing chunks may be empty, zero slabs)
     return g;
 }
 static inline size_t syrk_items(const SyrkGeom& g) { return (size_t)g.ntiles * g.nchunks; }
@@ -1576,7 +1576,7 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->own;
     // which = SGP_TIME_GROUP0 + g: the SYRK launch of statistics group g of the overlapped sweep, on the stream (and CUs) it runs on
     const StatGroup* G = nullptr;
-    if (which >= SGP_TIME_GROUP0) {
+    if (which >= SGP_TIME_GROUP0 && which < SGP_TIME_GROUP0 + LAM_MAX_GROUPS) {
         if (!h->overlap || which - SGP_TIME_GROUP0 >= h->ngroups) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: no such statistics group");
         HIPCHK(h, hipDeviceSynchronize());
         G = &h->grp[which - SGP_TIME_GROUP0];

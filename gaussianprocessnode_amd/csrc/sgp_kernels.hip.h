@@ -387,6 +387,31 @@ __device__ __forceinline__ void tile_mma(Acc4& acc, const double* As, const doub
     }
 }
 
+// tile_mma with a SWIZZLED B panel: Bs[k][j] is stored at column j ^ (k & 60).  The kernels that build their B panel from K_uf
+// (k_quadform_cols, k_theta_grad_uf) read 32-byte pieces of K_uf columns -- 16 threads per column, thread g the k-rows 4 g .. 4 g + 3 --
+// and store them transposed: unswizzled, the 16 threads of a column write rows 4 g + q, 320 doubles apart = the same LDS bank,
+// a 16-way conflict on every store (the per-point kernels ran at 22 TFLOP/s).  With the XOR the 16 rows land on 16 different
+// bank pairs; a 16-lane MFMA operand read (one row, 16 consecutive columns) stays a permutation of an aligned 16-group, i.e.
+// conflict-free as before.
+__device__ __forceinline__ int bswz(int k, int j) { return j ^ (k & 60); }
+__device__ __forceinline__ void tile_mma_bswz(Acc4& acc, const double* As, const double* Bs, int kcount, int lane, int wr, int wc) {
+    const int li = lane & 15, lk = lane >> 4;
+    const double* ap = As + lk * PS + wr * 32 + li;
+    const double* bp = Bs + lk * PS;
+    const int c0 = wc * 32 + li, c1 = c0 + 16;
+#pragma unroll 4
+    for (int k = 0; k < kcount; k += 4) {
+        double a0 = ap[0], a1 = ap[16];
+        double b0 = bp[c0 ^ (k & 60)], b1 = bp[c1 ^ (k & 60)];
+        acc.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.t[0][0], 0, 0, 0);
+        acc.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.t[0][1], 0, 0, 0);
+        acc.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.t[1][0], 0, 0, 0);
+        acc.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.t[1][1], 0, 0, 0);
+        ap += 4 * PS;
+        bp += 4 * PS;
+    }
+}
+
 // The same for a DIAGONAL tile of a symmetric product (As and Bs hold the same rows, Bs weighted): only the 10 sub-tiles (R, C),
 // R >= C, of the 4 x 4 grid of 16 x 16 blocks are formed, dealt 3 : 2 : 2 : 3 over the waves --
 //   wave 0: (0,0) (1,0) (1,1)   wave 1: (2,0) (2,1)   wave 2: (3,0) (3,1)   wave 3: (2,2) (3,2) (3,3)
@@ -2363,10 +2388,34 @@ __global__ void __launch_bounds__(256) k_kernelmatrix(const double* __restrict__
 // reduced over the row-blocks by atomics-free two-pass (partial[rowblk][n]).
 //   mode 0: F used as stored (lower, rows i, sum over k <= i);  mode 1: F^T (upper), sum over k >= i.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_quadform_cols(const double* __restrict__ F, const double* __restrict__ Kuf,
-                                                       double* __restrict__ partial, int ld, int T, int64_t N, int mode) {
-    __shared__ double lds[2 * TB * PS];
-    __shared__ double colsum[4][TB];
+// Software-pipelined: the next tile pair is fetched into registers while the matrix cores work on the current one (one LDS
+// buffer, two barriers per tile); the triangular mask of the diagonal tile is applied in registers on the way into LDS; both
+// panels are stored transposed-with-XOR (see tile_mma_bswz) where the global reads run along k.  80 KB of LDS: two workgroups
+// per CU (the column sums reuse the panels' memory).  Round 3: 127 / 143 us per launch at T (one workgroup per CU, loads and
+// MFMAs back to back) -> see DESIGN.md section 6.
+template <bool ASWZ>
+__device__ __forceinline__ void tile_mma_swz(Acc4& acc, const double* As, const double* Bs, int kcount, int lane, int wr, int wc) {
+    const int li = lane & 15, lk = lane >> 4;
+    const double* ap = As + lk * PS;
+    const double* bp = Bs + lk * PS;
+    const int r0 = wr * 32 + li, r1 = r0 + 16, c0 = wc * 32 + li, c1 = c0 + 16;
+#pragma unroll 4
+    for (int k = 0; k < kcount; k += 4) {
+        const int x = k & 60;
+        double a0 = ap[ASWZ ? (r0 ^ x) : r0], a1 = ap[ASWZ ? (r1 ^ x) : r1];
+        double b0 = bp[c0 ^ x], b1 = bp[c1 ^ x];
+        acc.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.t[0][0], 0, 0, 0);
+        acc.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.t[0][1], 0, 0, 0);
+        acc.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.t[1][0], 0, 0, 0);
+        acc.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.t[1][1], 0, 0, 0);
+        ap += 4 * PS;
+        bp += 4 * PS;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void quadform_body(const double* __restrict__ F, const double* __restrict__ Kuf, double* __restrict__ partial,
+                                              int ld, int T, int64_t N, double* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int I = blockIdx.y;
     const int64_t n0 = (int64_t)blockIdx.x * TB;
@@ -2374,46 +2423,56 @@ __global__ void __launch_bounds__(256) k_quadform_cols(const double* __restrict_
     double* Bs = lds + TB * PS;
     Acc4 acc;
     acc_zero(acc);
-    const int kbeg = (mode == 0) ? 0 : I, kend = (mode == 0) ? I + 1 : T;
-    for (int k = kbeg; k < kend; ++k) {
-        __syncthreads();
-        if (mode == 0) {
-            // As[kk][i] = F[(I*64 + i), (k*64 + kk)]
-            load_panel_n(As, F, ld, I * TB, k * TB, TB, tid);
-        } else {
-            // As[kk][i] = F^T[(I*64+i), (k*64+kk)] = F[(k*64+kk), (I*64+i)]
-            load_panel_t(As, F, ld, k * TB, I * TB, TB, tid);
-        }
-        // Bs[kk][j] = Kuf[(k*64 + kk), n0 + j]
-        for (int t = tid; t < TB * 16; t += 256) {
-            int j = t >> 4, g = t & 15;
-            int64_t n = n0 + j;
-            double v[4] = {0.0, 0.0, 0.0, 0.0};
-            if (n < N) {
-                const double* src = Kuf + (size_t)n * ld + k * TB + g * 4;
-                double2 v0 = *reinterpret_cast<const double2*>(src);
-                double2 v1 = *reinterpret_cast<const double2*>(src + 2);
-                v[0] = v0.x; v[1] = v0.y; v[2] = v1.x; v[3] = v1.y;
-            }
+    const int kbeg = (MODE == 0) ? 0 : I, kend = (MODE == 0) ? I + 1 : T;
+    // staging maps, 4 passes of 256 threads each.  A, mode 0 (F as stored: contiguous along i): thread -> (kk = t >> 4, rows 4 (t & 15) ..);
+    // A, mode 1 (F^T: contiguous along kk) and B (K_uf columns: contiguous along kk): thread -> (i or j = t >> 4, kk = 4 (t & 15) ..)
+    double2 ra[4][2], rb[4][2];
+    auto gload = [&](int k) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Bs[(g * 4 + q) * PS + j] = v[q];
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + 256 * u, hi = t >> 4, lo4 = (t & 15) * 4;
+            const double* sa = (MODE == 0) ? F + (size_t)(k * TB + hi) * ld + I * TB + lo4        // F[I*64 + lo4 .., k*64 + hi]
+                                           : F + (size_t)(I * TB + hi) * ld + k * TB + lo4;       // F[k*64 + lo4 .., I*64 + hi]
+            ra[u][0] = *reinterpret_cast<const double2*>(sa);
+            ra[u][1] = *reinterpret_cast<const double2*>(sa + 2);
+            const int64_t n = n0 + hi;
+            if (n < N) {
+                const double* sb = Kuf + (size_t)n * ld + k * TB + lo4;
+                rb[u][0] = *reinterpret_cast<const double2*>(sb);
+                rb[u][1] = *reinterpret_cast<const double2*>(sb + 2);
+            } else {
+                rb[u][0] = make_double2(0.0, 0.0);
+                rb[u][1] = make_double2(0.0, 0.0);
+            }
         }
+    };
+    auto lstore = [&](int k) {
+        const bool dg = (k == I);                     // the diagonal tile of the triangular factor: zero its other half
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + 256 * u, hi = t >> 4, lo4 = (t & 15) * 4;
+            const double va[4] = {ra[u][0].x, ra[u][0].y, ra[u][1].x, ra[u][1].y};
+            const double vb[4] = {rb[u][0].x, rb[u][0].y, rb[u][1].x, rb[u][1].y};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (MODE == 0) {
+                    const int kk = hi, i = lo4 + q;                              // As[kk][i] = F[I*64 + i, k*64 + kk], lower: kk <= i
+                    As[kk * PS + i] = (dg && kk > i) ? 0.0 : va[q];
+                } else {
+                    const int i = hi, kk = lo4 + q;                              // As[kk][i] = F[k*64 + kk, I*64 + i], lower: i <= kk
+                    As[kk * PS + (i ^ (lo4 & 60))] = (dg && kk < i) ? 0.0 : va[q];
+                }
+                Bs[(lo4 + q) * PS + (hi ^ (lo4 & 60))] = vb[q];                 // Bs[kk][j] = Kuf[k*64 + kk, n0 + j]
+            }
+        }
+    };
+    gload(kbeg);
+    for (int k = kbeg; k < kend; ++k) {
+        __syncthreads();                              // the previous tile pair has been consumed
+        lstore(k);
         __syncthreads();
-        if (mode == 0 && k == I) {
-            // diagonal tile of a lower-triangular F: zero the strict upper part of the panel
-            for (int t = tid; t < TB * TB; t += 256) {
-                int kk = t >> 6, i = t & 63;
-                if (kk > i) As[kk * PS + i] = 0.0;
-            }
-            __syncthreads();
-        } else if (mode == 1 && k == I) {
-            for (int t = tid; t < TB * TB; t += 256) {
-                int kk = t >> 6, i = t & 63;
-                if (kk < i) As[kk * PS + i] = 0.0;
-            }
-            __syncthreads();
-        }
-        tile_mma(acc, As, Bs, TB, lane, wr, wc);
+        if (k + 1 < kend) gload(k + 1);               // in flight while the matrix cores run
+        tile_mma_swz<MODE == 1>(acc, As, Bs, TB, lane, wr, wc);
     }
     // column sums of squares over this block's 64 rows
     double cs[2] = {0.0, 0.0};
@@ -2429,17 +2488,25 @@ __global__ void __launch_bounds__(256) k_quadform_cols(const double* __restrict_
         cs[tj] += __shfl_xor(cs[tj], 32);
     }
     __syncthreads();
+    double* colsum = lds;                             // [4][TB], reusing the panels
     if (lane < 16) {
-        colsum[wave][(wc * 32) + lane] = cs[0];           // waves (wr,wc): rows wr*32.., cols wc*32..
-        colsum[wave][(wc * 32) + 16 + lane] = cs[1];
+        colsum[wave * TB + (wc * 32) + lane] = cs[0];        // waves (wr,wc): rows wr*32.., cols wc*32..
+        colsum[wave * TB + (wc * 32) + 16 + lane] = cs[1];
     }
     __syncthreads();
     if (tid < TB) {
         int wcol = tid >> 5;                               // which wc owns this column
-        double s = colsum[0 * 2 + wcol][tid] + colsum[1 * 2 + wcol][tid];
+        double s = colsum[(0 * 2 + wcol) * TB + tid] + colsum[(1 * 2 + wcol) * TB + tid];
         int64_t n = n0 + tid;
         if (n < N) partial[(size_t)I * N + n] = s;
     }
+}
+
+__global__ void __launch_bounds__(256) k_quadform_cols(const double* __restrict__ F, const double* __restrict__ Kuf,
+                                                       double* __restrict__ partial, int ld, int T, int64_t N, int mode) {
+    __shared__ double lds[2 * TB * PS];
+    if (mode == 0) quadform_body<0>(F, Kuf, partial, ld, T, N, lds);
+    else quadform_body<1>(F, Kuf, partial, ld, T, N, lds);
 }
 
 // I1_n = sigma2 - sum_I pa[I][n] ;  I2_n = y^2 + v - 2 y (k_n . mu) + sum_I pb[I][n]
@@ -2533,10 +2600,10 @@ __global__ void __launch_bounds__(256) k_theta_grad_uf(const double* __restrict_
                 v[0] = v0.x; v[1] = v0.y; v[2] = v1.x; v[3] = v1.y;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Bs[(g * 4 + q) * PS + j] = v[q];
+            for (int q = 0; q < 4; ++q) Bs[(g * 4 + q) * PS + bswz(g * 4, j)] = v[q];
         }
         __syncthreads();
-        tile_mma(acc, As, Bs, TB, lane, wr, wc);
+        tile_mma_bswz(acc, As, Bs, TB, lane, wr, wc);
     }
     __syncthreads();
     // the panels are done: their LDS now holds the scaled coordinates of this block's 64 inducing rows / 64 points

@@ -251,6 +251,32 @@ function train!(meta::HipSGPMeta, X::Matrix{Float64}, y::Vector{Float64}, θ::Ve
     return θout
 end
 
+# The classification loop (experiments/classification_banana.ipynb cell 9: `y[i] ~ Probit(f[i])`, q(w) = GammaShapeRate carried
+# over the minibatches, q(v) never reset): labels 0 / 1 in y; returns (θ, shape, rate).  sgp_train_likelihood turns the run
+# opened by sgp_train_begin into this loop -- forward message, Probit moment matching, Gamma update and AdaMax on the device.
+function train_classification!(meta::HipSGPMeta, X::Matrix{Float64}, y::Vector{Float64}, θ::Vector{Float64}; batch, epochs,
+                               shape = 0.01, rate = 0.01, prior_var = 50.0, η = 1e-3, β = (0.9, 0.999), ϵ = 1e-8)
+    h = meta.handle; N = length(y)
+    set_prior!(h, C_NULL, fill(Float64(prior_var), 1, 1), 2)
+    check(ccall((:sgp_train_begin, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Int32, Float64, Float64, Float64, Float64, Float64),
+                h.ptr, X, y, N, θ, length(θ) - 1, meta.jitter, η, β[1], β[2], ϵ), h.ptr)
+    check(ccall((:sgp_train_likelihood, LIB), Cint, (Ptr{Cvoid}, Int32, Float64, Float64), h.ptr, Int32(1), shape, rate), h.ptr)   # SGP_LIKELIHOOD_PROBIT
+    for _ in 1:epochs, o in 0:batch:N-1
+        check(ccall((:sgp_train_step, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Int32), h.ptr, o, min(batch, N - o), Int32(1)), h.ptr)
+    end
+    θout = similar(θ); counts = zeros(Int64, 2); ab = zeros(2)
+    check(ccall((:sgp_train_end, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}), h.ptr, θout, counts), h.ptr)
+    check(ccall((:sgp_train_get_gamma, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, ab), h.ptr)
+    counts[2] == 0 || throw(PosDefException(Int(counts[2])))
+    return θout, ab[1], ab[2]
+end
+
+# Multi-GPU (one Julia process per GPU, e.g. under MPI.jl): register the communicator once; sgp_sweep / sgp_theta_objective /
+# sgp_train_step then sum what has to be summed inside the library -- the exchange buffer [lower tiles of Ψ2 | B | scalars] and
+# the data half of the θ gradient -- and every rank sees the statistics, the objective and the gradient of all shards.
+use_rccl!(h::Handle, comm::Ptr{Cvoid}) = check(ccall((:sgp_use_rccl, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h.ptr, comm), h.ptr)
+
 # ------------------------------------------------------------------------------------------------------------------
 # MultiSGP
 # ------------------------------------------------------------------------------------------------------------------

@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
-"""profiles/r02_pmc_traffic.json from the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the bench command: the
-HBM / fabric bytes per k_syrk_stream launch that bench.py reports as roofline.traffic.  FETCH_SIZE is doubled as
-MI355X_MICROARCH.md prescribes for 16-B-per-lane streaming reads (gfx950 tallies 128-B requests at 64 B)."""
+"""profiles/r03_pmc_traffic.json from the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the bench command (run with
+SGP_BENCH_SKIP_ALONE=1: every k_syrk_stream launch is then one of the timed sweeps' own): the HBM / fabric bytes per k_syrk_stream
+launch that bench.py reports as roofline.traffic -- the average over the sweep's launches (one per statistics group of the
+overlapped sweep), with the per-grid breakdown.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane
+streaming reads (gfx950 tallies 128-B requests at 64 B)."""
 import csv, json, subprocess, sys, collections
+
+
+by_grid = {}
 
 
 def avg_kib(path, counter):
@@ -10,7 +15,9 @@ def avg_kib(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter and "k_syrk_stream" in r["Kernel_Name"]:
             acc[0].append(float(r["Counter_Value"]))
+            acc[("grid", int(r.get("Grid_Size", 0) or 0) // 256)].append(float(r["Counter_Value"]))
     v = acc[0]
+    by_grid[counter] = {str(k[1]): {"launches": len(x), "avg_kib": sum(x) / len(x)} for k, x in acc.items() if k != 0}
     return sum(v) / len(v), len(v)
 
 
@@ -23,7 +30,7 @@ except Exception:
     commit = "unknown"
 rec = {"workload": workload, "n_gpus": 1, "kernel": "k_syrk_stream",
        "fetch_size_bytes": f * 1024, "write_size_bytes": w * 1024, "fetch_correction": 2.0,
-       "traffic_bytes_per_launch": 2.0 * f * 1024 + w * 1024, "launches_averaged": [nf, nw], "commit": commit,
-       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 20 --warmup 3"}
+       "traffic_bytes_per_launch": 2.0 * f * 1024 + w * 1024, "launches_averaged": [nf, nw], "by_grid_workgroups": by_grid, "commit": commit,
+       "source": "SGP_BENCH_SKIP_ALONE=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline"}
 json.dump(rec, open(out, "w"), indent=1)
 print(json.dumps(rec))
