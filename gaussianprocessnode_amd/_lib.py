@@ -65,6 +65,8 @@ def library_path(variant=None) -> str:
 def load(build_if_missing: bool = True, variant=None):
     """Load csrc/libsgp_hip.so -- or a variant library of the same ABI, see _build.VARIANTS -- building it first if hipcc is
     available.  Raises if it cannot."""
+    if variant is None:
+        variant = os.environ.get("SGP_LIB_VARIANT") or None      # diagnostics: run any script on a variant library (tools/step_trace.py)
     if variant in _libs:
         return _libs[variant]
     # PyTorch (used for streams / torch.distributed around this library) bundles its own libamdhip64.so.7.

@@ -163,6 +163,7 @@ struct sgp_handle {
     int64_t stats_count = 0;
     size_t slab_capacity = 0;
     Graph gLocal, gFinish, gFinish2, gKuu;
+    double* dBred = nullptr;
     double* dPack = nullptr;       // exchange buffer of data-sharded sweeps: [lower tiles | B | scalars] (allocated with the hook)
     int64_t pack_count = 0;
     bool pack_now = false;         // the statistics being enqueued go to dPack (exchange_stats follows)
@@ -423,6 +424,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dOmega, nmax);
     ALLOC(h->dKuf, Mp * nmax);
     ALLOC(h->dBpart, nblk_max * h->dout * Mp);
+    ALLOC(h->dBred, (size_t)h->T * h->dout * 4 * TB);      // k_assemble: where the four waves of a B block meet
     ALLOC(h->dSlabs, h->slab_capacity);
     ALLOC(h->dStatsOwn, (size_t)h->stats_count);
     ALLOC(h->dJoin, WORD_COUNT);
@@ -591,7 +593,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
                     h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
                     h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals, h->dUvWork,
                     h->dGradM, h->dGradPart, h->dGrad, h->dCall, h->dSaccK,
-                    h->dTrainX, h->dTrainY, h->dTrain, h->dTrainParams, h->dJoin, h->dPack};
+                    h->dTrainX, h->dTrainY, h->dTrain, h->dTrainParams, h->dJoin, h->dPack, h->dBred};
     for (void* b : bufs) if (b) hipFree(b);
 #ifdef SGP_WITH_PERSISTENT_CHAIN
     void* cbufs[] = {h->dChainFlags[0], h->dChainFlags[1],
@@ -630,24 +632,27 @@ extern "C" int sgp_set_inducing(sgp_handle* h, const double* Xu) {
 //     bound as the K_uu chain's gate).
 //   * group 0 (tile columns [0, c0) of P Lambda P = the LAST c0 tile rows of Psi2) runs on all CUs in front of the chain, the
 //     other groups on the masked stream while the chain factors; a group must be complete when the chain reaches its first
-//     column.  The cuts are chosen by a small model of that schedule (all plans of up to three groups are tried): per-tile
-//     SYRK time proportional to n (1.63 us per 10 000 points on all CUs, measured at T), the masked groups slower by the CU
-//     ratio, ~12 / ~10 us of launch gaps + assembly per unmasked / masked group, ~18 us per chain step.  Measured at T
+//     column.  The cuts are chosen by a small model of that schedule (all plans of up to three groups are tried): a SYRK
+//     launch lasts as long as its chunks are long (0.159 us per point of a chunk + 4 us, from the launch's real geometry),
+//     ~8 / ~6 us of assembly and gaps per unmasked / masked group, ~18 us per chain step.  Measured at T
 //     (N = 10 000, M = 512; sweeps/s on one box): plain order 3750; cuts {3} 3896, {2} 3832-3950, {2,4} 3925, {1,3} 3656,
 //     {2,3,5} 3790, {1,2,4} 3528 -- the model ranks them the same way.  When no plan beats the plain order by 5 us the plain
 //     order stays (huge N: the masked groups' lost CUs cost more than the chain's early start saves).
 static double model_overlap_end(const sgp_handle* h, int64_t n, const int* cuts, int ncuts, double* classic_end) {
     const int T = h->T;
-    const double tau0 = 1.63e-4 * (double)n, taum = tau0 * (double)h->num_cus / (double)h->stat_cus_masked;
-    const double ovh0 = 12.0, ovhm = 10.0, step = 18.0;
-    auto tiles_upto = [&](int c) { return c * (2 * T - c + 1) / 2; };
-    if (classic_end) *classic_end = h->ntiles * tau0 + ovh0 + step * T;
+    // one SYRK launch = one resident round: its duration follows the points per chunk (0.159 us per point at four workgroups
+    // per CU, + ~4 us of launch ramp and tail), whatever the number of tiles -- fewer CUs or an awkward tile count show up as
+    // fewer, longer chunks (syrk_geometry)
+    auto syrk_us = [&](int row_lo, int nrows, int cus) { return 4.0 + 0.159 * syrk_geometry(row_lo, nrows, cus, n).chunk; };
+    const double asm0 = 8.0, asmm = 6.0, step = 18.0;        // assembly + gaps behind a group's SYRK (unmasked / masked)
+    if (classic_end) *classic_end = syrk_us(0, T, h->num_cus) + asm0 + step * T;
     double ready[LAM_MAX_COLS];
-    double t = tiles_upto(cuts[0]) * tau0 + ovh0;             // group 0 assembled
+    double t = syrk_us(T - cuts[0], cuts[0], h->num_cus) + asm0;          // group 0 assembled
     for (int c = 0; c < cuts[0]; ++c) ready[c] = t;
+    t -= asm0 - 2.0;                                          // the masked stream starts when group 0's assembly does
     for (int g = 0; g < ncuts; ++g) {
         const int c0 = cuts[g], c1 = (g + 1 < ncuts) ? cuts[g + 1] : T;
-        t += (tiles_upto(c1) - tiles_upto(c0)) * taum + ovhm;
+        t += syrk_us(T - c1, c1 - c0, h->stat_cus_masked) + asmm;
         for (int c = c0; c < c1; ++c) ready[c] = t;
     }
     double end = ready[0];
@@ -981,7 +986,7 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_assemble, dim3(T, T + 1, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal,
                        h->pack_now ? h->dPack : h->dStats, Mp, T, ga, h->n > 0 ? h->nblk : 0, h->dout,
                        SGP_S_COUNT + h->dout * h->dout, 1, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL, h->dInfo + 1, (long long*)nullptr, 0LL,
-                       h->pack_now ? 1 : 0);
+                       h->pack_now ? 1 : 0, h->dBred);
 }
 
 // The statistics of an overlapped sweep (see plan_overlap): the same kernels, the SYRK and the assembly once per tile-row group.
@@ -1021,7 +1026,8 @@ static void enqueue_stats_overlapped(sgp_handle* h, hipStream_t own) {
         hipLaunchKernelGGL(k_assemble, dim3(G.nrows, T + (g == 0 ? 1 : 0), 16), dim3(256), 0, s, h->dSlabs + G.slab_off, h->dBpart,
                            h->dDataScal, h->dStats, Mp, T, G.geom, h->nblk, h->dout,
                            SGP_S_COUNT + h->dout * h->dout, g == 0 ? 1 : 0, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL,
-                           g == 0 ? h->dInfo + 1 : (int*)nullptr, g == 0 ? h->dJoin + WORD_ASM0 : (long long*)nullptr, h->stat_epoch, 0);
+                           g == 0 ? h->dInfo + 1 : (int*)nullptr, g == 0 ? h->dJoin + WORD_ASM0 : (long long*)nullptr, h->stat_epoch, 0,
+                           h->dBred);
         if (G.masked || g1_mode == 1) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_GROUP0 + g, h->stat_epoch);
     }
 }

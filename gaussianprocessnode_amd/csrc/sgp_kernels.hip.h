@@ -647,7 +647,8 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
                                                   const double* __restrict__ data_scalars, double* __restrict__ stats,
                                                   int Mp, int T, SyrkGeom g, int nblk, int d_out,
                                                   int nscal, int do_b, int64_t* stamps, int* __restrict__ info_reset,
-                                                  long long* start_word, long long start_value, int packed) {
+                                                  long long* start_word, long long start_value, int packed,
+                                                  double* __restrict__ bscratch) {
     // grid (rows, T + do_b, 16): blocks (x, y < T, z) sum rows [4 z, 4 z + 4) of the slab tile (I, J) = (row_lo + x, y), I >= J --
     // one entry per thread, up to 12 chunk loads in flight (the kernel is latency-bound: the first version, 4 entries per
     // thread in rounds of 4 chunks on a quarter of the workgroups, took 12 us for 28 MB) -- and write both mirror images.
@@ -711,11 +712,16 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
             if (I != J) stats[(size_t)(I * TB + z * 4 + il) * Mp + J * TB + j] = s;
         }
     }
-    // B = sum of the per-block partials: the blocks of the extra grid row take the (row block, output) pairs; 4 adjacent lanes
-    // per entry walk the partials with a stride of 4 (16 independent loads in flight) and are combined in a fixed order
+    // B = sum of the per-block partials: the blocks of the extra grid row take the (row block, output) pairs; 4 threads per
+    // entry -- one per wave, so that a wave reads 512-byte runs -- walk the partials with a stride of 4 (16 independent loads in
+    // flight) and are combined in a fixed order.  The four waves meet through a few hundred bytes of GLOBAL scratch (`bscratch`,
+    // written, workgroup barrier, read back by wave 0 on the same CU), not through LDS: any LDS in this launch -- static, or
+    // dynamic for the whole grid -- keeps a fourth SYRK workgroup off every CU that still holds one of its blocks, and the next
+    // group's SYRK then needs a second round (measured: +15 us on the statistics).  (Four adjacent lanes per entry and
+    // shuffles instead: 430 instead of 180 us for the 15 625 partial rows of N = 10^6.)
     if (do_b && J == T) {
         double* B = stats + (packed ? (size_t)(T * (T + 1) / 2) * (TB * TB) : (size_t)Mp * Mp);
-        const int m = tid >> 2, part = tid & 3;
+        const int m = tid & 63, part = tid >> 6;
         const int bid = blockIdx.x * 16 + z, nb = gridDim.x * 16;
         for (int pair = bid; pair < T * d_out; pair += nb) {
             const int Ib = pair % T, o = pair / T;
@@ -733,10 +739,10 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
                 for (int u = 0; u < 4; ++u) acc[u] += bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + Ib * TB + m];
             }
             for (; b < nblk; b += 4) acc[0] += bpart[((size_t)b * d_out + o) * Mp + Ib * TB + m];
-            double v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            v += __shfl_xor(v, 1);                           // (part 0 + part 1), (part 2 + part 3)
-            v += __shfl_xor(v, 2);
-            if (part == 0) B[(size_t)o * Mp + Ib * TB + m] = v;
+            double* red = bscratch + (size_t)pair * (4 * TB);
+            red[part * TB + m] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            __syncthreads();                                     // (waits for the stores: a workgroup-scope release)
+            if (part == 0) B[(size_t)o * Mp + Ib * TB + m] = (red[m] + red[TB + m]) + (red[2 * TB + m] + red[3 * TB + m]);
         }
         if (bid == 0)
             for (int e = tid; e < nscal; e += 256) B[(size_t)Mp * d_out + e] = data_scalars[e];

@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
-"""Copy what tools/measure_round.sh left under gpurun_out/final/ into profiles/r02_* (the tracked, judged copies) and stamp
+"""Copy what tools/measure_round.sh left under gpurun_out/final/ into profiles/r03_* (the tracked, judged copies) and stamp
 the traffic record with the commit (the GPU box has no .git).  Prints the headline figures."""
 import json, os, re, shutil, subprocess
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F, P = os.path.join(R, "gpurun_out", "final"), os.path.join(R, "profiles")
-names = {"bench_T.json": "r02_bench_T.json", "bench_N1M.json": "r02_bench_N1M.json", "kt.json": "r02_bench_T_under_rocprof.json",
-         "kernel_stats.csv": "r02_bench_T_kernel_stats.csv", "kernel_stats_per_sweep.txt": "r02_bench_T_kernel_stats_per_sweep.txt",
-         "timeline.txt": "r02_bench_T_timeline_one_sweep.txt", "syrk_launches.txt": "r02_syrk_launches.txt",
-         "pmc_FETCH_SIZE.txt": "r02_pmc_fetch_size_T.txt", "pmc_WRITE_SIZE.txt": "r02_pmc_write_size_T.txt",
-         "pmc_mfma.txt": "r02_pmc_mfma_T.txt", "config_rates.txt": "r02_config_rates.txt", "accuracy_sweep.txt": "r02_accuracy_sweep.txt",
-         "train_kin40k.txt": "r02_train_kin40k.json", "train_banana.txt": "r02_train_banana.json", "pytest_gpu.txt": "r02_pytest_gpu.txt",
-         "step_trace.txt": "r02_step_trace.txt"}
+names = {"bench_T.json": "r03_bench_T.json", "bench_N1M.json": "r03_bench_N1M.json", "kt.json": "r03_bench_T_under_rocprof.json",
+         "kernel_stats.csv": "r03_bench_T_kernel_stats.csv", "kernel_stats_per_sweep.txt": "r03_bench_T_kernel_stats_per_sweep.txt",
+         "sweep_timeline_T.txt": "r03_sweep_timeline_T.txt", "sweep_timeline_T_plain_order.txt": "r03_sweep_timeline_T_plain_order.txt",
+         "sweep_timeline_C3.txt": "r03_sweep_timeline_C3.txt", "syrk_launches.txt": "r03_syrk_launches.txt",
+         "bench_T_plain_order.json": "r03_bench_T_plain_order.json", "pmc_valu.txt": "r03_pmc_valu_T.txt",
+         "hooked_train.json": "r03_hooked_train.json", "hooked_train_kernel_stats.txt": "r03_hooked_train_kernel_stats.txt",
+         "soak.txt": "r03_soak.txt", "rehearse_two_ranks.txt": "r03_rehearse_two_ranks.txt",
+         "pmc_FETCH_SIZE.txt": "r03_pmc_fetch_size_T.txt", "pmc_WRITE_SIZE.txt": "r03_pmc_write_size_T.txt",
+         "pmc_mfma.txt": "r03_pmc_mfma_T.txt", "config_rates.txt": "r03_config_rates.txt", "accuracy_sweep.txt": "r03_accuracy_sweep.txt",
+         "train_kin40k.txt": "r03_train_kin40k.json", "train_banana.txt": "r03_train_banana.json", "pytest_gpu.txt": "r03_pytest_gpu.txt",
+         }
 for a, b in names.items():
     src = os.path.join(F, a)
     if not os.path.exists(src):
@@ -20,15 +24,15 @@ for a, b in names.items():
 c = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True, cwd=R).strip()
 d = json.load(open(os.path.join(F, "pmc_traffic.json")))
 d["commit"] = c + " (library and bench as of this commit; the GPU box has no .git, stamped when the summary was copied)"
-json.dump(d, open(os.path.join(P, "r02_pmc_traffic.json"), "w"), indent=1)
+json.dump(d, open(os.path.join(P, "r03_pmc_traffic.json"), "w"), indent=1)
 last = lambda f: json.loads(open(os.path.join(P, f)).read().strip().splitlines()[-1])
-b, n, t = last("r02_bench_T.json"), last("r02_bench_N1M.json"), last("r02_train_kin40k.json")
+b, n, t = last("r03_bench_T.json"), last("r03_bench_N1M.json"), last("r03_train_kin40k.json")
 r, p = b["roofline"], b["phases_us"]
 print(f"T: {b['value']:.0f} it/s, wall {b['ms_per_step']*1e3:.1f} us, device {p['sweep_device']:.1f}, local {p['local']:.1f} (gram {p['gram_uf']:.1f}, "
       f"syrk {p['syrk']:.1f}), F1 {p['finish1_lambda_chain']:.1f}, F2 {p['finish2_traces']:.1f}")
-print(f"   syrk alone {r['launch_us']:.1f} us = {r['achieved']:.1f} TF, frac {r['frac']:.3f}, of probe {r['frac_of_mfma_probe']:.2f} ({r['mfma_probe_tflops']:.1f} TF at "
+print(f"   syrk launches (avg of {r['launches_per_sweep']}) {r['launch_us']:.1f} us = {r['achieved']:.1f} TF, frac {r['frac']:.3f}, of probe {r['frac_of_mfma_probe']:.2f} ({r['mfma_probe_tflops']:.1f} TF at "
       f"{b['sclk_mhz_under_mfma_f64']:.0f} MHz); chain frac {b['roofline_chain']['frac']:.3f} floor {b['roofline_chain']['floor_us']:.1f}; cpu {b['cpu_baseline']['value']:.2f}")
 print(f"N1M: {n['value']:.1f} sweeps/s, gram {n['phases_us']['gram_uf']/1e3:.2f} ms, syrk {n['phases_us']['syrk']/1e3:.2f} ms, local {n['phases_us']['local']/1e3:.2f} ms")
 print(f"kin40k training: {t['train_seconds']:.2f} s")
-print(open(os.path.join(P, "r02_syrk_launches.txt")).read().splitlines()[2])
-print(open(os.path.join(P, "r02_config_rates.txt")).read())
+print(open(os.path.join(P, "r03_syrk_launches.txt")).read().splitlines()[2])
+print(open(os.path.join(P, "r03_config_rates.txt")).read())

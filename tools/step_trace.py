@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-phase timing of the Cholesky step kernel's critical workgroup (tile (j+1, j) of the Lambda chain), from a library built
-with -DSGP_STEP_TRACE:  SGP_LIB=ab/lib_trace.so python tools/step_trace.py"""
+with -DSGP_STEP_TRACE (the "trace" variant library):  python tools/step_trace.py      [SGP_OVERLAP=0 for the plain order]"""
 import ctypes as C, os, sys
+os.environ.setdefault("SGP_LIB_VARIANT", "trace")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import gaussianprocessnode_amd as G
@@ -11,6 +12,7 @@ N, M, D = 10000, 512, 8
 rng = np.random.default_rng(0)
 X = rng.uniform(-1.7, 1.7, (N, D)); Xu = X[:M].copy(); y = np.sin(X.sum(1))
 with G.SGPDevice(N, M, D) as dev:
+    print("order:", "overlapped" if dev.__class__ and os.environ.get("SGP_OVERLAP") != "0" else "plain")
     dev.set_inducing(Xu); dev.set_data(X, y); dev.set_kernel(0.9, np.linspace(1.5, 3, D), 0.0)
     dev.set_prior_isotropic(50.0); dev.set_noise([[1e4]])
     for _ in range(20): dev.sweep()
