@@ -157,6 +157,7 @@ struct sgp_handle {
     long long stat_epoch = 0;      // number of the last overlapped sweep: what its groups' words dJoin[WORD_GROUP0 + g] receive
     int env_overlap = -1;          // SGP_OVERLAP: 0 off, 1 on wherever it is possible; default: where the planner's model says it pays
     int env_g1_mode = 2;           // SGP_G1_AFTER (see enqueue_stats_overlapped)
+    int env_syrk_wt = 0;           // SGP_SYRK_WT (see plan_overlap)
     std::vector<int> env_overlap_cols;   // SGP_OVERLAP_COLS: group boundaries (tile columns of P Lambda P), e.g. "3" or "2,4"
     int nblk = 0, ntiles = 0, num_cus = 256;
     SyrkGeom geom{};               // the plain sweep's single SYRK launch over all tile rows (set_point_count)
@@ -251,6 +252,7 @@ static SyrkGeom syrk_geometry(int row_lo, int nrows, int cus, int64_t n) {
     g.ntiles = (row_lo + nrows) * (row_lo + nrows + 1) / 2 - g.tile0;
     g.chunk = KB;
     g.nchunks = 0;
+    g.write_through = 0;
     if (n <= 0) return g;
     const int slots = SYRK_BLOCKS_PER_CU * std::max(8, cus);
     int a = 8;
@@ -464,6 +466,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         if (const char* lim = getenv("SGP_SPIN_LIMIT")) h->spin_limit = std::max(1, atoi(lim));
         if (const char* ov = getenv("SGP_OVERLAP")) h->env_overlap = atoi(ov);
         if (const char* g1 = getenv("SGP_G1_AFTER")) h->env_g1_mode = atoi(g1);
+        if (const char* wt = getenv("SGP_SYRK_WT")) h->env_syrk_wt = atoi(wt);
         if (const char* oc = getenv("SGP_OVERLAP_COLS"))
             for (const char* q = oc; *q;) {
                 h->env_overlap_cols.push_back(atoi(q));
@@ -693,6 +696,8 @@ static void plan_overlap(sgp_handle* h, int64_t n) {
         G.masked = g > 0;
         G.form_step = G.c0;
         G.geom = syrk_geometry(G.row_lo, G.nrows, G.masked ? h->stat_cus_masked : h->num_cus, n);
+        // SGP_SYRK_WT (A/B, see k_syrk_stream): 0 plain slab stores (default), 1 write-through in the masked groups, 2 in all
+        G.geom.write_through = (h->env_syrk_wt == 2 || (h->env_syrk_wt == 1 && G.masked)) ? 1 : 0;
         G.ntiles = G.geom.ntiles;
         G.slab_off = off;
         off += syrk_items(G.geom) * TB * TB;

@@ -513,7 +513,7 @@ __device__ __forceinline__ void tile_from_index(int t, int& I, int& J) {
 // row-major; a diagonal tile as the full symmetric tile).
 template <bool DIAG>
 __device__ __forceinline__ void syrk_item(const double* __restrict__ Kuf, const double* __restrict__ omega, double* __restrict__ out,
-                                          double* lds, int Mp, int64_t N, int I, int J, int chunk_id, int chunk) {
+                                          double* lds, int Mp, int64_t N, int I, int J, int chunk_id, int chunk, bool write_through) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int64_t nbeg = (int64_t)chunk_id * chunk;
     int64_t nend = nbeg + chunk;
@@ -571,8 +571,17 @@ __device__ __forceinline__ void syrk_item(const double* __restrict__ Kuf, const 
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    out[acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj)] = acc.t[ti][tj][r];
+                for (int r = 0; r < 4; ++r) {
+                    // write_through (A/B switch SGP_SYRK_WT, default off): agent-scope stores, past this XCD's write-back L2, so
+                    // that the chain steps running beside this launch do not flush its slab lines at their kernel boundaries.
+                    // Measured at T, 4 alternations x 1000 sweeps on one box: 4118-4135 sweeps/s in all three modes -- no effect
+                    // on the overlapped sweep; alone, the single plain-order launch is slower with it (63.6 vs 59.5 us).
+                    double* dst = out + acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj);
+                    if (write_through)
+                        __hip_atomic_store((__attribute__((address_space(1))) double*)dst, acc.t[ti][tj][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        *dst = acc.t[ti][tj][r];
+                }
     } else {
         // the wave's sub-tiles (tile_mma_diag), each also at its mirror position: the slab is the full symmetric tile.
         // Accumulator slot s of the wave holds sub-tile (R0 + (s > 0), C0 + (s > 1)) for waves 0 / 3, (wave + 1, s) for waves 1 / 2
@@ -604,6 +613,7 @@ struct SyrkGeom {
     int row_lo, nrows;              // tile rows
     int tile0, ntiles;              // their lower tiles
     int chunk, nchunks;             // split of the point axis
+    int write_through;              // slabs stored past the L2 (launches that run beside the factorisation chains)
 };
 __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
                                                      double* __restrict__ slabs, int Mp, int64_t N, SyrkGeom g, int64_t* stamps,
@@ -631,10 +641,10 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
 #ifdef SGP_SYRK_DIAG_SKIP
     // two specialisations of the whole stage loop: with the choice inside the loop the kernel needed 148 VGPRs (2 waves per
     // SIMD, i.e. two workgroups per CU and a second round: 95 instead of 58 us)
-    if (I == J) syrk_item<true>(Kuf, omega, out, lds, Mp, N, I, J, chunk_id, chunk);
-    else syrk_item<false>(Kuf, omega, out, lds, Mp, N, I, J, chunk_id, chunk);
+    if (I == J) syrk_item<true>(Kuf, omega, out, lds, Mp, N, I, J, chunk_id, chunk, g.write_through != 0);
+    else syrk_item<false>(Kuf, omega, out, lds, Mp, N, I, J, chunk_id, chunk, g.write_through != 0);
 #else
-    syrk_item<false>(Kuf, omega, out, lds, Mp, N, I, J, chunk_id, chunk);
+    syrk_item<false>(Kuf, omega, out, lds, Mp, N, I, J, chunk_id, chunk, g.write_through != 0);
 #endif
     stamp_exit(stamps);
 }
