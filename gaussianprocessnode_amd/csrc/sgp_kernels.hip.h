@@ -63,7 +63,7 @@ __device__ __forceinline__ void trace_mark(int slot) {
     if ((threadIdx.x & 255) == 0 && slot < TRACE_SLOTS_N) g_sweep_trace[slot * 65] = realtime_ticks();
 }
 __device__ __forceinline__ void trace_end(int slot) {
-    if (threadIdx.x == 0 && slot < TRACE_SLOTS_N)
+    if ((threadIdx.x & 63) == 0 && slot < TRACE_SLOTS_N)      // every wave: the waves of a workgroup leave at different times
         atomicMax(&g_sweep_trace[slot * 65 + 1 + ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & 63)], (long long)realtime_ticks());
 }
 #else
@@ -1685,7 +1685,12 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     Acc4 accX;
     acc_zero(accX);
     const bool panel = (b == 0);
-    if (xgroup && !(panel && a != 0)) return;
+    // the diagonal workgroup of a chain that also wants W = L^-1 keeps its second half too: it inverts L_jj WHILE the first half
+    // factors it (below) -- with the inverse as a phase of its own after the factorisation the diagonal workgroup was the last
+    // to leave in half of the launches (in-kernel exit stamps: 21.8 us against the panel workgroups' 18.6), and the next step
+    // waits for the whole launch (A/B on one box, 3 x 1000 sweeps each: 4021 against 3990 sweeps/s)
+    const bool diag_inv = panel && a == 0 && Winv != nullptr;
+    if (xgroup && !(panel && (a != 0 || diag_inv))) return;
     // What this workgroup's tile column starts from (see LamForm): formed here (do_form), already in A (load_old), or neither yet
     const bool lam = form.stats != nullptr;
     const int fstep = lam ? (int)form.form_step[j + b] : -1;
@@ -1709,14 +1714,28 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     // update L_{j+1,j} L_{j+1,j}^T from the workgroup that solved L_{j+1,j} to the next launch (trsm_tile_next)
     double* Dn_out = scratch + (size_t)(1 + (j & 1)) * TB * TB;
     const double* Dn_in = scratch + (size_t)(2 - (j & 1)) * TB * TB;
-    if (j > 0 && a == 0 && b == 0) {                      // move the previous step's L_{j-1,j-1} into place
-        const int q0 = (j - 1) * TB;
+    if (j > 0 && a == 0 && b == 0 && xgroup == diag_inv) {  // move the previous step's L_{j-1,j-1} into place (by the half
+        const int q0 = (j - 1) * TB;                      // that has nothing on the critical path, if there are two)
         for (int e = tid; e < TB * TB; e += 256) A[(size_t)(q0 + (e >> 6)) * ld + q0 + (e & 63)] = scratch[e];
     }
     // the tiles this block updates are fetched into registers now, so that their latency hides behind the MFMA phase
     TileRegs rX, rS, rD;
     if (lam && j == 0) stamp_enter(form.stamps);
     STEP_TRACE(0);
+    if (diag_inv && xgroup) {
+        // ---- the diagonal block's solve group: W_jj = L_jj^-1 as the solve X L_jj^T = I, column block by column block in step
+        // with the factoring group's barriers exactly like a panel block's solve (column block cb of L_jj is final two
+        // intervals before it is needed); W_jj = X^T.  Row r of X is zero left of column r -- exactly: every term is 0 * finite.
+        for (int e = tid; e < TB * LT; e += 256) X[e] = (e / LT == e % LT) ? 1.0 : 0.0;
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl) __syncthreads();   // (tile in LDS, then the four intervals a panel block's update takes)
+        trsm_tile<true>(X, S, dprep, rinv);
+        for (int e = tid; e < TB * TB; e += 256) {
+            const int c = e >> 6, r = e & 63;
+            Winv[(size_t)(j0 + c) * ld + j0 + r] = X[c * LT + r];
+        }
+        return;
+    }
     if (panel && a != 0) {
         // ---- a block of the panel column below the diagonal: two groups of four waves ----
         if (!xgroup) {
@@ -1819,10 +1838,6 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);       // no other block reads A_jj in the last step
     else
         for (int e = tid; e < TB * TB; e += 256) scratch[e] = S[(e & 63) * LT + (e >> 6)];   // column-major tile
-    if (Winv) {
-        trtri_tile(S, rinv, X, lds);
-        tile_s2g(X, Winv, ld, j0, j0);
-    }
 }
 
 // v[kk] = V[64 kb + kk][j] = W'[Qp-1-64kb-kk][Qp-1-j]: 64 contiguous doubles of column Qp-1-j of W' (descending), read

@@ -50,4 +50,11 @@ for s in range(256):
 t0 = min(r[0] for r in rows if r[2].startswith("prep_xu (stats)") or r[2] == "gram_uf")
 for b, e, nm in sorted(rows):
     print(f"{(b - t0) / 100:9.1f} {(e - t0) / 100:9.1f} {(e - b) / 100:7.1f} us  {nm}")
+if os.environ.get("SGP_TRACE_WGS"):
+    # the chain steps have fewer than 64 workgroups: slot 1 + blockIdx of a step's record is that workgroup's own exit
+    for s in list(range(16, 24)) + list(range(40, 48)):
+        b = tr[s, 0]
+        if not b: continue
+        ends = [(int(e) - b) / 100 for e in tr[s, 1:] if e]
+        print(("Lambda" if s < 40 else "K_uu") + f" step {s % 8 if s < 40 else s - 40}: workgroup exits after " + " ".join(f"{e:.1f}" for e in ends))
 print(f"energy {sc.energy:.6f}")
