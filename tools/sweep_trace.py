@@ -52,9 +52,9 @@ for b, e, nm in sorted(rows):
     print(f"{(b - t0) / 100:9.1f} {(e - t0) / 100:9.1f} {(e - b) / 100:7.1f} us  {nm}")
 if os.environ.get("SGP_TRACE_WGS"):
     # the chain steps have fewer than 64 workgroups: slot 1 + blockIdx of a step's record is that workgroup's own exit
-    for s in list(range(16, 24)) + list(range(40, 48)):
+    for s in list(range(16, 25)) + list(range(40, 49)):       # (the launch behind the last step has no form: it shows as K_uu step Tn)
         b = tr[s, 0]
         if not b: continue
         ends = [(int(e) - b) / 100 for e in tr[s, 1:] if e]
-        print(("Lambda" if s < 40 else "K_uu") + f" step {s % 8 if s < 40 else s - 40}: workgroup exits after " + " ".join(f"{e:.1f}" for e in ends))
+        print(("Lambda" if s < 40 else "K_uu") + f" step {s - 16 if s < 40 else s - 40}: workgroup exits after " + " ".join(f"{e:.1f}" for e in ends))
 print(f"energy {sc.energy:.6f}")
