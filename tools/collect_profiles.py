@@ -7,7 +7,7 @@ F, P = os.path.join(R, "gpurun_out", "final"), os.path.join(R, "profiles")
 names = {"bench_T.json": "r03_bench_T.json", "bench_N1M.json": "r03_bench_N1M.json", "kt.json": "r03_bench_T_under_rocprof.json",
          "kernel_stats.csv": "r03_bench_T_kernel_stats.csv", "kernel_stats_per_sweep.txt": "r03_bench_T_kernel_stats_per_sweep.txt",
          "sweep_timeline_T.txt": "r03_sweep_timeline_T.txt", "sweep_timeline_T_plain_order.txt": "r03_sweep_timeline_T_plain_order.txt",
-         "sweep_timeline_C3.txt": "r03_sweep_timeline_C3.txt", "syrk_launches.txt": "r03_syrk_launches.txt",
+         "sweep_timeline_C3.txt": "r03_sweep_timeline_C3.txt", "step_trace_T.txt": "r03_step_trace_T.txt", "syrk_launches.txt": "r03_syrk_launches.txt",
          "bench_T_plain_order.json": "r03_bench_T_plain_order.json", "pmc_valu.txt": "r03_pmc_valu_T.txt",
          "hooked_train.json": "r03_hooked_train.json", "hooked_train_kernel_stats.txt": "r03_hooked_train_kernel_stats.txt",
          "soak.txt": "r03_soak.txt", "rehearse_two_ranks.txt": "r03_rehearse_two_ranks.txt",

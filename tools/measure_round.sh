@@ -29,7 +29,8 @@ cd $R
 timeout -k 10 300 python bench.py > $O/bench_T.json 2> $O/bench_T.err; tail -c 400 $O/bench_T.json; echo
 SGP_OVERLAP=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_T_plain_order.json 2> /dev/null
 timeout -k 10 300 python bench.py --workload N1M --no-cpu-baseline > $O/bench_N1M.json 2> $O/bench_N1M.err; tail -c 300 $O/bench_N1M.json; echo
-timeout -k 10 60 python tools/sweep_trace.py > $O/sweep_timeline_T.txt 2>&1
+SGP_TRACE_WGS=1 timeout -k 10 60 python tools/sweep_trace.py > $O/sweep_timeline_T.txt 2>&1
+timeout -k 10 60 python tools/step_trace.py > $O/step_trace_T.txt 2>&1
 SGP_OVERLAP=0 timeout -k 10 60 python tools/sweep_trace.py > $O/sweep_timeline_T_plain_order.txt 2>&1
 timeout -k 10 60 python tools/sweep_trace.py 40000 512 8 20 > $O/sweep_timeline_C3.txt 2>&1
 timeout -k 10 200 python tools/config_rates.py > $O/config_rates.txt 2>&1; tail -8 $O/config_rates.txt
