@@ -1585,7 +1585,7 @@ extern "C" int sgp_get_chain_trace(sgp_handle* h, int32_t which, int64_t* out) {
 extern "C" int sgp_get_step_trace(int64_t* out) {
     if (!out) return SGP_ERR_ARG;
     if (hipDeviceSynchronize() != hipSuccess) return SGP_ERR_HIP;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_trace), sizeof(long long) * 16 * 32) != hipSuccess) return SGP_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_trace), sizeof(long long) * 8 * 64) != hipSuccess) return SGP_ERR_HIP;
     return 0;
 }
 

@@ -1104,6 +1104,55 @@ __device__ __forceinline__ void trsm_tile(double* X, const double* S, const doub
     });
 }
 
+// One block of trsm_tile on its own: column block cb of the 16 rows of row block rb (any wave may take any row block: X lives
+// in LDS).  The unit of the scheduled solve group (k_potrf_step).
+template <int cb>
+__device__ __forceinline__ void trsm_block(double* X, const double* S, const double* Dp, const double* rinv, int rb) {
+    const int lane = threadIdx.x & 63;
+    const int r0 = 16 * rb;
+    const int li = lane & 15, lk = lane >> 4;
+    const int rr = lane >> 2, q = lane & 3;
+    if constexpr (cb > 0) {
+        d4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
+        const double* ap = X + (r0 + li) * LT + lk;
+        const double* bp = S + (16 * cb + li) * LT + lk;
+        double av[4 * cb], bv[4 * cb];
+#pragma unroll
+        for (int s4 = 0; s4 < 4 * cb; ++s4) { av[s4] = ap[4 * s4]; bv[s4] = bp[4 * s4]; }
+#pragma unroll
+        for (int s4 = 0; s4 < 4 * cb; ++s4)
+            acc[s4 & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc[s4 & 3], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+    }
+    double x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q];
+    solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [](auto) {});
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
+}
+// K-slice c (columns 16 c .. 16 c + 15 of the solved tile X) of the lower 16 x 16 tile (R, C) of X X^T, formed transposed
+// (A operand = the column tile) so that the stores run along Dn's columns (see trsm_tile_next)
+__device__ __forceinline__ void syrk_slice(d4& g, const double* X, int R, int C, int c) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const double* pa = X + (16 * C + li) * LT + 16 * c + lk;
+    const double* pb = X + (16 * R + li) * LT + 16 * c + lk;
+    double av[4], bv[4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) { av[k4] = pa[4 * k4]; bv[k4] = pb[4 * k4]; }
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) g = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k4], bv[k4], g, 0, 0, 0);
+}
+__device__ __forceinline__ void syrk_store(const d4& g, double* __restrict__ Dn, int R, int C) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Dn[(16 * C + lk + 4 * r) * TB + 16 * R + li] = g[r];
+}
+
 // trsm_tile for the workgroup that owns tile (j + 1, j): while it solves X = L_{j+1,j}, the matrix cores (idle during the
 // pivot runs, which are bound by instruction issue) also form the NEXT diagonal tile's update  X X^T  -- one MFMA per pivot,
 // on the 16-column slice of X finished by the previous column block -- and the lower 16 x 16 tiles of it go to Dn (64 x 64,
@@ -1376,10 +1425,32 @@ __device__ __forceinline__ void tile_fetch(TileRegs& t, bool do_form, bool load_
         for (int u = 0; u < 16; ++u) t.v[u] = 0.0;
     }
 }
+// (all LDS reads first, then eight 16-byte stores per thread: this is the last thing a panel block of a Cholesky step does)
 __device__ __forceinline__ void tile_s2g(const double* S, double* __restrict__ A, size_t ld, int row0, int col0) {
-    for (int e = threadIdx.x & 255; e < TB * TB; e += 256) {
-        int c = e >> 6, r = e & 63;
-        A[(size_t)(col0 + c) * ld + row0 + r] = S[r * LT + c];
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = (threadIdx.x & 255) + 256 * u, c = e >> 5, r = (e & 31) * 2;
+        v[u] = make_double2(S[r * LT + c], S[(r + 1) * LT + c]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = (threadIdx.x & 255) + 256 * u, c = e >> 5, r = (e & 31) * 2;
+        *reinterpret_cast<double2*>(A + (size_t)(col0 + c) * ld + row0 + r) = v[u];
+    }
+}
+// the same for the transposed tile: A(r, c) = S[c][r]
+__device__ __forceinline__ void tile_s2g_t(const double* S, double* __restrict__ A, size_t ld, int row0, int col0) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = (threadIdx.x & 255) + 256 * u, c = e >> 5, r = (e & 31) * 2;
+        v[u] = make_double2(S[c * LT + r], S[c * LT + r + 1]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = (threadIdx.x & 255) + 256 * u, c = e >> 5, r = (e & 31) * 2;
+        *reinterpret_cast<double2*>(A + (size_t)(col0 + c) * ld + row0 + r) = v[u];
     }
 }
 __device__ __forceinline__ void tile_sub_acc(double* S, const Acc4& acc, int lane, int wr, int wc) {
@@ -1629,10 +1700,14 @@ __device__ __forceinline__ bool wait_stat_group(const LamForm& f, int g) {
 }
 
 // Diagnostics (build with -DSGP_STEP_TRACE): 100 MHz stamps of the workgroup that owns tile (j + 1, j) of the Lambda chain,
-// slot 16 g + e of step j for event e of group g (0 factoring, 1 solve); read back with sgp_get_step_trace.
-__device__ long long g_step_trace[16 * 32];
+// slot 64 j + 32 g + e for event e of group g (0 factoring, 1 solve) of step j < 8; read back with sgp_get_step_trace.
+// SGP_STEP_TRACE_A: the panel block that is traced (1 = the one that also forms the next diagonal tile's update).
+__device__ long long g_step_trace[8 * 64];
+#ifndef SGP_STEP_TRACE_A
+#define SGP_STEP_TRACE_A 1
+#endif
 #ifdef SGP_STEP_TRACE
-#define STEP_TRACE(e) do { if (tv_t && a == 1 && b == 0 && lane == 0 && wave == 0 && j < 16) g_step_trace[j * 32 + (xgroup ? 16 : 0) + (e)] = realtime_ticks(); } while (0)
+#define STEP_TRACE(e) do { if (tv_t && a == SGP_STEP_TRACE_A && b == 0 && lane == 0 && wave == 0 && j < 8) g_step_trace[j * 64 + (xgroup ? 32 : 0) + (e)] = realtime_ticks(); } while (0)
 #else
 #define STEP_TRACE(e) do { } while (0)
 #endif
@@ -1729,11 +1804,26 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         for (int e = tid; e < TB * LT; e += 256) X[e] = (e / LT == e % LT) ? 1.0 : 0.0;
 #pragma unroll
         for (int sl = 0; sl < 5; ++sl) __syncthreads();   // (tile in LDS, then the four intervals a panel block's update takes)
+#ifdef SGP_LOCKSTEP_SOLVE
         trsm_tile<true>(X, S, dprep, rinv);
-        for (int e = tid; e < TB * TB; e += 256) {
-            const int c = e >> 6, r = e & 63;
-            Winv[(size_t)(j0 + c) * ld + j0 + r] = X[c * LT + r];
-        }
+#else
+        // (the panel blocks' schedule of the solve, see there)
+        if (wave == 0) { trsm_block<0>(X, S, dprep, rinv, 0); trsm_block<0>(X, S, dprep, rinv, 2); }
+        else if (wave == 1) { trsm_block<0>(X, S, dprep, rinv, 1); trsm_block<1>(X, S, dprep, rinv, 1); }
+        else if (wave == 3) { trsm_block<0>(X, S, dprep, rinv, 3); trsm_block<1>(X, S, dprep, rinv, 3); }
+        __syncthreads();
+        if (wave == 0) trsm_block<1>(X, S, dprep, rinv, 0);
+        else if (wave == 1) trsm_block<2>(X, S, dprep, rinv, 1);
+        else if (wave == 2) trsm_block<1>(X, S, dprep, rinv, 2);
+        __syncthreads();
+        if (wave == 0) trsm_block<2>(X, S, dprep, rinv, 0);
+        else if (wave == 1) trsm_block<2>(X, S, dprep, rinv, 3);
+        else if (wave == 2) trsm_block<2>(X, S, dprep, rinv, 2);
+        __syncthreads();
+        trsm_block<3>(X, S, dprep, rinv, wave);
+        __syncthreads();
+#endif
+        tile_s2g_t(X, Winv, ld, j0, j0);
         return;
     }
     if (panel && a != 0) {
@@ -1784,6 +1874,7 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
                 ap += 4 * PS; bp += 4 * PS;
             }
         };
+#ifdef SGP_LOCKSTEP_SOLVE                 // (A/B: the round-2 form -- every solve wave works in every interval)
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
             if (j > 0) {
@@ -1800,6 +1891,75 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         } else {
             trsm_tile<true>(X, S, dprep, rinv);
         }
+#else
+        // SIMD-AWARE SCHEDULE.  Wave w of the factoring group and wave w of this group share a SIMD (tools/simd_map_probe.hip:
+        // always, whatever the SIMD's number), and FP64 MFMAs and FP64 vector instructions share its pipe: a 64-cycle MFMA of
+        // this group in front of a dependent FMA of the pivot chain delays the chain by all of it.  Measured (step trace, this
+        // group's work compiled out): the factorisation takes 9.0 us alone and 13.3 with this group working in every interval.
+        // So in each of the eight barrier intervals of potf2_tile the waves whose SIMD carries the critical work stay idle:
+        //   I0 run 0 (factoring wave 0 pivots)          -> wave 0 idle
+        //   I1 phase 0 (waves 1, 2, 3 solve + update)   -> waves 1, 2, 3 idle
+        //   I2 run 1                                    -> wave 1 idle        I3 phase 1 (waves 2, 3)  -> waves 2, 3 idle
+        //   I4 run 2                                    -> wave 2 idle        I5 phase 2 (wave 3), I6 run 3 -> wave 3 idle
+        // and the work moves: the tile's own rank-64 update (four K-slices per wave, I0 .. I3) and the sixteen 16 x 16 blocks of
+        // the triangular solve (I4 .. I7; X is in LDS, so any wave can take any row block) go where a SIMD is free.
+        {
+            int done = 0;
+            auto slices = [&](int n) {
+                if (j == 0) return;
+                for (int q = 0; q < n; ++q) own_slice(done++);
+                if (done == 4) { tile_sub_acc(X, accX, lane, wr, wc); done = 5; }
+            };
+            slices(wave == 0 ? 0 : (wave == 1 ? 3 : 2));                       // I0
+            STEP_TRACE(3); __syncthreads(); STEP_TRACE(4);
+            slices(wave == 0 ? 2 : 0);                                         // I1
+            STEP_TRACE(5); __syncthreads(); STEP_TRACE(6);
+            slices(wave == 1 ? 0 : 2);                                         // I2
+            STEP_TRACE(7); __syncthreads(); STEP_TRACE(8);
+            slices(wave == 1 ? 1 : 0);                                         // I3
+            STEP_TRACE(9); __syncthreads(); STEP_TRACE(10);
+        }
+        const bool next = (a == 1);               // this workgroup also forms the next diagonal tile's update X X^T (Dn_out)
+        // lower 16 x 16 tiles of X X^T: wave 0 (0,0) (1,0) (1,1), wave 1 (2,0) (2,1) (2,2), wave 2 (3,0) (3,1) (3,2), wave 3 (3,3)
+        // -- wave 3 is idle in I5 and I6 and has everything left to do at the end, so it gets one tile
+        const int gR = (wave == 0) ? 1 : wave + 1, gR0 = (wave == 0) ? 0 : gR;       // rows of tiles 1,2 / of tile 0
+        d4 g0 = (d4){0.0, 0.0, 0.0, 0.0}, g1 = g0, g2 = g0;
+        auto syrk = [&](int c) {
+            if (wave == 0) { syrk_slice(g0, X, 0, 0, c); syrk_slice(g1, X, 1, 0, c); syrk_slice(g2, X, 1, 1, c); }
+            else if (wave == 3) { syrk_slice(g0, X, 3, 3, c); }
+            else { syrk_slice(g0, X, gR, 0, c); syrk_slice(g1, X, gR, 1, c); syrk_slice(g2, X, gR, 2, c); }
+        };
+        // I4: column block 0 everywhere, block 1 where its rows are at hand (D_1 is final since I2)
+        if (wave == 0) { trsm_block<0>(X, S, dprep, rinv, 0); trsm_block<0>(X, S, dprep, rinv, 2); }
+        else if (wave == 1) { trsm_block<0>(X, S, dprep, rinv, 1); trsm_block<1>(X, S, dprep, rinv, 1); }
+        else if (wave == 3) { trsm_block<0>(X, S, dprep, rinv, 3); trsm_block<1>(X, S, dprep, rinv, 3); }
+        STEP_TRACE(13); __syncthreads(); STEP_TRACE(14);
+        // I5
+        if (wave == 0) trsm_block<1>(X, S, dprep, rinv, 0);
+        else if (wave == 1) trsm_block<2>(X, S, dprep, rinv, 1);
+        else if (wave == 2) trsm_block<1>(X, S, dprep, rinv, 2);
+        STEP_TRACE(15); __syncthreads(); STEP_TRACE(16);
+        // I6 (slices 0 and 1 of X are final in all rows)
+        if (wave == 0) trsm_block<2>(X, S, dprep, rinv, 0);
+        else if (wave == 1) trsm_block<2>(X, S, dprep, rinv, 3);
+        else if (wave == 2) trsm_block<2>(X, S, dprep, rinv, 2);
+        if (next && wave != 3) { syrk(0); syrk(1); }
+        STEP_TRACE(17); __syncthreads(); STEP_TRACE(18);
+        // I7 (slice 2 is final)
+        trsm_block<3>(X, S, dprep, rinv, wave);
+        if (next) {
+            if (wave == 3) { syrk(0); syrk(1); }
+            syrk(2);
+        }
+        STEP_TRACE(19); __syncthreads(); STEP_TRACE(20);
+        if (next) {
+            syrk(3);
+            if (wave == 0) { syrk_store(g0, Dn_out, 0, 0); syrk_store(g1, Dn_out, 1, 0); syrk_store(g2, Dn_out, 1, 1); }
+            else if (wave == 3) { syrk_store(g0, Dn_out, 3, 3); }
+            else { syrk_store(g0, Dn_out, gR, 0); syrk_store(g1, Dn_out, gR, 1); syrk_store(g2, Dn_out, gR, 2); }
+        }
+        (void)gR0;
+#endif
         STEP_TRACE(11);
         tile_s2g(X, A, ld, i0, j0);
         STEP_TRACE(12);
@@ -1836,8 +1996,7 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     __syncthreads();
     potf2_tile(S, dprep, rinv, info, j0, n_valid);
     if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);       // no other block reads A_jj in the last step
-    else
-        for (int e = tid; e < TB * TB; e += 256) scratch[e] = S[(e & 63) * LT + (e >> 6)];   // column-major tile
+    else tile_s2g(S, scratch, TB, 0, 0);                // column-major tile
 }
 
 // v[kk] = V[64 kb + kk][j] = W'[Qp-1-64kb-kk][Qp-1-j]: 64 contiguous doubles of column Qp-1-j of W' (descending), read

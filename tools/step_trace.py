@@ -22,13 +22,16 @@ with G.SGPDevice(N, M, D) as dev:
         print('note:', type(e).__name__)
     out = (C.c_int64 * 512)()
     _lib.load().sgp_get_step_trace(out)
-t = np.array(out[:], dtype=np.int64).reshape(16, 2, 16)
+t = np.array(out[:], dtype=np.int64).reshape(8, 2, 32)
 names_f = ["entry", "tiles in LDS", "barrier", "potf2 done"]
-names_x = ["entry", "tiles in LDS", "barrier", "slice0", "b", "slice1", "b", "slice2", "b", "slice3+sub", "b", "trsm done", "stored"]
+# solve group (wave 0 of it): its work of interval I0 .. I7 done / the barrier behind it passed
+names_x = ["entry", "tiles in LDS", "barrier", "I0", "b", "I1", "b", "I2", "b", "I3", "b", "solve done", "stored", "I4", "b", "I5", "b", "I6", "b",
+           "I7", "b"]
 for j in range(8):
     f, x = t[j, 0], t[j, 1]
     if f[0] == 0: continue
     t0 = min(f[0], x[0])
     print(f"step {j}: factoring " + " ".join(f"{n}={(f[i]-t0)/100:.2f}" for i, n in enumerate(names_f)))
-    print(f"        solve     " + " ".join(f"{n}={(x[i]-t0)/100:.2f}" for i, n in enumerate(names_x)))
+    order = list(range(11)) + list(range(13, 21)) + [11, 12]
+    print(f"        solve     " + " ".join(f"{names_x[i]}={(x[i]-t0)/100:.2f}" for i in order if x[i]))
     if j + 1 < 8 and t[j + 1, 0, 0]: print(f"        next step's entry at {(min(t[j+1,0,0], t[j+1,1,0]) - t0)/100:.2f}")
