@@ -1789,10 +1789,12 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     // update L_{j+1,j} L_{j+1,j}^T from the workgroup that solved L_{j+1,j} to the next launch (trsm_tile_next)
     double* Dn_out = scratch + (size_t)(1 + (j & 1)) * TB * TB;
     const double* Dn_in = scratch + (size_t)(2 - (j & 1)) * TB * TB;
-    if (j > 0 && a == 0 && b == 0 && xgroup == diag_inv) {  // move the previous step's L_{j-1,j-1} into place (by the half
-        const int q0 = (j - 1) * TB;                      // that has nothing on the critical path, if there are two)
+    // (the diagonal block moves the previous step's L_{j-1,j-1} from `scratch` into place: see move_prev below)
+    auto move_prev = [&]() {
+        const int q0 = (j - 1) * TB;
         for (int e = tid; e < TB * TB; e += 256) A[(size_t)(q0 + (e >> 6)) * ld + q0 + (e & 63)] = scratch[e];
-    }
+    };
+    if (j > 0 && a == 0 && b == 0 && !diag_inv) move_prev();
     // the tiles this block updates are fetched into registers now, so that their latency hides behind the MFMA phase
     TileRegs rX, rS, rD;
     if (lam && j == 0) stamp_enter(form.stamps);
@@ -1802,8 +1804,15 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         // with the factoring group's barriers exactly like a panel block's solve (column block cb of L_jj is final two
         // intervals before it is needed); W_jj = X^T.  Row r of X is zero left of column r -- exactly: every term is 0 * finite.
         for (int e = tid; e < TB * LT; e += 256) X[e] = (e / LT == e % LT) ? 1.0 : 0.0;
+        STEP_TRACE(1);
+        __syncthreads();                                  // (tile in LDS)
+        STEP_TRACE(2);
+        // Behind the first barrier, not in front of it: the copy's loads miss every cache, and the factoring group would wait
+        // 1 - 2 us at that barrier for a tile nobody reads during this launch (the step trace showed exactly that).  `scratch`
+        // is overwritten only after the factorisation, eight barriers from here.
+        if (j > 0) move_prev();
 #pragma unroll
-        for (int sl = 0; sl < 5; ++sl) __syncthreads();   // (tile in LDS, then the four intervals a panel block's update takes)
+        for (int sl = 1; sl < 5; ++sl) { __syncthreads(); STEP_TRACE(2 + 2 * sl); }   // (the four intervals a panel block's update takes)
 #ifdef SGP_LOCKSTEP_SOLVE
         trsm_tile<true>(X, S, dprep, rinv);
 #else
@@ -1821,9 +1830,12 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         else if (wave == 2) trsm_block<2>(X, S, dprep, rinv, 2);
         __syncthreads();
         trsm_block<3>(X, S, dprep, rinv, wave);
+        STEP_TRACE(19);
         __syncthreads();
+        STEP_TRACE(20);
 #endif
         tile_s2g_t(X, Winv, ld, j0, j0);
+        STEP_TRACE(12);
         return;
     }
     if (panel && a != 0) {
@@ -1992,11 +2004,16 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
 #pragma unroll
         for (int u = 0; u < 16; ++u) rS.v[u] -= rD.v[u];
     }
+    if (diag_inv) __builtin_amdgcn_s_setprio(3);        // (as in the panel blocks: the latency-bound group first)
     tile_r2s(S, rS);
+    STEP_TRACE(1);
     __syncthreads();
+    STEP_TRACE(2);
     potf2_tile(S, dprep, rinv, info, j0, n_valid);
+    STEP_TRACE(3);
     if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);       // no other block reads A_jj in the last step
     else tile_s2g(S, scratch, TB, 0, 0);                // column-major tile
+    STEP_TRACE(4);
 }
 
 // v[kk] = V[64 kb + kk][j] = W'[Qp-1-64kb-kk][Qp-1-j]: 64 contiguous doubles of column Qp-1-j of W' (descending), read
