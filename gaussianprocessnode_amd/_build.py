@@ -16,9 +16,7 @@ LIB = os.path.join(CSRC, "libsgp_hip.so")
 # (csrc/sgp_chain.hip.h; correct, measured slower, kept out of the default library)
 VARIANTS = {"chain": ("libsgp_hip_chain.so", ["-DSGP_WITH_PERSISTENT_CHAIN"]),
             # diagnostics: in-kernel begin / end stamps of every kernel of a sweep (tools/sweep_trace.py)
-            "trace": ("libsgp_hip_trace.so", ["-DSGP_SWEEP_TRACE", "-DSGP_STEP_TRACE"]),
-            "trace2": ("libsgp_hip_trace2.so", ["-DSGP_SWEEP_TRACE", "-DSGP_STEP_TRACE", "-DSGP_STEP_TRACE_A=0"]),
-            "lockstep": ("libsgp_hip_lockstep.so", ["-DSGP_LOCKSTEP_SOLVE"])}
+            "trace": ("libsgp_hip_trace.so", ["-DSGP_SWEEP_TRACE", "-DSGP_STEP_TRACE"])}
 SOURCES = [os.path.join(CSRC, "sgp_api.hip")]
 HEADERS = [os.path.join(CSRC, "sgp_kernels.hip.h"), os.path.join(CSRC, "sgp_chain.hip.h"), os.path.join(os.path.dirname(HERE), "include", "sgp_hip.h")]
 

@@ -300,7 +300,7 @@ static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, doub
     };
     for (int j = 0; j < Tn; ++j) {
         const int nt = Tn - j;
-        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + extras(j)), dim3(PSTEP_THREADS), 0, s, A, ld, j, Tn, info, n_valid,
+        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + potrf_twins(Tn, j) + extras(j)), dim3(PSTEP_THREADS), 0, s, A, ld, j, Tn, info, n_valid,
                            scratch, Winv, Sacc, tv_xi, tv_t, form ? *form : none);      // (every step: a tile column may be formed later than step 0)
     }
     if (Winv && extras(Tn) > 0)
@@ -443,8 +443,8 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     ALLOC(h->dR, Qp * Qp);
     ALLOC(h->dTmp, Qp * Qp);
     ALLOC(h->dUvT, Qp * Qp);
-    ALLOC(h->dScratch, 9 * TB * TB);   // per factorisation chain: L_jj parking tile + two tiles of trsm_tile_next
-    hipMemset(h->dScratch, 0, sizeof(double) * 9 * TB * TB);   // (the unwritten upper tiles of those are read, never used)
+    ALLOC(h->dScratch, 3 * POTRF_SCRATCH);   // per factorisation chain: L_jj parking tile, two tiles of the next diagonal update, the twins' words
+    hipMemset(h->dScratch, 0, sizeof(double) * 3 * POTRF_SCRATCH);   // (the unwritten upper tiles of those are read, never used)
     ALLOC(h->dOut2, SGP_R_COUNT);
     ALLOC(h->dUvWork, (2 + 2 * (size_t)h->TQ) * Qp);
     ALLOC(h->dLambda0, Qp * Qp);
@@ -899,7 +899,7 @@ extern "C" int sgp_set_prior(sgp_handle* h, const double* vec, const double* mat
     if (rc) return rc;
     hipStream_t s = h->own;
     HIPCHK(h, hipMemsetAsync(h->dInfo + 2, 0, sizeof(int), s));
-    launch_potrf(h->dTmp, h->Qp, h->TQ, h->dInfo + 2, h->Q, h->dScratch + 6 * TB * TB, s, h->dWl);
+    launch_potrf(h->dTmp, h->Qp, h->TQ, h->dInfo + 2, h->Q, h->dScratch + 2 * POTRF_SCRATCH, s, h->dWl);
     launch_ata(h->dWl, h->dLambda0, h->Qp, h->TQ, s);
     // (the mean is staged in dXi and the factor in dTmp / dWl -- buffers every sweep rewrites before it reads them -- not in dMu:
     // sgp_get_posterior, sgp_predict(mu_v = NULL) and the theta gradient read the last sweep's mean from there)
@@ -1104,7 +1104,7 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
         launch_chain(h, 1, h->dLam, h->dLamAlt, Qp, TQ, h->dInfo + 1, Qp, s, h->dWl, &form, h->dTmp, h->dXi, uvt0, nullptr, nullptr, 0, 0);
     } else
 #endif
-        launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + 3 * TB * TB, s, h->dWl, &form, h->dTmp, h->dXi, uvt0);
+        launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + POTRF_SCRATCH, s, h->dWl, &form, h->dTmp, h->dXi, uvt0);
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
     // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
     double* uvp = h->dXi;                    // xi is consumed by the forward solve; p lands in the same vector afterwards
@@ -2186,8 +2186,8 @@ static int dense_common(int32_t device, const double* A, int32_t n, double* out,
     const bool chain = false;
 #endif
     {
-        HIPCHK(h, bScr.alloc(sizeof(double) * 3 * TB * TB));
-        HIPCHK(h, hipMemset(bScr.p, 0, sizeof(double) * 3 * TB * TB));
+        HIPCHK(h, bScr.alloc(sizeof(double) * POTRF_SCRATCH));
+        HIPCHK(h, hipMemset(bScr.p, 0, sizeof(double) * POTRF_SCRATCH));
         launch_potrf(bA.as<double>(), np, Tn, bInfo.as<int>(), n, bScr.as<double>(), 0, bW.as<double>());
     }
     const double* result = factor;

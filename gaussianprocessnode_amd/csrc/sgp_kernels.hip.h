@@ -1707,7 +1707,7 @@ __device__ long long g_step_trace[8 * 64];
 #define SGP_STEP_TRACE_A 1
 #endif
 #ifdef SGP_STEP_TRACE
-#define STEP_TRACE(e) do { if (tv_t && a == SGP_STEP_TRACE_A && b == 0 && lane == 0 && wave == 0 && j < 8) g_step_trace[j * 64 + (xgroup ? 32 : 0) + (e)] = realtime_ticks(); } while (0)
+#define STEP_TRACE(e) do { if (tv_t && a == SGP_STEP_TRACE_A && b == 0 && tw == 0 && lane == 0 && wave == 0 && j < 8) g_step_trace[j * 64 + (xgroup ? 32 : 0) + (e)] = realtime_ticks(); } while (0)
 #else
 #define STEP_TRACE(e) do { } while (0)
 #endif
@@ -1717,6 +1717,20 @@ __device__ long long g_step_trace[8 * 64];
 // triangular solve column block by column block, in step with the factoring group's eight barriers -- while waves 0 .. 3
 // factor the diagonal tile); everywhere else waves 4 .. 7 leave at once (ended waves do not count at a barrier).
 constexpr int PSTEP_THREADS = 512;
+// TWINS: the block that owns tile (j + 1, j) also forms the next diagonal tile's update X X^T from its solved tile (160 MFMAs
+// that can only start once column blocks of X are final, i.e. in the last three barrier intervals) and was the last to leave
+// in every step (in-kernel exit stamps: +1.6 us after the other panel blocks, and the next step waits for the launch).
+// POTRF_TWINS further workgroups solve the same tile redundantly and share the ten lower 16 x 16 tiles of X X^T with it.
+#ifndef POTRF_TWINS
+#define POTRF_TWINS 1
+#endif
+__host__ __device__ constexpr int potrf_twins(int Tn, int j) { return (Tn - j >= 2) ? POTRF_TWINS : 0; }
+// A twin reads tile (j + 1, j) of the matrix at its start; the owner overwrites that tile with L at its end -- and nothing orders
+// the start of one workgroup against the end of another (a twin may wait for a free CU).  So a twin counts itself into a word
+// once its tile is in LDS, and the owner stores only when all twins have (it polls early: the answer is normally there long
+// before it is needed; bounded, and a give-up is reported through `info` like any other, as -1).  Two words behind the three
+// scratch tiles, by the step's parity; the diagonal block of step j clears the word of step j + 1.
+constexpr int POTRF_SCRATCH = 3 * TB * TB + 64;     // doubles of scratch per factorisation chain
 __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
                                                     int n_valid, double* __restrict__ scratch, double* __restrict__ Winv,
                                                     double* __restrict__ Sacc, const double* __restrict__ tv_xi,
@@ -1731,9 +1745,9 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     const bool xgroup = threadIdx.x >= 256;               // the solve group
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     {
-        const int npot = (Tn - j) * (Tn - j + 1) / 2;     // this step's own tiles; the workgroups beyond them work on
-        if ((int)blockIdx.x >= npot) {                    // the inverse factor (winv_row_tile): finish block row j - 1,
-            if (xgroup) return;
+        const int npot = (Tn - j) * (Tn - j + 1) / 2 + potrf_twins(Tn, j);   // this step's own tiles (and the twins of the
+        if ((int)blockIdx.x >= npot) {                    // block below the diagonal); the workgroups beyond them work on
+            if (xgroup) return;                           // the inverse factor (winv_row_tile): finish block row j - 1,
             int e = blockIdx.x - npot;                    // then pre-accumulate block row j; Sigma = W^T W collects the
             const int nfin = (j >= 2) ? 2 * (j - 1) : 0;  // contribution of block row j - 2 (sigma_row_tile); and one
             const int npre = (j < Tn) ? nfin : 0;         // workgroup advances the forward solve t = W (P xi) (tvec_role)
@@ -1750,8 +1764,12 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             return;
         }
     }
-    int a, b;
-    tile_from_index(blockIdx.x, a, b);                    // a >= b, tile (j + a, j + b) of the matrix
+    int a, b, tw = 0;                                     // tw > 0: a twin of the block (1, 0), see POTRF_TWINS
+    {
+        const int nown = (Tn - j) * (Tn - j + 1) / 2;
+        if ((int)blockIdx.x >= nown) { a = 1; b = 0; tw = blockIdx.x - nown + 1; }
+        else tile_from_index(blockIdx.x, a, b);           // a >= b, tile (j + a, j + b) of the matrix
+    }
     const int i0 = (j + a) * TB, k0 = (j + b) * TB, j0 = j * TB;
     double* P0 = lds;
     double* P1 = lds + TB * PS;
@@ -1813,9 +1831,6 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         if (j > 0) move_prev();
 #pragma unroll
         for (int sl = 1; sl < 5; ++sl) { __syncthreads(); STEP_TRACE(2 + 2 * sl); }   // (the four intervals a panel block's update takes)
-#ifdef SGP_LOCKSTEP_SOLVE
-        trsm_tile<true>(X, S, dprep, rinv);
-#else
         // (the panel blocks' schedule of the solve, see there)
         if (wave == 0) { trsm_block<0>(X, S, dprep, rinv, 0); trsm_block<0>(X, S, dprep, rinv, 2); }
         else if (wave == 1) { trsm_block<0>(X, S, dprep, rinv, 1); trsm_block<1>(X, S, dprep, rinv, 1); }
@@ -1833,7 +1848,6 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         STEP_TRACE(19);
         __syncthreads();
         STEP_TRACE(20);
-#endif
         tile_s2g_t(X, Winv, ld, j0, j0);
         STEP_TRACE(12);
         return;
@@ -1869,6 +1883,9 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             load_panel_n(P1, A, ld, k0, p0, TB, tid);         // L_{j, j-1}
         }
         tile_r2s(X, rX);
+        long long* tw_word = reinterpret_cast<long long*>(scratch + 3 * TB * TB) + (j & 1);
+        if (tw > 0 && tid == 0)                           // (rX has arrived: it was just stored to LDS)
+            __hip_atomic_fetch_add((__attribute__((address_space(1))) long long*)tw_word, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         STEP_TRACE(1);
         __syncthreads();
         STEP_TRACE(2);
@@ -1886,24 +1903,6 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
                 ap += 4 * PS; bp += 4 * PS;
             }
         };
-#ifdef SGP_LOCKSTEP_SOLVE                 // (A/B: the round-2 form -- every solve wave works in every interval)
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {
-            if (j > 0) {
-                own_slice(sl);
-                if (sl == 3) tile_sub_acc(X, accX, lane, wr, wc);
-            }
-            STEP_TRACE(3 + 2 * sl);
-            __syncthreads();
-            STEP_TRACE(4 + 2 * sl);
-        }
-        if (a == 1) {
-            if (wave == 0 || wave == 3) trsm_tile_next<true>(X, S, dprep, rinv, Dn_out);
-            else trsm_tile_next<false>(X, S, dprep, rinv, Dn_out);
-        } else {
-            trsm_tile<true>(X, S, dprep, rinv);
-        }
-#else
         // SIMD-AWARE SCHEDULE.  Wave w of the factoring group and wave w of this group share a SIMD (tools/simd_map_probe.hip:
         // always, whatever the SIMD's number), and FP64 MFMAs and FP64 vector instructions share its pipe: a 64-cycle MFMA of
         // this group in front of a dependent FMA of the pivot chain delays the chain by all of it.  Measured (step trace, this
@@ -1932,14 +1931,22 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             STEP_TRACE(9); __syncthreads(); STEP_TRACE(10);
         }
         const bool next = (a == 1);               // this workgroup also forms the next diagonal tile's update X X^T (Dn_out)
-        // lower 16 x 16 tiles of X X^T: wave 0 (0,0) (1,0) (1,1), wave 1 (2,0) (2,1) (2,2), wave 2 (3,0) (3,1) (3,2), wave 3 (3,3)
-        // -- wave 3 is idle in I5 and I6 and has everything left to do at the end, so it gets one tile
-        const int gR = (wave == 0) ? 1 : wave + 1, gR0 = (wave == 0) ? 0 : gR;       // rows of tiles 1,2 / of tile 0
-        d4 g0 = (d4){0.0, 0.0, 0.0, 0.0}, g1 = g0, g2 = g0;
+        // ... its share of the ten lower 16 x 16 tiles: tile t belongs to workgroup t mod (1 + twins), and a workgroup's tiles go
+        // round the waves 0, 1, 2 (wave 3 is idle in I5 and I6 and would have everything left to do at the end)
+        const int ntw = 1 + potrf_twins(Tn, j);
+        int gcount = 0, gR[4], gC[4];
+        d4 g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            g[q] = (d4){0.0, 0.0, 0.0, 0.0};
+            gR[q] = gC[q] = 0;
+            const int t = tw + ntw * (wave + 3 * q);     // my q-th tile
+            if (next && wave < 3 && t < 10) { tile_from_index(t, gR[q], gC[q]); gcount = q + 1; }
+        }
         auto syrk = [&](int c) {
-            if (wave == 0) { syrk_slice(g0, X, 0, 0, c); syrk_slice(g1, X, 1, 0, c); syrk_slice(g2, X, 1, 1, c); }
-            else if (wave == 3) { syrk_slice(g0, X, 3, 3, c); }
-            else { syrk_slice(g0, X, gR, 0, c); syrk_slice(g1, X, gR, 1, c); syrk_slice(g2, X, gR, 2, c); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < gcount) syrk_slice(g[q], X, gR[q], gC[q], c);
         };
         // I4: column block 0 everywhere, block 1 where its rows are at hand (D_1 is final since I2)
         if (wave == 0) { trsm_block<0>(X, S, dprep, rinv, 0); trsm_block<0>(X, S, dprep, rinv, 2); }
@@ -1955,25 +1962,28 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         if (wave == 0) trsm_block<2>(X, S, dprep, rinv, 0);
         else if (wave == 1) trsm_block<2>(X, S, dprep, rinv, 3);
         else if (wave == 2) trsm_block<2>(X, S, dprep, rinv, 2);
-        if (next && wave != 3) { syrk(0); syrk(1); }
+        syrk(0); syrk(1);
+        const int tw_need = (next && tw == 0) ? potrf_twins(Tn, j) : 0;
+        bool tw_ready = true;
+        if (tw_need > 0 && lane == 0) tw_ready = join_ready(tw_word, tw_need);       // (early poll: see POTRF_SCRATCH)
         STEP_TRACE(17); __syncthreads(); STEP_TRACE(18);
         // I7 (slice 2 is final)
         trsm_block<3>(X, S, dprep, rinv, wave);
-        if (next) {
-            if (wave == 3) { syrk(0); syrk(1); }
-            syrk(2);
-        }
+        syrk(2);
         STEP_TRACE(19); __syncthreads(); STEP_TRACE(20);
-        if (next) {
-            syrk(3);
-            if (wave == 0) { syrk_store(g0, Dn_out, 0, 0); syrk_store(g1, Dn_out, 1, 0); syrk_store(g2, Dn_out, 1, 1); }
-            else if (wave == 3) { syrk_store(g0, Dn_out, 3, 3); }
-            else { syrk_store(g0, Dn_out, gR, 0); syrk_store(g1, Dn_out, gR, 1); syrk_store(g2, Dn_out, gR, 2); }
-        }
-        (void)gR0;
-#endif
+        syrk(3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < gcount) syrk_store(g[q], Dn_out, gR[q], gC[q]);
         STEP_TRACE(11);
-        tile_s2g(X, A, ld, i0, j0);
+        if (tw_need > 0 && lane == 0 && !tw_ready) {
+            int it = 0;
+            while (!join_ready(tw_word, tw_need)) {
+                if (++it >= (1 << 21)) { atomicMin(info, -1); break; }       // (the twins never read their tile: the factor is not to be trusted)
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        if (tw == 0) tile_s2g(X, A, ld, i0, j0);
         STEP_TRACE(12);
         return;
     }
@@ -2005,6 +2015,7 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         for (int u = 0; u < 16; ++u) rS.v[u] -= rD.v[u];
     }
     if (diag_inv) __builtin_amdgcn_s_setprio(3);        // (as in the panel blocks: the latency-bound group first)
+    if (tid == 0 && !xgroup) reinterpret_cast<long long*>(scratch + 3 * TB * TB)[(j + 1) & 1] = 0;   // the twins' word of the next step
     tile_r2s(S, rS);
     STEP_TRACE(1);
     __syncthreads();
