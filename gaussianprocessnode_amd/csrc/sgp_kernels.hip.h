@@ -1722,7 +1722,7 @@ constexpr int PSTEP_THREADS = 512;
 // in every step (in-kernel exit stamps: +1.6 us after the other panel blocks, and the next step waits for the launch).
 // POTRF_TWINS further workgroups solve the same tile redundantly and share the ten lower 16 x 16 tiles of X X^T with it.
 #ifndef POTRF_TWINS
-#define POTRF_TWINS 1
+#define POTRF_TWINS 2
 #endif
 __host__ __device__ constexpr int potrf_twins(int Tn, int j) { return (Tn - j >= 2) ? POTRF_TWINS : 0; }
 // A twin reads tile (j + 1, j) of the matrix at its start; the owner overwrites that tile with L at its end -- and nothing orders
