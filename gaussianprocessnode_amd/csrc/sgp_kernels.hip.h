@@ -1871,6 +1871,21 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             STEP_TRACE(2);
             potf2_tile(S, dprep, rinv, info, j0, n_valid);
             STEP_TRACE(3);
+            if (a == 1 && tw == 0) {
+                // The block below the diagonal: behind the last barrier its solve group still has the last K-slice of the next
+                // diagonal tile's update and that tile's stores to do -- so THIS group, done, stores the solved tile meanwhile.
+                // (Only once every twin has read the tile it overwrites, see POTRF_SCRATCH.)
+                const int need = potrf_twins(Tn, j);
+                if (need > 0 && lane == 0) {
+                    const long long* w = reinterpret_cast<const long long*>(scratch + 3 * TB * TB) + (j & 1);
+                    int it = 0;
+                    while (!join_ready(w, need)) {
+                        if (++it >= (1 << 21)) { atomicMin(info, -1); break; }   // (the twins never read it: the factor is not to be trusted)
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                }
+                tile_s2g(X, A, ld, i0, j0);
+            }
             return;
         }
         // solve group: the own tile (j + a, j).  Its rank-64 update L_{i,j-1} L_{j,j-1}^T takes the first four of the
@@ -1963,9 +1978,6 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         else if (wave == 1) trsm_block<2>(X, S, dprep, rinv, 3);
         else if (wave == 2) trsm_block<2>(X, S, dprep, rinv, 2);
         syrk(0); syrk(1);
-        const int tw_need = (next && tw == 0) ? potrf_twins(Tn, j) : 0;
-        bool tw_ready = true;
-        if (tw_need > 0 && lane == 0) tw_ready = join_ready(tw_word, tw_need);       // (early poll: see POTRF_SCRATCH)
         STEP_TRACE(17); __syncthreads(); STEP_TRACE(18);
         // I7 (slice 2 is final)
         trsm_block<3>(X, S, dprep, rinv, wave);
@@ -1976,14 +1988,7 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         for (int q = 0; q < 4; ++q)
             if (q < gcount) syrk_store(g[q], Dn_out, gR[q], gC[q]);
         STEP_TRACE(11);
-        if (tw_need > 0 && lane == 0 && !tw_ready) {
-            int it = 0;
-            while (!join_ready(tw_word, tw_need)) {
-                if (++it >= (1 << 21)) { atomicMin(info, -1); break; }       // (the twins never read their tile: the factor is not to be trusted)
-                __builtin_amdgcn_s_sleep(16);
-            }
-        }
-        if (tw == 0) tile_s2g(X, A, ld, i0, j0);
+        if (!next) tile_s2g(X, A, ld, i0, j0);           // (the block below the diagonal: its factoring group stores, the twins nobody)
         STEP_TRACE(12);
         return;
     }
