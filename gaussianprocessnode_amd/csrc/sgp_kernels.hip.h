@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(256) k_form_lambda(const double* __restrict__ 
 //   (A_ik -= L_i,j-1 L_k,j-1^T on the matrix cores).  Blocks of the first trailing column (b = 0) then
 //   continue with step j without leaving the kernel: each of them ALSO factors the diagonal tile A_jj itself in
 //   LDS (redundant compute instead of an inter-block hand-off; its rank-64 update arrives as a tile formed by
-//   the previous launch, see trsm_tile_next) and solves X L_jj^T = A_ij for its own tile; the block on the
+//   the previous launch, see syrk_slice) and solves X L_jj^T = A_ij for its own tile; the block on the
 //   diagonal writes L_jj.
 // Thread layout of the sequential parts: the triangular solves give 4 adjacent lanes (q = tid & 3) one row
 // r = tid >> 2, lane q keeping the row's entries c = q (mod 4) in registers (no reductions; the quad exchanges
@@ -1065,47 +1065,11 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
     potf2_tile(S, Dp, rinv, info, col_base, n_valid, [](int) {}, [](auto, auto) {}, [](auto) {});
 }
 
-// Solve X L^T = B in place: X (LDS tile, stride LT) holds B on entry and X on exit; S holds L (normal layout, as written
-// by potf2_tile, with Dp and rinv), rinv = 1 / diag(L).  Blocked by 16 columns and entirely WAVE-LOCAL (wave w owns rows
-// 16 w .. 16 w + 15, no workgroup barrier): for each 16-column block the contribution of the blocks to its left is one
-// MFMA product per wave (K = 16 cb), the 16 x 16 triangle is then solved with 4 lanes per row in registers.
-template <bool SYNC = false>
-__device__ __forceinline__ void trsm_tile(double* X, const double* S, const double* Dp, const double* rinv) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;   // (the solve group of an 8-wave workgroup: waves 4 .. 7)
-    const int r0 = 16 * wave;
-    const int li = lane & 15, lk = lane >> 4;            // MFMA operand coordinates
-    const int rr = lane >> 2, q = lane & 3;              // solve coordinates: row r0 + rr, quarter q
-    static_for<4>([&](auto cbc) {
-        constexpr int cb = decltype(cbc)::value;
-        if constexpr (cb > 0) {
-            // four independent accumulators: a dependent v_mfma_f64 chain costs ~200 cycles per link, independent ones ~140
-            d4 acc[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
-            const double* ap = X + (r0 + li) * LT + lk;              // A[i][k] = X[r0 + i][k]
-            const double* bp = S + (16 * cb + li) * LT + lk;         // B[k][j] = L[16 cb + j][k]
-            double av[4 * cb], bv[4 * cb];                           // all operands first: one LDS latency, not one per pair
-#pragma unroll
-            for (int s4 = 0; s4 < 4 * cb; ++s4) { av[s4] = ap[4 * s4]; bv[s4] = bp[4 * s4]; }
-#pragma unroll
-            for (int s4 = 0; s4 < 4 * cb; ++s4)
-                acc[s4 & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc[s4 & 3], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-        }
-        double x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q];
-        solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [](auto) {});
-#pragma unroll
-        for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
-        if constexpr (SYNC) __syncthreads();              // (in step with the factoring group's barriers, see k_potrf_step)
-    });
-}
-
-// One block of trsm_tile on its own: column block cb of the 16 rows of row block rb (any wave may take any row block: X lives
-// in LDS).  The unit of the scheduled solve group (k_potrf_step).
+// One 16 x 16 block of the solve X L^T = B, in place (X: LDS tile, stride LT; S holds L as potf2_tile left it, with Dp and
+// rinv = 1 / diag(L)): column block cb of the 16 rows of row block rb -- first the contribution of the column blocks to its
+// left (one MFMA product, K = 16 cb, four independent accumulators: a dependent v_mfma_f64 chain costs ~200 cycles per link),
+// then the 16 x 16 triangle with 4 lanes per row in registers (solve16).  Wave-local; any wave may take any row block.  The
+// unit of the scheduled solve group (k_potrf_step).
 template <int cb>
 __device__ __forceinline__ void trsm_block(double* X, const double* S, const double* Dp, const double* rinv, int rb) {
     const int lane = threadIdx.x & 63;
@@ -1136,7 +1100,8 @@ __device__ __forceinline__ void trsm_block(double* X, const double* S, const dou
     for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
 }
 // K-slice c (columns 16 c .. 16 c + 15 of the solved tile X) of the lower 16 x 16 tile (R, C) of X X^T, formed transposed
-// (A operand = the column tile) so that the stores run along Dn's columns (see trsm_tile_next)
+// (A operand = the column tile) so that the stores run along Dn's columns (Dn: 64 x 64, column-major, ld 64; the next step
+// subtracts it from its diagonal tile instead of recomputing the product in front of its factorisation)
 __device__ __forceinline__ void syrk_slice(d4& g, const double* X, int R, int C, int c) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const double* pa = X + (16 * C + li) * LT + 16 * c + lk;
@@ -1151,87 +1116,6 @@ __device__ __forceinline__ void syrk_store(const d4& g, double* __restrict__ Dn,
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Dn[(16 * C + lk + 4 * r) * TB + 16 * R + li] = g[r];
-}
-
-// trsm_tile for the workgroup that owns tile (j + 1, j): while it solves X = L_{j+1,j}, the matrix cores (idle during the
-// pivot runs, which are bound by instruction issue) also form the NEXT diagonal tile's update  X X^T  -- one MFMA per pivot,
-// on the 16-column slice of X finished by the previous column block -- and the lower 16 x 16 tiles of it go to Dn (64 x 64,
-// column-major, ld 64).  Step j + 1 then subtracts Dn from A_{j+1,j+1} instead of recomputing the product in front of its
-// factorisation (64 MFMAs per wave on the critical path of every step).  Ten tiles over four waves: waves 0 and 3
-// (DIAGW) take (b,b), (b+1,b), (b+1,b+1) for b = 0, 2; waves 1 and 2 take (3,0),(3,1) and (2,0),(2,1).  The products are
-// formed transposed (A operand = the column tile) so that the stores run along Dn's columns.  One workgroup barrier per
-// column block (the slice must be complete in all 64 rows); every wave passes the same four barriers.
-template <bool DIAGW>
-__device__ __forceinline__ void trsm_tile_next(double* X, const double* S, const double* Dp, const double* rinv,
-                                               double* __restrict__ Dn) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
-    const int r0 = 16 * wave;
-    const int li = lane & 15, lk = lane >> 4;
-    const int rr = lane >> 2, q = lane & 3;
-    const int tb = (wave == 0) ? 0 : 2;                  // DIAGW: first tile of the diagonal pair
-    const int tR = (wave == 1) ? 3 : 2;                  // !DIAGW: the row tile
-    const double* p0 = X + ((DIAGW ? 16 * tb : 16 * tR) + li) * LT + lk;
-    const double* p1 = X + ((DIAGW ? 16 * (tb + 1) : 0) + li) * LT + lk;
-    const double* p2 = X + (16 + li) * LT + lk;
-    d4 g0 = (d4){0.0, 0.0, 0.0, 0.0}, g1 = g0, g2 = g0;
-    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-    auto syrk_step = [&](auto sc, auto mc) {
-        constexpr int sl = decltype(sc)::value, m = decltype(mc)::value;
-        constexpr int per = DIAGW ? 3 : 2;
-        if constexpr (m < 4 * per) {
-            constexpr int off = 16 * sl + 4 * (m / per), t = m % per;
-            if constexpr (t == 0) {
-                x0 = p0[off];
-                x1 = p1[off];
-                if constexpr (!DIAGW) x2 = p2[off];
-            }
-            if constexpr (DIAGW) {
-                if constexpr (t == 0) g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, g0, 0, 0, 0);
-                else if constexpr (t == 1) g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, g1, 0, 0, 0);
-                else g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, g2, 0, 0, 0);
-            } else {
-                if constexpr (t == 0) g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, g0, 0, 0, 0);
-                else g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, x0, g1, 0, 0, 0);
-            }
-        }
-    };
-    static_for<4>([&](auto cbc) {
-        constexpr int cb = decltype(cbc)::value;
-        if constexpr (cb > 0) {
-            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-            const double* ap = X + (r0 + li) * LT + lk;
-            const double* bp = S + (16 * cb + li) * LT + lk;
-#pragma unroll
-            for (int s4 = 0; s4 < 4 * cb; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s4], bp[4 * s4], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= acc[r];
-        }
-        double x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q];
-        solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [&](auto kc) {
-            if constexpr (cb > 0) syrk_step(std::integral_constant<int, cb - 1>{}, kc);
-        });
-#pragma unroll
-        for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
-        __syncthreads();
-    });
-    static_for<12>([&](auto mc) { syrk_step(std::integral_constant<int, 3>{}, mc); });
-    // value (row 16 R + li, column 16 C + lk + 4 r) of tile (R, C)
-    if constexpr (DIAGW) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Dn[(16 * tb + lk + 4 * r) * TB + 16 * tb + li] = g0[r];
-            Dn[(16 * tb + lk + 4 * r) * TB + 16 * (tb + 1) + li] = g1[r];
-            Dn[(16 * (tb + 1) + lk + 4 * r) * TB + 16 * (tb + 1) + li] = g2[r];
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Dn[(lk + 4 * r) * TB + 16 * tR + li] = g0[r];
-            Dn[(16 + lk + 4 * r) * TB + 16 * tR + li] = g1[r];
-        }
-    }
 }
 
 // Invert the 64 x 64 lower-triangular tile S (LDS, S[r][c], stride LT; rinv[c] = 1 / L_cc) into Wt (LDS, same layout,
@@ -1804,7 +1688,7 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     }
     // scratch: tile 0 parks L_jj; tiles 1 and 2 (alternating with the step's parity: a late workgroup of step j + 1 may
     // still read one while step j + 1's owner of tile (j + 2, j + 1) writes the other) carry the next diagonal tile's
-    // update L_{j+1,j} L_{j+1,j}^T from the workgroup that solved L_{j+1,j} to the next launch (trsm_tile_next)
+    // update L_{j+1,j} L_{j+1,j}^T from the workgroup that solved L_{j+1,j} to the next launch (syrk_slice / syrk_store)
     double* Dn_out = scratch + (size_t)(1 + (j & 1)) * TB * TB;
     const double* Dn_in = scratch + (size_t)(2 - (j & 1)) * TB * TB;
     // (the diagonal block moves the previous step's L_{j-1,j-1} from `scratch` into place: see move_prev below)
