@@ -921,41 +921,45 @@ __device__ __forceinline__ void solve16(double (&x)[4], const double* Dp, const 
 //       broadcast and ds_bpermute -- all inside ONE wave, so the 16 pivots need no workgroup barrier;
 //   (3) after a barrier the waves below solve their 16 x 16 block against it (rows independent, in registers) and at once
 //       subtract its square from their own diagonal block (w, w).
-// Two workgroup barriers per 16 pivots instead of one per pivot.  `idle_work(cb)` is called by the three waves that wait
-// while wave cb runs its 16 pivots (k_potrf_step gives them a slice of the block's own rank-64 update).
-// `solve_hook(cb, k)` is called once per pivot by the waves that solve below block cb, `solve_idle(cb)` by wave cb, which
-// waits there.
+// Two workgroup barriers per 16 pivots instead of one per pivot.
+// The four column blocks are a RUNTIME loop (one copy of the 16 unrolled pivots, not four): the step kernel's code was 210 KB
+// with everything unrolled, several times the instruction cache, and the pivot chain -- one instruction every few cycles, no
+// reuse -- then runs at the rate instructions arrive from the L2, which a streaming SYRK on the other CUs keeps busy.
 #ifdef SGP_POTF2_LEFT_LOOKING          // A/B switch: the diagonal blocks updated left-looking, in front of their pivot runs
 constexpr int POTF2_LEFT = 1;
 #else
 constexpr int POTF2_LEFT = 0;
 #endif
-template <class IdleWork, class SolveHook, class SolveIdle>
-__device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, int* info, int col_base, int n_valid,
-                                           IdleWork&& idle_work, SolveHook&& solve_hook, SolveIdle&& solve_idle) {
+// acc += A[16 x 16 K] B^T for K = 16 chunks: rows of A at ap, of B at bp (both LDS, [row][k], stride LT, already offset by the
+// lane's row and k), operands of all chunks first, four independent accumulators
+template <int CHUNKS>
+__device__ __forceinline__ void mma_left(d4 (&acc)[4], const double* ap, const double* bp) {
+    double av[4 * CHUNKS], bv[4 * CHUNKS];
+#pragma unroll
+    for (int s4 = 0; s4 < 4 * CHUNKS; ++s4) { av[s4] = ap[4 * s4]; bv[s4] = bp[4 * s4]; }
+#pragma unroll
+    for (int s4 = 0; s4 < 4 * CHUNKS; ++s4) acc[s4 & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc[s4 & 3], 0, 0, 0);
+}
+__device__ __forceinline__ void mma_left_n(d4 (&acc)[4], const double* ap, const double* bp, int chunks) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (chunks == 1) mma_left<1>(acc, ap, bp);
+    else if (chunks == 2) mma_left<2>(acc, ap, bp);
+    else if (chunks == 3) mma_left<3>(acc, ap, bp);
+}
+__device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, int* info, int col_base, int n_valid) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = 16 * wave;
     const int li = lane & 15, lk = lane >> 4;
     const int rr = lane >> 2, q = lane & 3;
-    static_for<4>([&](auto cbc) {
-        constexpr int cb = decltype(cbc)::value;
-        if constexpr (cb > 0) {
-            if (wave > cb - POTF2_LEFT) {                                // (the pivot wave's own block is already up to date, see (3))
-                d4 acc[4];
+#pragma unroll 1
+    for (int cb = 0; cb < 4; ++cb) {
+        if (cb > 0 && wave > cb - POTF2_LEFT) {                          // (the pivot wave's own block is already up to date, see (3))
+            d4 acc[4];
+            mma_left_n(acc, S + (r0 + li) * LT + lk /* A[i][k] = L[r0 + i][k] */, S + (16 * cb + li) * LT + lk /* B[k][j] = L[16 cb + j][k] */, cb);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
-                const double* ap = S + (r0 + li) * LT + lk;              // A[i][k] = L[r0 + i][k]
-                const double* bp = S + (16 * cb + li) * LT + lk;         // B[k][j] = L[16 cb + j][k]
-                double av[4 * cb], bv[4 * cb];
-#pragma unroll
-                for (int s4 = 0; s4 < 4 * cb; ++s4) { av[s4] = ap[4 * s4]; bv[s4] = bp[4 * s4]; }
-#pragma unroll
-                for (int s4 = 0; s4 < 4 * cb; ++s4)
-                    acc[s4 & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc[s4 & 3], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    S[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-            }
+            for (int r = 0; r < 4; ++r)
+                S[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
         }
         if (wave == cb) {
             // Pivot-phase coordinates: lane = 16 pq + pr holds row pr, columns 4 i + pq -- of the FULL symmetric block, so
@@ -1022,15 +1026,13 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
                 S[(r0 + pr) * LT + 16 * cb + c] = l;
                 Dp[cb * DPB + pr * DPS + c] = (c < pr) ? l * rrow : 0.0;
             }
-        } else {
-            idle_work(cb);                                // three waves have nothing to do during these 16 pivots
         }
         __syncthreads();
         if (wave > cb) {
             double x[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = S[(r0 + rr) * LT + 16 * cb + 4 * i + q];
-            solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [&](auto kc) { solve_hook(cbc, kc); });
+            solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [](auto) {});
 #pragma unroll
             for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
             // The wave's OWN diagonal block loses L(w, cb) L(w, cb)^T right away -- its rows only, no other wave involved --
@@ -1050,19 +1052,13 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
                 for (int r = 0; r < 4; ++r)
                     S[(r0 + lk + 4 * r) * LT + r0 + li] -= (g[0][r] + g[1][r]) + (g[2][r] + g[3][r]);
             }
-        } else if (wave == cb) {
-            solve_idle(cbc);
-        } else {
+        } else if (wave < cb) {
             // rows of finished waves: the strict upper part of this block column is zero
 #pragma unroll
             for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = 0.0;
         }
         __syncthreads();
-    });
-}
-
-__device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, int* info, int col_base, int n_valid) {
-    potf2_tile(S, Dp, rinv, info, col_base, n_valid, [](int) {}, [](auto, auto) {}, [](auto) {});
+    }
 }
 
 // One 16 x 16 block of the solve X L^T = B, in place (X: LDS tile, stride LT; S holds L as potf2_tile left it, with Dp and
@@ -1070,24 +1066,14 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
 // left (one MFMA product, K = 16 cb, four independent accumulators: a dependent v_mfma_f64 chain costs ~200 cycles per link),
 // then the 16 x 16 triangle with 4 lanes per row in registers (solve16).  Wave-local; any wave may take any row block.  The
 // unit of the scheduled solve group (k_potrf_step).
-template <int cb>
-__device__ __forceinline__ void trsm_block(double* X, const double* S, const double* Dp, const double* rinv, int rb) {
+__device__ __forceinline__ void trsm_block(double* X, const double* S, const double* Dp, const double* rinv, int rb, int cb) {
     const int lane = threadIdx.x & 63;
     const int r0 = 16 * rb;
     const int li = lane & 15, lk = lane >> 4;
     const int rr = lane >> 2, q = lane & 3;
-    if constexpr (cb > 0) {
+    if (cb > 0) {
         d4 acc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
-        const double* ap = X + (r0 + li) * LT + lk;
-        const double* bp = S + (16 * cb + li) * LT + lk;
-        double av[4 * cb], bv[4 * cb];
-#pragma unroll
-        for (int s4 = 0; s4 < 4 * cb; ++s4) { av[s4] = ap[4 * s4]; bv[s4] = bp[4 * s4]; }
-#pragma unroll
-        for (int s4 = 0; s4 < 4 * cb; ++s4)
-            acc[s4 & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc[s4 & 3], 0, 0, 0);
+        mma_left_n(acc, X + (r0 + li) * LT + lk, S + (16 * cb + li) * LT + lk, cb);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
@@ -1696,52 +1682,19 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         const int q0 = (j - 1) * TB;
         for (int e = tid; e < TB * TB; e += 256) A[(size_t)(q0 + (e >> 6)) * ld + q0 + (e & 63)] = scratch[e];
     };
-    if (j > 0 && a == 0 && b == 0 && !diag_inv) move_prev();
     // the tiles this block updates are fetched into registers now, so that their latency hides behind the MFMA phase
     TileRegs rX, rS, rD;
     if (lam && j == 0) stamp_enter(form.stamps);
     STEP_TRACE(0);
-    if (diag_inv && xgroup) {
-        // ---- the diagonal block's solve group: W_jj = L_jj^-1 as the solve X L_jj^T = I, column block by column block in step
-        // with the factoring group's barriers exactly like a panel block's solve (column block cb of L_jj is final two
-        // intervals before it is needed); W_jj = X^T.  Row r of X is zero left of column r -- exactly: every term is 0 * finite.
-        for (int e = tid; e < TB * LT; e += 256) X[e] = (e / LT == e % LT) ? 1.0 : 0.0;
-        STEP_TRACE(1);
-        __syncthreads();                                  // (tile in LDS)
-        STEP_TRACE(2);
-        // Behind the first barrier, not in front of it: the copy's loads miss every cache, and the factoring group would wait
-        // 1 - 2 us at that barrier for a tile nobody reads during this launch (the step trace showed exactly that).  `scratch`
-        // is overwritten only after the factorisation, eight barriers from here.
-        if (j > 0) move_prev();
-#pragma unroll
-        for (int sl = 1; sl < 5; ++sl) { __syncthreads(); STEP_TRACE(2 + 2 * sl); }   // (the four intervals a panel block's update takes)
-        // (the panel blocks' schedule of the solve, see there)
-        if (wave == 0) { trsm_block<0>(X, S, dprep, rinv, 0); trsm_block<0>(X, S, dprep, rinv, 2); }
-        else if (wave == 1) { trsm_block<0>(X, S, dprep, rinv, 1); trsm_block<1>(X, S, dprep, rinv, 1); }
-        else if (wave == 3) { trsm_block<0>(X, S, dprep, rinv, 3); trsm_block<1>(X, S, dprep, rinv, 3); }
-        __syncthreads();
-        if (wave == 0) trsm_block<1>(X, S, dprep, rinv, 0);
-        else if (wave == 1) trsm_block<2>(X, S, dprep, rinv, 1);
-        else if (wave == 2) trsm_block<1>(X, S, dprep, rinv, 2);
-        __syncthreads();
-        if (wave == 0) trsm_block<2>(X, S, dprep, rinv, 0);
-        else if (wave == 1) trsm_block<2>(X, S, dprep, rinv, 3);
-        else if (wave == 2) trsm_block<2>(X, S, dprep, rinv, 2);
-        __syncthreads();
-        trsm_block<3>(X, S, dprep, rinv, wave);
-        STEP_TRACE(19);
-        __syncthreads();
-        STEP_TRACE(20);
-        tile_s2g_t(X, Winv, ld, j0, j0);
-        STEP_TRACE(12);
-        return;
-    }
-    if (panel && a != 0) {
-        // ---- a block of the panel column below the diagonal: two groups of four waves ----
+    if (panel) {
+        // ---- a block of the panel column, the diagonal one included: two groups of four waves ----
+        // (ONE copy of every inlined piece -- potf2_tile, the solve block, the tile formation -- for all of them: see potf2_tile
+        // on what the code size of this kernel costs)
+        long long* tw_words = reinterpret_cast<long long*>(scratch + 3 * TB * TB);
         if (!xgroup) {
-            // factoring group: the diagonal tile A_jj (minus the rank-64 update the previous launch formed), factored here
-            // redundantly -- no inter-block hand-off -- while the solve group works on the block's own tile
-            __builtin_amdgcn_s_setprio(3);                // (the latency-bound group goes first where both want the same SIMD)
+            // factoring group: the diagonal tile A_jj (minus the rank-64 update the previous launch formed), factored by every
+            // panel block itself -- no inter-block hand-off -- while the solve group works on the block's own tile
+            if (a != 0 || diag_inv) __builtin_amdgcn_s_setprio(3);   // (the latency-bound group goes first where both want the same SIMD)
             tile_fetch(rS, do_form, load_old, A, form, ld, j0, j0, bypass);
             if (j > 0) {
                 tile_g2r(rD, Dn_in, TB, 0, 0);
@@ -1749,59 +1702,61 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
                 for (int u = 0; u < 16; ++u) rS.v[u] -= rD.v[u];
             }
             if (xi_duty) form_xi(form, ld, tid, bypass);
+            if (a == 0 && tid == 0) tw_words[(j + 1) & 1] = 0;       // the twins' word of the next step (see POTRF_SCRATCH)
             tile_r2s(S, rS);
             STEP_TRACE(1);
             __syncthreads();
             STEP_TRACE(2);
+            if (a == 0 && j > 0 && !diag_inv) move_prev();            // (no second half in this block: nobody else to do it)
             potf2_tile(S, dprep, rinv, info, j0, n_valid);
             STEP_TRACE(3);
-            if (a == 1 && tw == 0) {
+            if (a == 0) {
+                // The diagonal block must not overwrite A_jj in place: the other panel blocks read it during this launch.  It parks
+                // L_jj in `scratch`; the next step's diagonal block moves it into place.  The last step has no readers.
+                if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);
+                else tile_s2g(S, scratch, TB, 0, 0);                  // column-major tile
+            } else if (a == 1 && tw == 0) {
                 // The block below the diagonal: behind the last barrier its solve group still has the last K-slice of the next
                 // diagonal tile's update and that tile's stores to do -- so THIS group, done, stores the solved tile meanwhile.
                 // (Only once every twin has read the tile it overwrites, see POTRF_SCRATCH.)
                 const int need = potrf_twins(Tn, j);
                 if (need > 0 && lane == 0) {
-                    const long long* w = reinterpret_cast<const long long*>(scratch + 3 * TB * TB) + (j & 1);
                     int it = 0;
-                    while (!join_ready(w, need)) {
+                    while (!join_ready(tw_words + (j & 1), need)) {
                         if (++it >= (1 << 21)) { atomicMin(info, -1); break; }   // (the twins never read it: the factor is not to be trusted)
                         __builtin_amdgcn_s_sleep(16);
                     }
                 }
                 tile_s2g(X, A, ld, i0, j0);
             }
+            STEP_TRACE(4);
             return;
         }
-        // solve group: the own tile (j + a, j).  Its rank-64 update L_{i,j-1} L_{j,j-1}^T takes the first four of the
-        // factoring group's eight barrier intervals (one 16-deep K-slice each, 16 MFMAs per wave), the triangular solve
-        // against L_jj the other four: column block cb of L_jj is final two intervals before it is needed here.
-        tile_fetch(rX, do_form, load_old, A, form, ld, i0, j0, bypass);
-        if (j > 0) {
-            const int p0 = (j - 1) * TB;
-            load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
-            load_panel_n(P1, A, ld, k0, p0, TB, tid);         // L_{j, j-1}
+        // solve group.  Below the diagonal: the block's own tile (j + a, j) -- its rank-64 update L_{i,j-1} L_{j,j-1}^T, then the
+        // solve X L_jj^T = A_ij.  In the diagonal block (diag_inv): the same solve on the identity, W_jj = X^T = L_jj^-1 (row r of
+        // X is zero left of column r -- exactly: every term is 0 * finite), instead of an inversion behind the factorisation.
+        const bool below = (a != 0);
+        if (below) {
+            tile_fetch(rX, do_form, load_old, A, form, ld, i0, j0, bypass);
+            if (j > 0) {
+                const int p0 = (j - 1) * TB;
+                load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
+                load_panel_n(P1, A, ld, k0, p0, TB, tid);         // L_{j, j-1}
+            }
+            tile_r2s(X, rX);
+            if (tw > 0 && tid == 0)                           // (rX has arrived: it was just stored to LDS)
+                __hip_atomic_fetch_add((__attribute__((address_space(1))) long long*)(tw_words + (j & 1)), 1LL, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (int e = tid; e < TB * LT; e += 256) X[e] = (e / LT == e % LT) ? 1.0 : 0.0;
         }
-        tile_r2s(X, rX);
-        long long* tw_word = reinterpret_cast<long long*>(scratch + 3 * TB * TB) + (j & 1);
-        if (tw > 0 && tid == 0)                           // (rX has arrived: it was just stored to LDS)
-            __hip_atomic_fetch_add((__attribute__((address_space(1))) long long*)tw_word, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         STEP_TRACE(1);
         __syncthreads();
         STEP_TRACE(2);
-        auto own_slice = [&](int sl) {
-            const int li = lane & 15, lk = lane >> 4;
-            const double* ap = P0 + (16 * sl + lk) * PS + wr * 32 + li;
-            const double* bp = P1 + (16 * sl + lk) * PS + wc * 32 + li;
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
-                accX.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, accX.t[0][0], 0, 0, 0);
-                accX.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, accX.t[0][1], 0, 0, 0);
-                accX.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, accX.t[1][0], 0, 0, 0);
-                accX.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accX.t[1][1], 0, 0, 0);
-                ap += 4 * PS; bp += 4 * PS;
-            }
-        };
+        // The diagonal block moves the previous step's L tile into place BEHIND its first barrier: the copy's loads miss every
+        // cache, and in front of the barrier the factoring group waited 1 - 2 us for a tile nobody reads during this launch
+        // (the step trace showed exactly that).  `scratch` is overwritten only after the factorisation, eight barriers on.
+        if (!below && j > 0) move_prev();
         // SIMD-AWARE SCHEDULE.  Wave w of the factoring group and wave w of this group share a SIMD (tools/simd_map_probe.hip:
         // always, whatever the SIMD's number), and FP64 MFMAs and FP64 vector instructions share its pipe: a 64-cycle MFMA of
         // this group in front of a dependent FMA of the pivot chain delays the chain by all of it.  Measured (step trace, this
@@ -1814,20 +1769,35 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
         // and the work moves: the tile's own rank-64 update (four K-slices per wave, I0 .. I3) and the sixteen 16 x 16 blocks of
         // the triangular solve (I4 .. I7; X is in LDS, so any wave can take any row block) go where a SIMD is free.
         {
+            // K-slices of the own update per wave and interval, a nibble each (immediates: a table in memory costs a scalar-cache
+            // miss per interval): wave 0: 0 2 2 0, wave 1: 3 0 0 1, waves 2 and 3: 2 0 2 0
+            const unsigned nslice = (wave == 0) ? 0x0220u : (wave == 1) ? 0x1003u : 0x0202u;
             int done = 0;
-            auto slices = [&](int n) {
-                if (j == 0) return;
-                for (int q = 0; q < n; ++q) own_slice(done++);
-                if (done == 4) { tile_sub_acc(X, accX, lane, wr, wc); done = 5; }
-            };
-            slices(wave == 0 ? 0 : (wave == 1 ? 3 : 2));                       // I0
-            STEP_TRACE(3); __syncthreads(); STEP_TRACE(4);
-            slices(wave == 0 ? 2 : 0);                                         // I1
-            STEP_TRACE(5); __syncthreads(); STEP_TRACE(6);
-            slices(wave == 1 ? 0 : 2);                                         // I2
-            STEP_TRACE(7); __syncthreads(); STEP_TRACE(8);
-            slices(wave == 1 ? 1 : 0);                                         // I3
-            STEP_TRACE(9); __syncthreads(); STEP_TRACE(10);
+#pragma unroll 1
+            for (int it = 0; it < 4; ++it) {
+                if (below && j > 0) {
+                    const int n = (nslice >> (4 * it)) & 15;
+                    for (int q = 0; q < n; ++q) {
+                        const int sl = done++;
+                        const int li = lane & 15, lk = lane >> 4;
+                        const double* ap = P0 + (16 * sl + lk) * PS + wr * 32 + li;
+                        const double* bp = P1 + (16 * sl + lk) * PS + wc * 32 + li;
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) {
+                            const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
+                            accX.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, accX.t[0][0], 0, 0, 0);
+                            accX.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, accX.t[0][1], 0, 0, 0);
+                            accX.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, accX.t[1][0], 0, 0, 0);
+                            accX.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accX.t[1][1], 0, 0, 0);
+                            ap += 4 * PS; bp += 4 * PS;
+                        }
+                    }
+                    if (done == 4) { tile_sub_acc(X, accX, lane, wr, wc); done = 5; }
+                }
+                STEP_TRACE(3 + 2 * it);
+                __syncthreads();
+                STEP_TRACE(4 + 2 * it);
+            }
         }
         const bool next = (a == 1);               // this workgroup also forms the next diagonal tile's update X X^T (Dn_out)
         // ... its share of the ten lower 16 x 16 tiles: tile t belongs to workgroup t mod (1 + twins), and a workgroup's tiles go
@@ -1847,73 +1817,62 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             for (int q = 0; q < 4; ++q)
                 if (q < gcount) syrk_slice(g[q], X, gR[q], gC[q], c);
         };
-        // I4: column block 0 everywhere, block 1 where its rows are at hand (D_1 is final since I2)
-        if (wave == 0) { trsm_block<0>(X, S, dprep, rinv, 0); trsm_block<0>(X, S, dprep, rinv, 2); }
-        else if (wave == 1) { trsm_block<0>(X, S, dprep, rinv, 1); trsm_block<1>(X, S, dprep, rinv, 1); }
-        else if (wave == 3) { trsm_block<0>(X, S, dprep, rinv, 3); trsm_block<1>(X, S, dprep, rinv, 3); }
-        STEP_TRACE(13); __syncthreads(); STEP_TRACE(14);
-        // I5
-        if (wave == 0) trsm_block<1>(X, S, dprep, rinv, 0);
-        else if (wave == 1) trsm_block<2>(X, S, dprep, rinv, 1);
-        else if (wave == 2) trsm_block<1>(X, S, dprep, rinv, 2);
-        STEP_TRACE(15); __syncthreads(); STEP_TRACE(16);
-        // I6 (slices 0 and 1 of X are final in all rows)
-        if (wave == 0) trsm_block<2>(X, S, dprep, rinv, 0);
-        else if (wave == 1) trsm_block<2>(X, S, dprep, rinv, 3);
-        else if (wave == 2) trsm_block<2>(X, S, dprep, rinv, 2);
-        syrk(0); syrk(1);
-        STEP_TRACE(17); __syncthreads(); STEP_TRACE(18);
-        // I7 (slice 2 is final)
-        trsm_block<3>(X, S, dprep, rinv, wave);
-        syrk(2);
-        STEP_TRACE(19); __syncthreads(); STEP_TRACE(20);
-        syrk(3);
+        {
+            // solve blocks per (interval, wave): column block * 4 + row block, 0xff = none.  I4: column block 0 everywhere, block 1
+            // where its rows are at hand (D_1 is final since I2); I7: the last column block, each wave its own rows
+            //   I4: w0 T0r0 T0r2 | w1 T0r1 T1r1 | w2 -          | w3 T0r3 T1r3
+            //   I5: w0 T1r0      | w1 T2r1      | w2 T1r2       | w3 -
+            //   I6: w0 T2r0      | w1 T2r3      | w2 T2r2       | w3 -
+            //   I7: w0 T3r0      | w1 T3r1      | w2 T3r2       | w3 T3r3
+            // packed per wave as bytes [interval][unit] (immediates, no table in memory)
+            const unsigned long long units = (wave == 0) ? 0xff0cff08ff040200ull
+                                           : (wave == 1) ? 0xff0dff0bff090501ull
+                                           : (wave == 2) ? 0xff0eff0aff06ffffull
+                                                         : 0xff0fffffffff0703ull;
+#pragma unroll 1
+            for (int it = 0; it < 4; ++it) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q < gcount) syrk_store(g[q], Dn_out, gR[q], gC[q]);
+                for (int u = 0; u < 2; ++u) {
+                    const int unit = (int)((units >> (8 * (2 * it + u))) & 0xff);
+                    if (unit != 0xff) trsm_block(X, S, dprep, rinv, unit & 3, unit >> 2);
+                }
+                // K-slice c of the next diagonal update once column block c of X is final in all rows: 0 and 1 in I6, 2 in I7
+                if (it == 2) { syrk(0); syrk(1); }
+                else if (it == 3) syrk(2);
+                STEP_TRACE(13 + 2 * it);
+                __syncthreads();
+                STEP_TRACE(14 + 2 * it);
+            }
+        }
+        if (next) {
+            syrk(3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < gcount) syrk_store(g[q], Dn_out, gR[q], gC[q]);
+        }
         STEP_TRACE(11);
-        if (!next) tile_s2g(X, A, ld, i0, j0);           // (the block below the diagonal: its factoring group stores, the twins nobody)
+        if (!below) tile_s2g_t(X, Winv, ld, j0, j0);
+        else if (!next) tile_s2g(X, A, ld, i0, j0);      // (the block below the diagonal: its factoring group stores, the twins nobody)
         STEP_TRACE(12);
         return;
     }
+    // ---- a trailing tile: A_ik -= L_{i,j-1} L_{k,j-1}^T, through LDS for coalesced global access ----
     // (the Lambda chain forms its tiles instead of loading them; step 0's last workgroup also writes xi)
-    if (!panel) tile_fetch(rX, do_form, load_old, A, form, ld, i0, k0, bypass);
-    else tile_fetch(rS, do_form, load_old, A, form, ld, j0, j0, bypass);
+    tile_fetch(rX, do_form, load_old, A, form, ld, i0, k0, bypass);
     if (xi_duty) form_xi(form, ld, tid, bypass);
-    if (panel && j > 0) tile_g2r(rD, Dn_in, TB, 0, 0);    // the diagonal tile's rank-64 update, formed by the previous launch
-    if (!panel) {
-        if (j > 0) {
-            const int p0 = (j - 1) * TB;
-            load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
-            if (a != b) load_panel_n(P1, A, ld, k0, p0, TB, tid);   // L_{k, j-1}
-            __syncthreads();
-            tile_mma(accX, P0, (a != b) ? P1 : P0, TB, lane, wr, wc);
-            __syncthreads();
-        }
-        // plain trailing tile: A_ik -= acc, through LDS for coalesced global access
-        tile_r2s(X, rX);
-        __syncthreads();
-        tile_sub_acc(X, accX, lane, wr, wc);
-        __syncthreads();
-        tile_s2g(X, A, ld, i0, k0);
-        return;
-    }
-    // ---- the diagonal block (a == b == 0) ----
     if (j > 0) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) rS.v[u] -= rD.v[u];
+        const int p0 = (j - 1) * TB;
+        load_panel_n(P0, A, ld, i0, p0, TB, tid);         // L_{i, j-1}
+        if (a != b) load_panel_n(P1, A, ld, k0, p0, TB, tid);   // L_{k, j-1}
+        __syncthreads();
+        tile_mma(accX, P0, (a != b) ? P1 : P0, TB, lane, wr, wc);
+        __syncthreads();
     }
-    if (diag_inv) __builtin_amdgcn_s_setprio(3);        // (as in the panel blocks: the latency-bound group first)
-    if (tid == 0 && !xgroup) reinterpret_cast<long long*>(scratch + 3 * TB * TB)[(j + 1) & 1] = 0;   // the twins' word of the next step
-    tile_r2s(S, rS);
-    STEP_TRACE(1);
+    tile_r2s(X, rX);
     __syncthreads();
-    STEP_TRACE(2);
-    potf2_tile(S, dprep, rinv, info, j0, n_valid);
-    STEP_TRACE(3);
-    if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);       // no other block reads A_jj in the last step
-    else tile_s2g(S, scratch, TB, 0, 0);                // column-major tile
-    STEP_TRACE(4);
+    tile_sub_acc(X, accX, lane, wr, wc);
+    __syncthreads();
+    tile_s2g(X, A, ld, i0, k0);
 }
 
 // v[kk] = V[64 kb + kk][j] = W'[Qp-1-64kb-kk][Qp-1-j]: 64 contiguous doubles of column Qp-1-j of W' (descending), read
