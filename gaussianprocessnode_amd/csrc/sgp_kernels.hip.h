@@ -947,7 +947,10 @@ __device__ __forceinline__ void mma_left_n(d4 (&acc)[4], const double* ap, const
     else if (chunks == 2) mma_left<2>(acc, ap, bp);
     else if (chunks == 3) mma_left<3>(acc, ap, bp);
 }
-__device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, int* info, int col_base, int n_valid) {
+// `idle(iv)`: what a wave does that has nothing to do in barrier interval iv (2 cb: the pivot run of block cb -- every wave but
+// cb; 2 cb + 1: the solve phase behind it -- the waves <= cb).  k_potrf_step gives such waves blocks of the panel solve.
+template <class Idle>
+__device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, int* info, int col_base, int n_valid, Idle&& idle) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = 16 * wave;
     const int li = lane & 15, lk = lane >> 4;
@@ -1026,6 +1029,8 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
                 S[(r0 + pr) * LT + 16 * cb + c] = l;
                 Dp[cb * DPB + pr * DPS + c] = (c < pr) ? l * rrow : 0.0;
             }
+        } else {
+            idle(2 * cb);
         }
         __syncthreads();
         if (wave > cb) {
@@ -1052,10 +1057,13 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
                 for (int r = 0; r < 4; ++r)
                     S[(r0 + lk + 4 * r) * LT + r0 + li] -= (g[0][r] + g[1][r]) + (g[2][r] + g[3][r]);
             }
-        } else if (wave < cb) {
-            // rows of finished waves: the strict upper part of this block column is zero
+        } else {
+            if (wave < cb) {
+                // rows of finished waves: the strict upper part of this block column is zero
 #pragma unroll
-            for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = 0.0;
+                for (int i = 0; i < 4; ++i) S[(r0 + rr) * LT + 16 * cb + 4 * i + q] = 0.0;
+            }
+            idle(2 * cb + 1);
         }
         __syncthreads();
     }
@@ -1708,26 +1716,47 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             __syncthreads();
             STEP_TRACE(2);
             if (a == 0 && j > 0 && !diag_inv) move_prev();            // (no second half in this block: nobody else to do it)
-            potf2_tile(S, dprep, rinv, info, j0, n_valid);
+            // What this group's waves do while they have nothing to factor (potf2_tile's `idle`): wave 0 is free in every interval
+            // behind its own pivot run -- a fifth worker of the panel solve (T0r2 in I4, T1r3 in I5, T2r3 in I6; the blocks the
+            // solve group's waves 2 and 3 cannot take there, see below: they run two to a SIMD with a latency-bound solve of
+            // that group, which costs neither much).  Waves 1 and 2 are free from I6 on: in the block below the diagonal and
+            // its twins they form the workgroup's share of the next diagonal tile's update X X^T (tile t of the ten lower
+            // 16 x 16 tiles belongs to workgroup t mod (1 + twins)): K-slice c once column block c of X is final in all rows.
+            const bool has_solve = (a != 0) || diag_inv;
+            const int ntwf = 1 + potrf_twins(Tn, j);
+            int fcount = 0, fR[3], fC[3];
+            d4 fg[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                fg[q] = (d4){0.0, 0.0, 0.0, 0.0};
+                fR[q] = fC[q] = 0;
+                const int t = tw + ntwf * ((wave - 1) + 2 * q);      // the q-th tile of wave 1 / wave 2
+                if (a == 1 && (wave == 1 || wave == 2) && t < 10) { tile_from_index(t, fR[q], fC[q]); fcount = q + 1; }
+            }
+            auto fsyrk = [&](int c) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < fcount) syrk_slice(fg[q], X, fR[q], fC[q], c);
+            };
+            auto idle = [&](int iv) {
+                if (!has_solve) return;
+                if (wave == 0 && iv >= 4 && iv <= 6) trsm_block(X, S, dprep, rinv, iv == 4 ? 2 : 3, iv - 4);
+                if (iv == 6) { fsyrk(0); fsyrk(1); }
+                else if (iv == 7) fsyrk(2);
+            };
+            potf2_tile(S, dprep, rinv, info, j0, n_valid, idle);
             STEP_TRACE(3);
+            if (fcount > 0) {
+                fsyrk(3);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < fcount) syrk_store(fg[q], Dn_out, fR[q], fC[q]);
+            }
             if (a == 0) {
                 // The diagonal block must not overwrite A_jj in place: the other panel blocks read it during this launch.  It parks
                 // L_jj in `scratch`; the next step's diagonal block moves it into place.  The last step has no readers.
                 if (j == Tn - 1) tile_s2g(S, A, ld, j0, j0);
                 else tile_s2g(S, scratch, TB, 0, 0);                  // column-major tile
-            } else if (a == 1 && tw == 0) {
-                // The block below the diagonal: behind the last barrier its solve group still has the last K-slice of the next
-                // diagonal tile's update and that tile's stores to do -- so THIS group, done, stores the solved tile meanwhile.
-                // (Only once every twin has read the tile it overwrites, see POTRF_SCRATCH.)
-                const int need = potrf_twins(Tn, j);
-                if (need > 0 && lane == 0) {
-                    int it = 0;
-                    while (!join_ready(tw_words + (j & 1), need)) {
-                        if (++it >= (1 << 21)) { atomicMin(info, -1); break; }   // (the twins never read it: the factor is not to be trusted)
-                        __builtin_amdgcn_s_sleep(16);
-                    }
-                }
-                tile_s2g(X, A, ld, i0, j0);
             }
             STEP_TRACE(4);
             return;
@@ -1799,60 +1828,36 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
                 STEP_TRACE(4 + 2 * it);
             }
         }
-        const bool next = (a == 1);               // this workgroup also forms the next diagonal tile's update X X^T (Dn_out)
-        // ... its share of the ten lower 16 x 16 tiles: tile t belongs to workgroup t mod (1 + twins), and a workgroup's tiles go
-        // round the waves 0, 1, 2 (wave 3 is idle in I5 and I6 and would have everything left to do at the end)
-        const int ntw = 1 + potrf_twins(Tn, j);
-        int gcount = 0, gR[4], gC[4];
-        d4 g[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            g[q] = (d4){0.0, 0.0, 0.0, 0.0};
-            gR[q] = gC[q] = 0;
-            const int t = tw + ntw * (wave + 3 * q);     // my q-th tile
-            if (next && wave < 3 && t < 10) { tile_from_index(t, gR[q], gC[q]); gcount = q + 1; }
-        }
-        auto syrk = [&](int c) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q < gcount) syrk_slice(g[q], X, gR[q], gC[q], c);
-        };
-        {
-            // solve blocks per (interval, wave): column block * 4 + row block, 0xff = none.  I4: column block 0 everywhere, block 1
-            // where its rows are at hand (D_1 is final since I2); I7: the last column block, each wave its own rows
-            //   I4: w0 T0r0 T0r2 | w1 T0r1 T1r1 | w2 -          | w3 T0r3 T1r3
-            //   I5: w0 T1r0      | w1 T2r1      | w2 T1r2       | w3 -
-            //   I6: w0 T2r0      | w1 T2r3      | w2 T2r2       | w3 -
-            //   I7: w0 T3r0      | w1 T3r1      | w2 T3r2       | w3 T3r3
-            // packed per wave as bytes [interval][unit] (immediates, no table in memory)
-            const unsigned long long units = (wave == 0) ? 0xff0cff08ff040200ull
-                                           : (wave == 1) ? 0xff0dff0bff090501ull
-                                           : (wave == 2) ? 0xff0eff0aff06ffffull
-                                                         : 0xff0fffffffff0703ull;
+        // I4 .. I7: column block it - 4 of the wave's own 16 rows -- except where the wave's SIMD carries the factorisation (wave 2
+        // in I4, wave 3 in I5 and I6): those blocks are taken by wave 0 of the factoring group (see `idle` there), and wave 3
+        // picks its rows up again at T3.
+        const bool next = (a == 1);
+        const int tw_need = (next && tw == 0) ? potrf_twins(Tn, j) : 0;      // the owner of the tile the twins read, see POTRF_SCRATCH
+        bool tw_ready = true;
 #pragma unroll 1
-            for (int it = 0; it < 4; ++it) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int unit = (int)((units >> (8 * (2 * it + u))) & 0xff);
-                    if (unit != 0xff) trsm_block(X, S, dprep, rinv, unit & 3, unit >> 2);
-                }
-                // K-slice c of the next diagonal update once column block c of X is final in all rows: 0 and 1 in I6, 2 in I7
-                if (it == 2) { syrk(0); syrk(1); }
-                else if (it == 3) syrk(2);
-                STEP_TRACE(13 + 2 * it);
-                __syncthreads();
-                STEP_TRACE(14 + 2 * it);
-            }
-        }
-        if (next) {
-            syrk(3);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q < gcount) syrk_store(g[q], Dn_out, gR[q], gC[q]);
+        for (int it = 0; it < 4; ++it) {
+            // (the owner looks at the twins' word early -- the answer is normally there long before it is needed, and a look costs
+            // a trip to memory that would otherwise sit in front of the tile's store)
+            if (it == 3 && tw_need > 0 && lane == 0) tw_ready = join_ready(tw_words + (j & 1), tw_need);
+            const bool off = (wave == 2 && it == 0) || (wave == 3 && (it == 1 || it == 2));
+            if (!off) trsm_block(X, S, dprep, rinv, wave, it);
+            STEP_TRACE(13 + 2 * it);
+            __syncthreads();
+            STEP_TRACE(14 + 2 * it);
         }
         STEP_TRACE(11);
         if (!below) tile_s2g_t(X, Winv, ld, j0, j0);
-        else if (!next) tile_s2g(X, A, ld, i0, j0);      // (the block below the diagonal: its factoring group stores, the twins nobody)
+        else if (tw == 0) {
+            // (the twins store nothing; the owner of the tile only once every twin has read what it overwrites, see POTRF_SCRATCH)
+            if (tw_need > 0 && lane == 0 && !tw_ready) {
+                int it = 0;
+                while (!join_ready(tw_words + (j & 1), tw_need)) {
+                    if (++it >= (1 << 21)) { atomicMin(info, -1); break; }   // (the twins never read it: the factor is not to be trusted)
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+            tile_s2g(X, A, ld, i0, j0);
+        }
         STEP_TRACE(12);
         return;
     }
