@@ -267,8 +267,9 @@ int sgp_get_phase_totals(sgp_handle* h, int64_t* totals /* SGP_T_COUNT */, int64
  * [16 + 4 cb ..]: that feeder's wave 0 at column block cb: block in registers, solved, published, updates applied.
  * which: 0 = K_uu chain, 1 = Lambda chain. */
 /* diagnostics of the Cholesky step kernel (all zeros unless the library was built with -DSGP_STEP_TRACE): out[512],
- * 100 MHz stamps of the workgroup that owns tile (j + 1, j) of the Lambda chain; slot 32 j + 16 g + e = event e of wave
- * group g (0 factoring, 1 solve) in step j. */
+ * 100 MHz stamps of one panel workgroup of the Lambda chain (the owner of tile (j + 1, j), or the block chosen with
+ * -DSGP_STEP_TRACE_A=a); slot 64 j + 32 g + e = event e of wave group g (0 factoring, 1 solve) in step j < 8.  Events: see
+ * tools/step_trace.py. */
 int sgp_get_step_trace(int64_t* out /* 512 */);
 /* diagnostics of the variant library built with -DSGP_SWEEP_TRACE (all zeros otherwise): out[65 s] = begin, out[65 s + 1 .. 65 s + 64]
  * = exit ticks (100 MHz; take the maximum) of trace slot s of the last sweep, 256 slots: 0 k_prep_xu, 2 k_gram_uf, 16 + j step j of the
