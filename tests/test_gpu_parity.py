@@ -997,6 +997,24 @@ def test_overlapped_sweep_agrees_with_the_plain_order_and_with_a_dense_prior(G, 
     assert math.isclose(a[3].energy, b[3].energy, rel_tol=1e-6)     # (the energy cancels against s_kk: cond(K_uu) * eps)
 
 
+def test_slab_store_switch_changes_no_bit(G, monkeypatch):
+    # SGP_SYRK_WT (A/B switch of k_syrk_stream: slabs stored past the L2): same sums, same bits, in the masked groups or in all
+    N, M, D, w = 6000, 320, 4, 300.0
+    X, Xu, y, _ = synth(N, M, D, seed=23)
+    s2, ell = 0.8, np.array([1.1, 2.0, 1.4, 0.9])
+    monkeypatch.setenv("SGP_OVERLAP", "1")
+    res = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("SGP_SYRK_WT", mode)
+        res[mode] = _sweep_once(G, X, Xu, y, s2, ell, w, jitter=1e-8)
+    base = res["0"][1][0]
+    for mode in ("1", "2"):
+        other = res[mode][1][0]
+        assert np.array_equal(base[4][0], other[4][0]) and np.array_equal(base[4][1], other[4][1])      # Psi2, B
+        for i in range(3):
+            assert np.array_equal(base[i], other[i])                                                    # mu_v, Sigma_v, Uv
+
+
 def test_overlapped_and_plain_sweeps_interleave_on_one_handle(G, monkeypatch):
     # sweep() (overlapped) and sweep_local() + sweep_finish() (plain order, the two-phase entry points of the multi-GPU path)
     # on the same handle, back to back without waiting in between: the done word / statistics words keep them apart
