@@ -648,18 +648,21 @@ extern "C" int sgp_set_inducing(sgp_handle* h, const double* Xu) {
 //   * group 0 (tile columns [0, c0) of P Lambda P = the LAST c0 tile rows of Psi2) runs on all CUs in front of the chain, the
 //     other groups on the masked stream while the chain factors; a group must be complete when the chain reaches its first
 //     column.  The cuts are chosen by a small model of that schedule (all plans of up to three groups are tried): a SYRK
-//     launch lasts as long as its chunks are long (0.159 us per point of a chunk + 4 us, from the launch's real geometry),
-//     ~8 / ~6 us of assembly and gaps per unmasked / masked group, ~18 us per chain step.  Measured at T
+//     launch lasts as long as its chunks are long (0.18 us per point of a chunk + 5 us, from the launch's real geometry),
+//     ~8 / ~11 us of assembly, word kernel and gaps per unmasked / masked group, ~17 us per chain step, 4 us of margin.  Measured at T
 //     (N = 10 000, M = 512; sweeps/s on one box): plain order 3750; cuts {3} 3896, {2} 3832-3950, {2,4} 3925, {1,3} 3656,
 //     {2,3,5} 3790, {1,2,4} 3528 -- the model ranks them the same way.  When no plan beats the plain order by 5 us the plain
 //     order stays (huge N: the masked groups' lost CUs cost more than the chain's early start saves).
 static double model_overlap_end(const sgp_handle* h, int64_t n, const int* cuts, int ncuts, double* classic_end) {
     const int T = h->T;
-    // one SYRK launch = one resident round: its duration follows the points per chunk (0.159 us per point at four workgroups
-    // per CU, + ~4 us of launch ramp and tail), whatever the number of tiles -- fewer CUs or an awkward tile count show up as
+    // one SYRK launch = one resident round: its duration follows the points per chunk (0.18 us per point at four workgroups
+    // per CU, + ~5 us of launch ramp and tail), whatever the number of tiles -- fewer CUs or an awkward tile count show up as
     // fewer, longer chunks (syrk_geometry)
-    auto syrk_us = [&](int row_lo, int nrows, int cus) { return 4.0 + 0.159 * syrk_geometry(row_lo, nrows, cus, n).chunk; };
-    const double asm0 = 8.0, asmm = 6.0, step = 18.0;        // assembly + gaps behind a group's SYRK (unmasked / masked)
+    auto syrk_us = [&](int row_lo, int nrows, int cus) { return 5.0 + 0.18 * syrk_geometry(row_lo, nrows, cus, n).chunk; };
+    // assembly + gaps behind a group's SYRK (unmasked / masked); a chain step with its launch gap (18 before the step kernel's
+    // rework of round 3); and how long before its step a group should be there: a step that finds its group's word unset waits
+    // and then reads the statistics past the L2, element by element -- far slower than the wait alone
+    const double asm0 = 8.0, asmm = 11.0, step = 17.0, margin = 4.0, forming = 2.5;   // (forming: the poll and the extra tile loads of a step that forms a masked group)
     if (classic_end) *classic_end = syrk_us(0, T, h->num_cus) + asm0 + step * T;
     double ready[LAM_MAX_COLS];
     double t = syrk_us(T - cuts[0], cuts[0], h->num_cus) + asm0;          // group 0 assembled
@@ -671,7 +674,11 @@ static double model_overlap_end(const sgp_handle* h, int64_t n, const int* cuts,
         for (int c = c0; c < c1; ++c) ready[c] = t;
     }
     double end = ready[0];
-    for (int j = 0; j < T; ++j) end = std::max(end, ready[j]) + step;
+    for (int j = 0; j < T; ++j) {
+        bool forms = false;
+        for (int g = 0; g < ncuts; ++g) forms = forms || cuts[g] == j;
+        end = std::max(end, ready[j] + (j >= cuts[0] ? margin : 0.0)) + step + (forms ? forming : 0.0);
+    }
     return end;
 }
 
@@ -687,13 +694,14 @@ static void plan_overlap(sgp_handle* h, int64_t n) {
     if (cuts.empty()) {
         double classic = 0.0, best = 1e300;
         int cand[2];
-        for (int a = 1; a < T; ++a)
-            for (int b = a; b < T; ++b) {                    // b == a: one cut
-                cand[0] = a; cand[1] = b;
-                const int nc = (b > a) ? 2 : 1;
-                const double e = model_overlap_end(h, n, cand, nc, &classic);
-                if (e < best - 1e-9) { best = e; cuts.assign(cand, cand + nc); }
-            }
+        // ONE cut: with the step kernel of round 3 the chain no longer waits for a third group to be worth its launches -- measured
+        // at T {3} 4 290-4 320 against {2,4} 4 200-4 260 and {3,4} 4 210 sweeps/s, at N = 40 000 {5} 2 330 against {4,6} 2 270
+        // (more groups: SGP_OVERLAP_COLS)
+        for (int a = 1; a < T; ++a) {
+            cand[0] = a; cand[1] = a;
+            const double e = model_overlap_end(h, n, cand, 1, &classic);
+            if (e < best - 1e-9) { best = e; cuts.assign(cand, cand + 1); }
+        }
         if (h->env_overlap != 1 && best > classic - 5.0) return;
     }
     if ((int)cuts.size() + 1 > LAM_MAX_GROUPS) return;

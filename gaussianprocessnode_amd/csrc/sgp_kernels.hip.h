@@ -1074,24 +1074,37 @@ __device__ __forceinline__ void potf2_tile(double* S, double* Dp, double* rinv, 
 // left (one MFMA product, K = 16 cb, four independent accumulators: a dependent v_mfma_f64 chain costs ~200 cycles per link),
 // then the 16 x 16 triangle with 4 lanes per row in registers (solve16).  Wave-local; any wave may take any row block.  The
 // unit of the scheduled solve group (k_potrf_step).
-__device__ __forceinline__ void trsm_block(double* X, const double* S, const double* Dp, const double* rinv, int rb, int cb) {
+// The two halves on their own: the update needs the column blocks to the left of cb solved (and L's block row cb, final one
+// phase before D_cb is), the substitution needs D_cb -- so a block's update can run an interval ahead of its substitution.
+__device__ __forceinline__ void trsm_update(double* X, const double* S, int rb, int cb) {       // cb >= 1
     const int lane = threadIdx.x & 63;
     const int r0 = 16 * rb;
     const int li = lane & 15, lk = lane >> 4;
-    const int rr = lane >> 2, q = lane & 3;
-    if (cb > 0) {
-        d4 acc[4];
-        mma_left_n(acc, X + (r0 + li) * LT + lk, S + (16 * cb + li) * LT + lk, cb);
+    d4 acc[4];
+    mma_left_n(acc, X + (r0 + li) * LT + lk, S + (16 * cb + li) * LT + lk, cb);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-    }
+    for (int r = 0; r < 4; ++r)
+        X[(r0 + lk + 4 * r) * LT + 16 * cb + li] -= (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+}
+__device__ __forceinline__ void trsm_solve(double* X, const double* Dp, const double* rinv, int rb, int cb) {
+    const int lane = threadIdx.x & 63;
+    const int r0 = 16 * rb;
+    const int rr = lane >> 2, q = lane & 3;
     double x[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) x[i] = X[(r0 + rr) * LT + 16 * cb + 4 * i + q];
     solve16(x, Dp + cb * DPB, rinv + 16 * cb, q, [](auto) {});
 #pragma unroll
     for (int i = 0; i < 4; ++i) X[(r0 + rr) * LT + 16 * cb + 4 * i + q] = x[i];
+}
+// The solve work of one row block in solve interval it (0 .. 3 = I4 .. I7): the substitution of column block `it` behind its
+// update -- except that block 1's update runs ahead, behind block 0's substitution in I4: the interval of a pivot run has
+// room, the phase interval I5 (0.85 us) has none for more than a substitution.  (Block 3's update ahead in I6 as well:
+// I6 grows by more than I7 shrinks.)
+__device__ __forceinline__ void trsm_interval(double* X, const double* S, const double* Dp, const double* rinv, int rb, int it) {
+    if (it >= 2) trsm_update(X, S, rb, it);
+    trsm_solve(X, Dp, rinv, rb, it);
+    if (it == 0) trsm_update(X, S, rb, 1);
 }
 // K-slice c (columns 16 c .. 16 c + 15 of the solved tile X) of the lower 16 x 16 tile (R, C) of X X^T, formed transposed
 // (A operand = the column tile) so that the stores run along Dn's columns (Dn: 64 x 64, column-major, ld 64; the next step
@@ -1740,7 +1753,7 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             };
             auto idle = [&](int iv) {
                 if (!has_solve) return;
-                if (wave == 0 && iv >= 4 && iv <= 6) trsm_block(X, S, dprep, rinv, iv == 4 ? 2 : 3, iv - 4);
+                if (wave == 0 && iv >= 4 && iv <= 6) trsm_interval(X, S, dprep, rinv, iv == 4 ? 2 : 3, iv - 4);
                 if (iv == 6) { fsyrk(0); fsyrk(1); }
                 else if (iv == 7) fsyrk(2);
             };
@@ -1840,7 +1853,7 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             // a trip to memory that would otherwise sit in front of the tile's store)
             if (it == 3 && tw_need > 0 && lane == 0) tw_ready = join_ready(tw_words + (j & 1), tw_need);
             const bool off = (wave == 2 && it == 0) || (wave == 3 && (it == 1 || it == 2));
-            if (!off) trsm_block(X, S, dprep, rinv, wave, it);
+            if (!off) trsm_interval(X, S, dprep, rinv, wave, it);
             STEP_TRACE(13 + 2 * it);
             __syncthreads();
             STEP_TRACE(14 + 2 * it);
