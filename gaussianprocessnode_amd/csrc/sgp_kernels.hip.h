@@ -836,12 +836,13 @@ __global__ void __launch_bounds__(256) k_form_lambda(const double* __restrict__ 
 //   continue with step j without leaving the kernel: each of them ALSO factors the diagonal tile A_jj itself in
 //   LDS (redundant compute instead of an inter-block hand-off; its rank-64 update arrives as a tile formed by
 //   the previous launch, see syrk_slice) and solves X L_jj^T = A_ij for its own tile; the block on the
-//   diagonal writes L_jj.
+//   diagonal writes L_jj (and, with Winv, L_jj^-1).
 // Thread layout of the sequential parts: the triangular solves give 4 adjacent lanes (q = tid & 3) one row
 // r = tid >> 2, lane q keeping the row's entries c = q (mod 4) in registers (no reductions; the quad exchanges
 // the pivot entry with a DPP quad broadcast); the pivot runs of the factorisation use lane = 16 q + r over the
 // full symmetric 16 x 16 block (DPP row broadcast + one ds_bpermute per pivot, see potf2_tile).  Two workgroup
-// barriers per 16 pivots in the factorisation, none in the triangular solve.
+// barriers per 16 pivots in the factorisation; the panel solve's 16 x 16 blocks (trsm_update / trsm_solve) are wave-local and
+// placed in those eight intervals where their wave's SIMD is free of factoring work.
 // `info` receives (global column + 1) of the first non-positive pivot (LAPACK convention).
 // ------------------------------------------------------------------------------------------------
 
@@ -1603,10 +1604,11 @@ __device__ long long g_step_trace[8 * 64];
 #define STEP_TRACE(e) do { } while (0)
 #endif
 
-// Workgroups are launched with PSTEP_THREADS = 512 threads.  Only the blocks of the panel column below the diagonal use
-// the second half (the "solve group", waves 4 .. 7: they carry the block's own tile -- its rank-64 update, then its
-// triangular solve column block by column block, in step with the factoring group's eight barriers -- while waves 0 .. 3
-// factor the diagonal tile); everywhere else waves 4 .. 7 leave at once (ended waves do not count at a barrier).
+// Workgroups are launched with PSTEP_THREADS = 512 threads.  The blocks of the panel column use the second half (the "solve
+// group", waves 4 .. 7): below the diagonal it carries the block's own tile -- its rank-64 update, then its triangular solve
+// column block by column block, scheduled around the factoring group's eight barrier intervals (see the schedule in the kernel)
+// -- while waves 0 .. 3 factor the diagonal tile; in the diagonal block (when the inverse factor is wanted) it runs the same
+// solve on the identity, i.e. inverts L_jj.  Everywhere else waves 4 .. 7 leave at once (ended waves do not count at a barrier).
 constexpr int PSTEP_THREADS = 512;
 // TWINS: the block that owns tile (j + 1, j) also forms the next diagonal tile's update X X^T from its solved tile (160 MFMAs
 // that can only start once column blocks of X are final, i.e. in the last three barrier intervals) and was the last to leave
