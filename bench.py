@@ -94,7 +94,7 @@ def extras(headline):
     `configs`   sweeps/s of every BASELINE.json configuration on this box (tools/config_rates.py's shapes);
     `per_point` what the drop-in calls through the real plugin API when q(w) is random: every :w message needs its own
                 I1_n / I2_n (GPnode/UniSGPnode.jl:196-238), i.e. sgp_w_stats after every sweep -- the rate with that call in
-                the loop, and the roofline entry of its dominant kernel k_quadform_cols."""
+                the loop, and the roofline entry of its dominant kernel k_quadform_fused."""
     from gaussianprocessnode_amd import SGPDevice, _lib
     shapes = [("C1 toy regression (GPT_regression.ipynb)", 50, 20, 1, 1), ("C2 kin40k M=256", 10000, 256, 8, 1),
               ("T kin40k M=512", 10000, 512, 8, 1), ("C3 kin40k N=40000 on one GPU", 40000, 512, 8, 1),
@@ -118,16 +118,66 @@ def extras(headline):
                                    "order": "overlapped" if dev.overlap_plan() else "plain"})
             if per_point:
                 rate_pp = _rate(dev, reps, per_point=True)
-                q_us = [dev.time_kernel(_lib.SGP_TIME_QUADFORM + m, 10) for m in (0, 1)]
-                flops = float(N) * M * (M + 64)                  # lower-triangular factor, 64-wide tiles incl. the diagonal ones
-                tf = flops / (sum(q_us) / 2 * 1e-6) / 1e12
+                q_us = dev.time_kernel(_lib.SGP_TIME_QUADFORM, 10)
+                flops = 2.0 * float(N) * M * (M + 64)            # two lower-triangular factors, 64-wide tiles incl. the diagonal ones
+                tf = flops / (q_us * 1e-6) / 1e12
                 out["per_point"].append({
                     "config": name, "sweeps_per_s_with_w_stats": rate_pp, "sweeps_per_s_without": rate,
-                    "what": "sgp_sweep + sgp_w_stats (k_quadform_cols x 2 + k_w_point_finish, then 2 n doubles to the host) per iteration",
-                    "roofline_quadform": {"kernel": "k_quadform_cols (|L^-1 k_n|^2 and |Uv k_n|^2 from the resident K_uf)", "bound": "mfma",
+                    "what": "sgp_sweep + sgp_w_stats (k_quadform_fused + k_w_point_finish, then 2 n doubles to the host in one copy) per iteration",
+                    "roofline_quadform": {"kernel": "k_quadform_fused (|L^-1 k_n|^2, |Uv k_n|^2 and k_n . mu in one pass over the resident K_uf)", "bound": "mfma",
                                           "launch_us": q_us, "algorithmic_flops_per_launch": flops, "achieved": tf,
                                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS}})
     return out
+
+
+def scaling_leg(world, rank, local_rank, barrier):
+    """N > 1 only (or SGP_BENCH_SCALING=1): the same sweep on the N1M workload (N = 10^6, M = 512), sharded the same way, right
+    after the headline workload.  At T the replicated M^3 tail is two thirds of the sweep and no number of GPUs helps (DESIGN.md
+    section 5: 1.05x / 1.05x / 0.91x predicted); this is the regime the design does scale in (6.6x predicted at 8 GPUs), so one
+    SCALE run records both.  Returns sweeps/s (median of 3 blocks of 10 sweeps, max over ranks) and rank 0's phase durations."""
+    import torch
+    import torch.distributed as dist
+    from gaussianprocessnode_amd import _lib
+    from gaussianprocessnode_amd.distributed import HipEngine, ShardedSweep, shard_bounds
+    N, M, D = WORKLOADS["N1M"]
+    X, Xu, y, _, _ = synthetic(N, M, D, n_test=1)
+    lo, hi = shard_bounds(N, world, rank)
+    eng = HipEngine(hi - lo, M, D, 1, device=local_rank)
+    dev = eng.dev
+    dev.set_inducing(Xu)
+    dev.set_data(X[lo:hi], y[lo:hi])
+    dev.set_kernel(SIGMA2, ELL, 0.0)
+    dev.set_prior_isotropic(PRIOR_VAR)
+    dev.set_noise([[W_BAR]])
+    sw = ShardedSweep(eng)
+    for _ in range(3):
+        sw.sweep()
+    barrier()
+    dev.phase_totals(reset=True)
+    steps, block_s = 10, []
+    for _ in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sw.sweep()
+        barrier()
+        block_s.append(time.perf_counter() - t0)
+    if world > 1:
+        t = torch.tensor(block_s, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        block_s = [float(v) for v in t.cpu()]
+    phase_us, _ = dev.phase_totals()
+    sc = dev.scalars()
+    dev.close()
+    med = float(np.median(block_s))
+    return {"workload": f"N1M: N={N} M={M} D={D}, the same sweep and hyper-parameters, data-sharded x{world}",
+            "sweeps_per_s": steps / med, "ms_per_sweep": 1e3 * med / steps, "points_per_gpu": hi - lo, "scaling": "strong",
+            "blocks_ms_per_sweep": [1e3 * b / steps for b in block_s], "energy": sc.energy,
+            "phases_us_rank0": {"sweep_device": float(phase_us[_lib.SGP_T_SWEEP]), "local_statistics": float(phase_us[_lib.SGP_T_LOCAL]),
+                                "gap_local_to_finish_incl_allreduce": float(phase_us[_lib.SGP_T_GAP_LOCAL_FINISH]),
+                                "finish1_lambda_chain": float(phase_us[_lib.SGP_T_FINISH1]),
+                                "finish2_traces": float(phase_us[_lib.SGP_T_FINISH2])},
+            "collective": {"backend": sw.backend, "payload_doubles": int(eng.stats.numel())}}
 
 
 def main():
@@ -137,6 +187,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="T", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blocks", type=int, default=None,
+                    help="back-to-back timed blocks of --steps sweeps each (default 15, 5 at N > 1e5); the MEDIAN block is reported")
     args = ap.parse_args()
 
     import torch
@@ -187,19 +239,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Timed region: R back-to-back blocks, each EXACTLY --steps full sweeps bracketed by barrier + synchronize on both sides (max
+    # over ranks per block); the MEDIAN block is the reported one.  One block of 20 sweeps is 5 ms of timing -- a single hiccup of
+    # the host thread moved round 3's driver line by 3 % against the same process' 200-sweep figure.
+    if args.blocks is None:
+        args.blocks = 15 if N <= 100000 else 5
     for _ in range(args.warmup):
         sweep.sweep()
     barrier()
     dev.phase_totals(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sweep.sweep()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    block_s = []
+    for _ in range(max(1, args.blocks)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sweep.sweep()
+        barrier()
+        block_s.append(time.perf_counter() - t0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor(block_s, dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        block_s = [float(v) for v in t.cpu()]
+    elapsed = float(np.median(block_s))
 
     # ---- live per-kernel numbers (this rank's shard) ------------------------------------------------
     # (1) averages over the K timed sweeps, from in-kernel first-block-in / last-block-out stamps (100 MHz clock)
@@ -259,6 +320,10 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "blocks": {"count": len(block_s), "steps_per_block": args.steps, "reported": "median block",
+                   "ms_per_step_min": 1e3 * min(block_s) / args.steps, "ms_per_step_median": 1e3 * elapsed / args.steps,
+                   "ms_per_step_max": 1e3 * max(block_s) / args.steps,
+                   "iterations_per_s_over_all_blocks": len(block_s) * args.steps / sum(block_s)},
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -316,6 +381,15 @@ def main():
                       "local": tick_us(_lib.SGP_T_LOCAL), "gap_local_to_finish": tick_us(_lib.SGP_T_GAP_LOCAL_FINISH),
                       "finish1_lambda_chain": tick_us(_lib.SGP_T_FINISH1), "finish2_traces": tick_us(_lib.SGP_T_FINISH2)},
     }
+
+    # N > 1: the scaling regime of the design, measured in the same run (all ranks take part; after the headline's timed region)
+    if args.workload == "T" and (world > 1 or os.environ.get("SGP_BENCH_SCALING") is not None):
+        try:
+            out.setdefault("extra", {})["scaling_workload"] = scaling_leg(world, rank, local_rank, barrier)
+        except Exception as e:                                       # pragma: no cover
+            if world > 1:
+                raise                                                # (a rank that drops out of a collective would hang the others)
+            out.setdefault("extra", {})["scaling_workload"] = {"error": repr(e)}
 
     if rank == 0:
         # ---- parity of what was timed + CPU baseline (rank 0; the oracle is the checker, never the product) ----
@@ -408,9 +482,9 @@ def main():
                 out["parity"]["smse_kin40k_real"] = {"error": repr(e)}
             if N <= 100000:
                 try:
-                    out["extra"] = extras(args.workload)
+                    out.setdefault("extra", {}).update(extras(args.workload))
                 except Exception as e:                               # pragma: no cover
-                    out["extra"] = {"error": repr(e)}
+                    out.setdefault("extra", {})["error"] = repr(e)
         if ctx:
             ctx.__exit__(None, None, None)
         print(json.dumps(out))

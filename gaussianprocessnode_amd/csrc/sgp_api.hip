@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,40 @@ namespace {
 
 thread_local std::string g_create_error;
 std::atomic<int> g_live_handles{0};       // handles alive in this process (two sweeping at once cannot promise each other CUs)
+
+// Every live handle, so that none outlives the process' orderly exit: a handle that is still alive when exit() runs the static
+// destructors -- streams (one of them CU-masked), events, pinned blocks, possibly an all-reduce hook whose trampoline the host
+// language has already freed -- was seen to end a rocprofv3-profiled run in SIGSEGV inside __cxa_finalize (round 3:
+// tools/hooked_train.py).  The first sgp_create registers an atexit handler; it is registered AFTER the HIP runtime initialised
+// (sgp_create has just talked to it), so it runs BEFORE the runtime's own teardown and destroys what the caller left behind.
+// sgp_destroy on a handle that is no longer in the registry is a no-op (a finaliser that runs later still).
+std::mutex g_registry_mutex;
+std::vector<sgp_handle*>& registry() { static std::vector<sgp_handle*>* r = new std::vector<sgp_handle*>(); return *r; }   // (never destructed)
+bool g_atexit_registered = false;
+void destroy_live_handles_at_exit() {
+    std::vector<sgp_handle*> live;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        live = registry();
+    }
+    for (sgp_handle* h : live) sgp_destroy(h);
+}
+void register_handle(sgp_handle* h) {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    registry().push_back(h);
+    if (!g_atexit_registered) {
+        g_atexit_registered = true;
+        atexit(destroy_live_handles_at_exit);
+    }
+}
+bool unregister_handle(sgp_handle* h) {          // false: not (or no longer) a live handle
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    auto& r = registry();
+    auto it = std::find(r.begin(), r.end(), h);
+    if (it == r.end()) return false;
+    r.erase(it);
+    return true;
+}
 
 #ifdef SGP_WITH_PERSISTENT_CHAIN
 // The persistent factorisation launches need ALL their workgroups resident at once (they wait for each other).  Two handles
@@ -84,6 +119,8 @@ struct sgp_handle {
     int prior_form = 2;            // 1 dense precision, 2 isotropic
     bool swept_local = false, swept = false, stats_dirty = false;
     bool in_flight = false;        // a sweep may still be executing (its streams are non-blocking)
+    bool sync_reported = false;    // a getter has reported dInfo[3] (check_sync_status): the next sweep clears it
+    hipStream_t last_stream = nullptr;   // the stream the last sweep's tail was enqueued on (sgp_sweep_finish): what stream order covers
     uint64_t data_gen = 0, swept_data_gen = ~0ull;   // bumped by set_data / set_inducing; recorded by the sweep
     Params swept_params{};                            // kernel / noise parameters the last sweep ran with
     int n_ell = 1;
@@ -93,7 +130,7 @@ struct sgp_handle {
     double *dKuu = nullptr, *dWk = nullptr, *dKinv = nullptr;
     double *dLam = nullptr, *dWl = nullptr, *dSigma = nullptr, *dR = nullptr, *dXi = nullptr, *dMu = nullptr;
     double *dLambda0 = nullptr, *dXi0 = nullptr, *dOut = nullptr, *dWishart = nullptr, *dTrace = nullptr, *dTmp = nullptr;
-    double *dPa = nullptr, *dPb = nullptr, *dUvT = nullptr, *dScratch = nullptr, *dOut2 = nullptr, *dUvWork = nullptr;
+    double *dPa = nullptr, *dPb = nullptr, *dKmu = nullptr, *dUvT = nullptr, *dScratch = nullptr, *dOut2 = nullptr, *dUvWork = nullptr;
     double *dGradM = nullptr, *dGradPart = nullptr, *dGrad = nullptr;   // theta-gradient scratch (allocated on first use)
     double* dSaccK = nullptr;      // K_uu chain: Sigma-style accumulator of K_uu^-1 = W_K^T W_K (see sigma_row_tile)
     bool use_chain = false;        // (always false without SGP_WITH_PERSISTENT_CHAIN)
@@ -115,6 +152,7 @@ struct sgp_handle {
 #endif
     // environment switches (diagnostics / A-B), read once in sgp_create
     bool env_no_gate = false, env_join_event = false, env_grad_one_stream = false;
+    bool env_kuu_early = false;    // SGP_KUU_EARLY=1: K_uu's Gram in front of the gate (A/B switch; measured slower, see enqueue_kuu)
     int spin_limit = JOIN_SPIN_LIMIT;   // polls before a bounded device-word wait gives up (SGP_SPIN_LIMIT: tests shorten it)
     double* dCall = nullptr;       // scratch of the per-call outputs (sgp_predict, sgp_w_stats): grows, never shrinks
     size_t call_capacity = 0;
@@ -285,6 +323,7 @@ static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, doub
                          const double* tv_xi = nullptr, double* tv_t = nullptr) {
     LamForm none;
     memset(&none, 0, sizeof none);
+    none.trace_chain = form ? 1 : 0;
     // extra workgroups of launch j: (j >= 2) finish block row j - 1 of W, pre-accumulate block row j (not in the last,
     // potrf-free launch j = Tn), with Sacc add block row j - 2's contribution to Sigma = W^T W; (j >= 1, with tv_t) one
     // workgroup computes block j - 1 of the forward solve t = W (P xi)
@@ -390,6 +429,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         return fail(nullptr, SGP_ERR_NODEVICE, "sgp_create: device is not gfx950 (MI355X); this library is built for gfx950 only");
 
     sgp_handle* h = new sgp_handle();
+    register_handle(h);
     ++g_live_handles;
     h->cfg = *cfg;
     h->M = cfg->m; h->D = cfg->d; h->dout = cfg->d_out; h->n_max = cfg->n_max;
@@ -407,7 +447,9 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         h->num_cus = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
                          ? prop.multiProcessorCount : 256;
     }
-    h->slab_capacity = (size_t)(SYRK_BLOCKS_PER_CU * std::max(8, h->num_cus)) * TB * TB;      // one slab per workgroup of the round
+    // one slab per workgroup of the SYRK's single round -- and never fewer than one per lower tile (M > 2816: more tiles than slots,
+    // the point axis is then not split at all, syrk_geometry)
+    h->slab_capacity = (size_t)std::max(SYRK_BLOCKS_PER_CU * std::max(8, h->num_cus), h->ntiles) * TB * TB;
     const size_t nblk_max = (nmax + TB - 1) / TB;
 
 #define ALLOC(ptr, count)                                            \
@@ -465,6 +507,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         h->env_no_gate = getenv("SGP_NO_GATE") != nullptr;
         h->env_join_event = getenv("SGP_JOIN_EVENT") != nullptr;
         h->env_grad_one_stream = getenv("SGP_GRAD_ONE_STREAM") != nullptr;
+        if (const char* ke = getenv("SGP_KUU_EARLY")) h->env_kuu_early = atoi(ke) != 0;
         if (const char* lim = getenv("SGP_SPIN_LIMIT")) h->spin_limit = std::max(1, atoi(lim));
         if (const char* ov = getenv("SGP_OVERLAP")) h->env_overlap = atoi(ov);
         if (const char* g1 = getenv("SGP_G1_AFTER")) h->env_g1_mode = atoi(g1);
@@ -527,8 +570,10 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
     }
 #endif
     if (cfg->flags & SGP_FLAG_KEEP_KUF) {
-        ALLOC(h->dPa, (size_t)h->T * nmax);
-        ALLOC(h->dPb, (size_t)h->T * nmax);
+        // per-point partials of k_quadform_fused: [2 T] rows of each quadratic form, then [4] rows of k_n . mu (one allocation)
+        ALLOC(h->dPa, (4 * (size_t)h->T + 4) * nmax);
+        h->dPb = h->dPa + 2 * (size_t)h->T * nmax;
+        h->dKmu = h->dPb + 2 * (size_t)h->T * nmax;
     }
 #undef ALLOC
     h->dStats = h->dStatsOwn;
@@ -593,8 +638,18 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
 
 extern "C" int sgp_destroy(sgp_handle* h) {
     if (!h) return 0;
-    hipSetDevice(h->cfg.device);
-    hipDeviceSynchronize();
+    if (!unregister_handle(h)) return 0;       // destroyed already (by the exit handler, or twice by the caller)
+    // the hook's trampoline belongs to the host language: never call it again, whatever is still queued
+    h->allreduce = nullptr;
+    h->allreduce_ctx = nullptr;
+    if (hipSetDevice(h->cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        // the HIP runtime is already down (a finaliser that ran behind its teardown): its teardown released the device objects,
+        // all that is left to free is the host struct
+        (void)hipGetLastError();
+        --g_live_handles;
+        delete h;
+        return 0;
+    }
 #ifdef SGP_WITH_PERSISTENT_CHAIN
     if (g_chain_owner == h) g_chain_owner = nullptr;
 #endif
@@ -604,7 +659,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
     h->gKuu.reset();
     void* bufs[] = {h->dXu, h->dXus, h->dX, h->dYw, h->dY, h->dYv, h->dOmega, h->dKuf, h->dBpart, h->dSlabs, h->dStatsOwn,
                     h->dDataScal, h->dKuu, h->dWk, h->dKinv, h->dLam, h->dWl, h->dSigma, h->dR, h->dTmp, h->dLambda0,
-                    h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa, h->dPb,
+                    h->dXi, h->dMu, h->dXi0, h->dOut, h->dWishart, h->dTrace, h->dInfo, h->dStamps, h->dParams, h->dPa,
                     h->dUvT, h->dScratch, h->dParamsK, h->dXusK, h->dOut2, h->dStampTotals, h->dUvWork,
                     h->dGradM, h->dGradPart, h->dGrad, h->dCall, h->dSaccK,
                     h->dTrainX, h->dTrainY, h->dTrain, h->dTrainParams, h->dJoin, h->dPack, h->dBred};
@@ -972,10 +1027,20 @@ extern "C" int sgp_bind_stats(sgp_handle* h, void* stats_dev) {
 static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
     const bool words = h->dev_words && s == h->side;
+    // Where the gate sits (the chain's whole-CU workgroups stay off the chip until the SYRK's resident round is on it).  Default:
+    // inside k_prep_xu, in front of K_uu's Gram -- k_gram_uu then starts together with the SYRK, is starved beside it (35 us for a
+    // 512 x 512 matrix) and the chain's first step begins just as the SYRK drains.  SGP_KUU_EARLY=1 (round 4)
+    // puts k_gram_uu in front of the gate, at the start of the sweep beside k_gram_uf: the chain is then ready ~35 us earlier, its
+    // step 0 starts while group 0's SYRK is still running -- and that SYRK, which is on the sweep's critical path, takes 52
+    // instead of 40 us (its last workgroups share their CUs' issue slots and L2 with the chain's).  Same-box A/B at T,
+    // 2 x 1000 sweeps each: 4 312 / 4 317 sweeps/s with the gate first, 4 168 / 4 174 with the Gram first -- the starved Gram is
+    // what keeps the chain off the SYRK, so the default stays.
+    const bool gate = words && h->gate_side;
+    const bool gate_late = gate && h->env_kuu_early && !h->use_chain;
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->params_src,
                        h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0,
                        words ? (const long long*)(h->dJoin + WORD_DONE) : (const long long*)nullptr, h->done_epoch,
-                       (words && h->gate_side) ? (const long long*)(h->dJoin + WORD_GATE) : (const long long*)nullptr,
+                       (gate && !gate_late) ? (const long long*)(h->dJoin + WORD_GATE) : (const long long*)nullptr,
                        h->gate_epoch, h->spin_limit, h->dInfo + 3);
 #ifdef SGP_WITH_PERSISTENT_CHAIN
     if (h->use_chain) {
@@ -988,6 +1053,10 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
 #endif
     {
         hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
+        // (scheduling only: giving up here costs time, not correctness, so no status bit)
+        if (gate_late)
+            hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, s, (const long long*)(h->dJoin + WORD_GATE), h->gate_epoch, h->spin_limit,
+                               (int*)nullptr, 0, 9);
         launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk, nullptr, h->dSaccK);
     }
     launch_ata(h->dWk, h->dKinv, Mp, T, s, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->dSaccK);
@@ -1062,7 +1131,7 @@ static void enqueue_stats_overlapped(sgp_handle* h, hipStream_t own) {
     const int g1_mode = h->env_g1_mode;
     const long long* g1_word = h->dJoin + (g1_mode == 0 ? WORD_GATE : (g1_mode == 1 ? WORD_GROUP0 : WORD_ASM0));
     hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, h->statM, g1_word, g1_mode == 0 ? h->gate_epoch : h->stat_epoch,
-                       h->spin_limit, h->dInfo + 3, (int)SYNC_LATE_COLUMN);
+                       h->spin_limit, h->dInfo + 3, (int)SYNC_LATE_COLUMN, 8);
     for (int g = 0; g < h->ngroups; ++g) {
         const StatGroup& G = h->grp[g];
         hipStream_t s = G.masked ? h->statM : own;
@@ -1091,6 +1160,7 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     form.stamps = h->dStamps + STAMP_STRIDE * SGP_T_FINISH1;
     form.spin_limit = h->spin_limit;
     form.sync_status = h->dInfo + 3;
+    form.trace_chain = 1;
     if (h->overlap_now) {
         // the statistics arrive group by group while the chain runs (enqueue_stats_overlapped): step G.form_step forms group G.
         // Group 0 was summed on this very stream: nothing to wait for.  (A step 0 resident from the start of the sweep and
@@ -1229,6 +1299,11 @@ static int sweep_local_impl(sgp_handle* h, void* stream, bool overlapped) {
         g_chain_owner = h;
     }
 #endif
+    if (h->sync_reported) {
+        // (the getter that reported the word had drained the device: nothing is in flight)
+        HIPCHK(h, hipMemset(h->dInfo + 3, 0, sizeof(int)));
+        h->sync_reported = false;
+    }
     h->in_flight = true;
     h->overlap_now = overlapped;
     // The K_uu chain depends on theta and Xu only: it starts on the (low-priority) side stream as soon as the previous
@@ -1241,7 +1316,9 @@ static int sweep_local_impl(sgp_handle* h, void* stream, bool overlapped) {
     const bool graph = (h->cfg.flags & SGP_FLAG_GRAPH) != 0;
     const bool hooked = h->allreduce != nullptr && !overlapped;
     h->dev_words = !graph;
-    h->use_events = graph || hooked;
+    // (a caller's stream as well: two-phase callers -- sgp_sweep_local, their own reduce, sgp_sweep_finish -- may sit in a collective
+    // between the halves for longer than the bounded words wait, exactly like the hook)
+    h->use_events = graph || hooked || s != h->own;
     if (h->use_events) HIPCHK(h, hipStreamWaitEvent(h->side, h->evDone, 0));
     // How F2 will join the K_uu chain: an event wait between two kernels of the main stream costs it ~5 us of idle time even
     // when the event fired long ago, so the UniSGP path lets the Sigma launch's product workgroups poll a device word in
@@ -1296,6 +1373,7 @@ extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
     if (h->use_events) HIPCHK(h, hipEventRecord(h->evDone, s));
     h->overlap_now = false;
     h->swept = true;
+    h->last_stream = s;
     return 0;
 }
 
@@ -1440,13 +1518,13 @@ static int sync_all(sgp_handle* h) {
 }
 
 // A bounded wait on a device word gave up somewhere since the last check (dInfo[3], see SYNC_LATE_* in sgp_kernels.hip.h): what
-// the wait protected -- the buffers the two streams hand each other -- cannot be trusted, so the results are refused.  The
-// word is cleared: the next sweep starts clean.  Call after a device synchronisation.
+// the wait protected -- the buffers the two streams hand each other -- cannot be trusted, so the results are refused by EVERY
+// getter, until the next sweep is enqueued (sweep_local_impl clears the word then).  Call after a device synchronisation.
 static int check_sync_status(sgp_handle* h) {
     int bits = 0;
     HIPCHK(h, hipMemcpy(&bits, h->dInfo + 3, sizeof(int), hipMemcpyDeviceToHost));
     if (bits == 0) return 0;
-    HIPCHK(h, hipMemset(h->dInfo + 3, 0, sizeof(int)));
+    h->sync_reported = true;                 // (sticky: every getter refuses until the next sweep is enqueued, which clears the word)
     std::string msg = "a bounded device-word wait gave up (stream hand-off not honoured; results refused):";
     if (bits & SYNC_LATE_DONE) msg += " [done word: the next sweep's first kernels started before the previous sweep had finished]";
     if (bits & SYNC_LATE_GRAD_START) msg += " [done word: the K_uu half of the theta gradient started before the sweep had finished]";
@@ -1533,6 +1611,7 @@ extern "C" int sgp_get_stats(sgp_handle* h, double* Psi2, double* B, double* sca
     if (!h->swept_local) return fail(h, SGP_ERR_ARG, "sgp_get_stats: no sweep yet");
     int rc = sync_all(h);
     if (rc) return rc;
+    if (int src = check_sync_status(h)) return src;
     const int M = h->M, Mp = h->Mp;
     if (Psi2) { rc = download_square(h, h->dStats, Mp, M, Psi2); if (rc) return rc; }
     if (B)
@@ -1549,6 +1628,7 @@ extern "C" int sgp_get_kuu_chol(sgp_handle* h, double* KuuL) {
     if (!h->swept) return fail(h, SGP_ERR_ARG, "sgp_get_kuu_chol: no finished sweep");
     int rc = sync_all(h);
     if (rc) return rc;
+    if (int src = check_sync_status(h)) return src;
     rc = download_square(h, h->dKuu, h->Mp, h->M, KuuL);
     if (rc) return rc;
     for (int j = 0; j < h->M; ++j)
@@ -1562,6 +1642,7 @@ extern "C" int sgp_get_wishart_invscale(sgp_handle* h, double* S) {
     if (h->dout == 1) return fail(h, SGP_ERR_ARG, "sgp_get_wishart_invscale: d_out = 1 (use sgp_get_scalars)");
     int rc = sync_all(h);
     if (rc) return rc;
+    if (int src = check_sync_status(h)) return src;
     std::vector<double> tmp(MAXO * MAXO);
     HIPCHK(h, hipMemcpy(tmp.data(), h->dWishart, sizeof(double) * MAXO * MAXO, hipMemcpyDeviceToHost));
     for (int i = 0; i < h->dout * h->dout; ++i) S[i] = tmp[i];
@@ -1634,8 +1715,8 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
         G = &h->grp[which - SGP_TIME_GROUP0];
         s = G->masked ? h->statM : h->own;
     }
-    // which = SGP_TIME_QUADFORM + mode: k_quadform_cols of sgp_w_stats (mode 0: |L^-1 k_n|^2 with W_K, mode 1: |Uv k_n|^2)
-    const int qmode = (which == SGP_TIME_QUADFORM || which == SGP_TIME_QUADFORM + 1) ? which - SGP_TIME_QUADFORM : -1;
+    // which = SGP_TIME_QUADFORM: k_quadform_fused of sgp_w_stats (|L^-1 k_n|^2 with W_K and |Uv k_n|^2 in one launch)
+    const int qmode = (which == SGP_TIME_QUADFORM) ? 0 : -1;
     if (qmode >= 0 && (!(h->cfg.flags & SGP_FLAG_KEEP_KUF) || !h->swept))
         return fail(h, SGP_ERR_ARG, "sgp_time_kernel: the per-point kernels need SGP_FLAG_KEEP_KUF and a finished sweep");
     EventPair ev;
@@ -1643,8 +1724,8 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
     hipEvent_t e0 = ev.a, e1 = ev.b;
     auto launch = [&]() {
         if (qmode >= 0)
-            hipLaunchKernelGGL(k_quadform_cols, dim3(h->nblk, h->T), dim3(256), 0, s, qmode == 0 ? h->dWk : h->dUvT, h->dKuf,
-                               qmode == 0 ? h->dPa : h->dPb, h->Mp, h->T, h->n, qmode);
+            hipLaunchKernelGGL(k_quadform_fused, dim3(h->nblk, h->T), dim3(256), 0, s, h->dWk, h->dUvT, h->dKuf, h->dMu, h->dPa, h->dPb,
+                               h->dKmu, h->Mp, h->T, h->n);
         else if (G)
             hipLaunchKernelGGL(k_syrk_stream, dim3((unsigned)syrk_items(G->geom)), dim3(256), 0, s, h->dKuf, h->has_omega ? h->dOmega : nullptr,
                                h->dSlabs + G->slab_off, h->Mp, h->n, G->geom, (int64_t*)nullptr, (long long*)nullptr, 0LL);
@@ -1702,21 +1783,33 @@ extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) 
     const int64_t n = h->n;
     if (n == 0) return 0;
     double *dI1 = nullptr, *dI2 = nullptr;
-    // Ordered after the sweep by the stream when that is the sweep's own (the usual case: no device-wide wait in front of the
-    // three launches); a caller's stream is not ordered against the library's, so then the device is drained first.  The
-    // scratch grows only here and in sgp_predict, both blocking: a reallocation never races with a queued launch.
-    if (s != h->own || 2 * (size_t)n > h->call_capacity) HIPCHK(h, hipDeviceSynchronize());
+    // Ordered after the sweep by the stream when that is the stream the sweep's tail was enqueued on (the usual case: both the
+    // library's own -- no device-wide wait in front of the launches); any other pairing -- the sweep on a caller's stream and this
+    // call on the library's, or the reverse -- is not ordered by anything, so then the device is drained first.  The scratch
+    // grows only here and in sgp_predict, both blocking: a reallocation never races with a queued launch.
+    if (s != h->last_stream || 2 * (size_t)n > h->call_capacity) HIPCHK(h, hipDeviceSynchronize());
     if (int crc = call_scratch(h, 2 * (size_t)n, &dI1)) return crc;
     dI2 = dI1 + n;
-    // |L^-1 k_n|^2 with the explicit inverse factor W_k, |Uv k_n|^2 = |L_R^T k_n|^2
-    hipLaunchKernelGGL(k_quadform_cols, dim3(h->nblk, h->T), dim3(256), 0, s, h->dWk, h->dKuf, h->dPa, h->Mp, h->T, n, 0);
-    hipLaunchKernelGGL(k_quadform_cols, dim3(h->nblk, h->T), dim3(256), 0, s, h->dUvT, h->dKuf, h->dPb, h->Mp, h->T, n, 1);
-    hipLaunchKernelGGL(k_w_point_finish, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, h->dPa, h->dPb, h->dKuf, h->dMu,
-                       h->dY, h->has_yv ? h->dYv : nullptr, dI1, dI2, h->dParams, h->M, h->Mp, h->T, n);
+    // |L^-1 k_n|^2 with the explicit inverse factor W_k, |Uv k_n|^2 = |L_R^T k_n|^2 and k_n . mu: ONE pass over the resident K_uf
+    // (k_quadform_fused), then the fixed-order sums
+    hipLaunchKernelGGL(k_quadform_fused, dim3(h->nblk, h->T), dim3(256), 0, s, h->dWk, h->dUvT, h->dKuf, h->dMu, h->dPa, h->dPb, h->dKmu,
+                       h->Mp, h->T, n);
+    hipLaunchKernelGGL(k_w_point_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dPa, h->dPb, h->dKmu, h->dY,
+                       h->has_yv ? h->dYv : nullptr, dI1, dI2, h->dParams, h->T, n);
+    // both vectors come back in one copy through the pinned staging block when they fit (two blocking copies into pageable memory
+    // were ~60 us of a 280 us call at n = 10 000)
+    const bool staged = h->hStage && 2 * (size_t)n <= h->stage_doubles;
+    if (staged) HIPCHK(h, hipMemcpyAsync(h->hStage, dI1, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
-    if (I1) HIPCHK(h, hipMemcpy(I1, dI1, sizeof(double) * n, hipMemcpyDeviceToHost));
-    if (I2) HIPCHK(h, hipMemcpy(I2, dI2, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (int src = check_sync_status(h)) return src;          // (the sweep whose q(v) these are: a hand-off that gave up voids them too)
+    if (staged) {
+        if (I1) memcpy(I1, h->hStage, sizeof(double) * n);
+        if (I2) memcpy(I2, h->hStage + n, sizeof(double) * n);
+    } else {
+        if (I1) HIPCHK(h, hipMemcpy(I1, dI1, sizeof(double) * n, hipMemcpyDeviceToHost));
+        if (I2) HIPCHK(h, hipMemcpy(I2, dI2, sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 
@@ -1811,7 +1904,7 @@ static int enqueue_theta_grad(sgp_handle* h, hipStream_t s) {
     hipStream_t su = split ? h->side : s;
     if (split)
         hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, su, (const long long*)(h->dJoin + WORD_DONE), h->done_epoch,
-                           h->spin_limit, h->dInfo + 3, (int)SYNC_LATE_GRAD_START);
+                           h->spin_limit, h->dInfo + 3, (int)SYNC_LATE_GRAD_START, 8);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, su, (const double*)h->dKinv, (const double*)h->dStats, dT1,
                        Mp, T, 3, 0, 0, (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, UvArgs{}, (const double*)nullptr);
     hipLaunchKernelGGL(k_gemm32, dim3(T * T * 4), dim3(256), 0, su, (const double*)dT1, (const double*)h->dKinv, dH, Mp, T,
@@ -1876,6 +1969,7 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipDeviceSynchronize());
     h->in_flight = false;
+    if (int src = check_sync_status(h)) return src;
     hipStream_t s = h->own;
     // Same theta, data and noise as the sweep that produced q(v) -- the notebooks' call pattern
     // (experiments/regression_kin40k.ipynb:205-221 evaluates the gradient at the theta the sweep just used): K_uf, Psi2, b,
@@ -1957,7 +2051,7 @@ extern "C" int sgp_train_begin(sgp_handle* h, const double* X, const double* y, 
     HIPCHK(h, hipMemcpy(h->dTrainParams, h->hParams, sizeof(Params), hipMemcpyHostToDevice));
     h->n_ell = n_ell;
     hipLaunchKernelGGL(k_train_adamax, dim3(1), dim3(64), 0, h->own, h->dTrain, (const double*)nullptr, (const double*)nullptr,
-                       h->dTrainParams, h->D, n_ell, 0, (const int*)nullptr, (const Params*)nullptr, 0.0);
+                       h->dTrainParams, h->D, n_ell, 0, (const int*)nullptr, (const Params*)nullptr, (const double*)nullptr);
     HIPCHK(h, hipStreamSynchronize(h->own));
     h->params_src = h->dTrainParams;
     h->have_kernel = true;
@@ -2064,7 +2158,7 @@ extern "C" int sgp_train_step(sgp_handle* h, int64_t offset, int64_t n, int32_t 
         if (!rc)
             hipLaunchKernelGGL(k_train_adamax, dim3(1), dim3(64), 0, s, h->dTrain, (const double*)h->dGrad, (const double*)h->dOut,
                                h->dTrainParams, h->D, h->n_ell, learn ? 1 : 2, (const int*)(h->dInfo + 3), (const Params*)h->dParams,
-                               (double)n);
+                               (const double*)(h->dStats + (size_t)h->Mp * h->Mp + (size_t)h->Mp * h->dout + SGP_S_N));
         // the next K_uu chain (side stream) reads the parameters this step wrote and overwrites the K_uu^-1 its gradient read
         if (!rc) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_DONE, ++h->done_epoch);
         if (!rc && h->use_events) HIPCHK(h, hipEventRecord(h->evDone, s));   // (hooked run: the next K_uu chain waits on this, see sweep_local_impl)

@@ -1241,6 +1241,7 @@ struct LamForm {
     unsigned char form_step[LAM_MAX_COLS], col_group[LAM_MAX_COLS];      // col_group 0xff: in stream order, nothing to wait for
     int spin_limit;
     int* sync_status;
+    int trace_chain;            // diagnostics (SGP_SWEEP_TRACE): 1 = this launch belongs to the Lambda chain (its slots), 0 = K_uu chain
 };
 // Straight-line on purpose, with the two uniform choices (dense prior? several outputs?) made OUTSIDE the 16-entry loop:
 // any branch inside it splits the loop body into basic blocks, the compiler then waits for each load before the next is
@@ -1634,7 +1635,7 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     __shared__ __attribute__((aligned(16))) double tiles[2 * TB * LT];
     __shared__ double dprep[4 * DPB];                     // the diagonal tile's 16 x 16 blocks as solve16 reads them
     __shared__ double rinv[TB];
-    TraceScope trace((form.stats ? 16 : 40) + j);
+    TraceScope trace((form.trace_chain ? 16 : 40) + j);
     const bool xgroup = threadIdx.x >= 256;               // the solve group
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     {
@@ -1788,15 +1789,17 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
                 load_panel_n(P1, A, ld, k0, p0, TB, tid);         // L_{j, j-1}
             }
             tile_r2s(X, rX);
-            if (tw > 0 && tid == 0)                           // (rX has arrived: it was just stored to LDS)
-                __hip_atomic_fetch_add((__attribute__((address_space(1))) long long*)(tw_words + (j & 1)), 1LL, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
         } else {
             for (int e = tid; e < TB * LT; e += 256) X[e] = (e / LT == e % LT) ? 1.0 : 0.0;
         }
         STEP_TRACE(1);
         __syncthreads();
         STEP_TRACE(2);
+        // a twin counts itself in BEHIND the barrier: only then has EVERY wave's share of tile (j + 1, j) arrived in LDS (a wave
+        // stores its registers as soon as its own loads are back; the owner overwrites the tile once the count is complete)
+        if (below && tw > 0 && tid == 0)
+            __hip_atomic_fetch_add((__attribute__((address_space(1))) long long*)(tw_words + (j & 1)), 1LL, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         // The diagonal block moves the previous step's L tile into place BEHIND its first barrier: the copy's loads miss every
         // cache, and in front of the barrier the factoring group waited 1 - 2 us for a tile nobody reads during this launch
         // (the step trace showed exactly that).  `scratch` is overwritten only after the factorisation, eight barriers on.
@@ -1925,8 +1928,8 @@ struct UvArgs {
     int spin_limit;          // polls before a late join gives up (its trace shares become NaN and SYNC_LATE_KINV is set)
     int* sync_status;
 };
-__global__ void k_join_wait(const long long* w, long long need, int spin_limit, int* sync_status, int bit) {
-    TraceScope trace(8);
+__global__ void k_join_wait(const long long* w, long long need, int spin_limit, int* sync_status, int bit, int trace_slot) {
+    TraceScope trace(trace_slot);
     if (threadIdx.x == 0 && blockIdx.x == 0) spin_until(w, need, spin_limit, sync_status, bit);
 }
 __global__ void k_join_set(long long* w, long long v) {
@@ -2472,13 +2475,8 @@ __global__ void __launch_bounds__(256) k_kernelmatrix(const double* __restrict__
 //   replaced by its transpose product, |Uv k_n|^2 = k_n^T R k_n = |L_R^T k_n|^2.
 // Tile: 64 rows of F K x 64 points per block, K loop over block columns of F; squared column sums are
 // reduced over the row-blocks by atomics-free two-pass (partial[rowblk][n]).
-//   mode 0: F used as stored (lower, rows i, sum over k <= i);  mode 1: F^T (upper), sum over k >= i.
+//   first factor used as stored (lower, rows i, sum over k <= i);  second factor transposed (upper), sum over k >= i.
 // ------------------------------------------------------------------------------------------------
-// Software-pipelined: the next tile pair is fetched into registers while the matrix cores work on the current one (one LDS
-// buffer, two barriers per tile); the triangular mask of the diagonal tile is applied in registers on the way into LDS; both
-// panels are stored transposed-with-XOR (see tile_mma_bswz) where the global reads run along k.  80 KB of LDS: two workgroups
-// per CU (the column sums reuse the panels' memory).  Round 3: 127 / 143 us per launch at T (one workgroup per CU, loads and
-// MFMAs back to back) -> see DESIGN.md section 6.
 template <bool ASWZ>
 __device__ __forceinline__ void tile_mma_swz(Acc4& acc, const double* As, const double* Bs, int kcount, int lane, int wr, int wc) {
     const int li = lane & 15, lk = lane >> 4;
@@ -2499,9 +2497,24 @@ __device__ __forceinline__ void tile_mma_swz(Acc4& acc, const double* As, const 
     }
 }
 
-template <int MODE>
-__device__ __forceinline__ void quadform_body(const double* __restrict__ F, const double* __restrict__ Kuf, double* __restrict__ partial,
-                                              int ld, int T, int64_t N, double* lds) {
+// ONE launch for both quadratic forms (round 4; round 3 launched the body once per factor and a third kernel re-read K_uf for
+// k_n . mu): workgroup (point block nb, row tile I) walks T + 1 tile products --
+//     steps 0 .. I   :  rows I of  W_K K_uf   (W_K = L_K^-1, lower: tile columns k <= I)        -> a = sum of squares down the column
+//     steps I .. T-1 :  rows I of  Uv  K_uf   (Uv upper = LR^T: tile columns k >= I)            -> b
+// so every workgroup carries the same work (the per-factor launches had 1 .. T products per workgroup), the K_uf tile of
+// k = I is staged once for both factors, and the accumulator is reused: at the switch the column sums of squares of the first
+// factor leave as two partial rows (one per wave row, summed in fixed order by k_w_point_finish -- no LDS beyond the panels, so
+// that two workgroups share a CU, and no atomics).  The workgroup with I == nb mod T also forms k_n . mu from the K_uf tiles it
+// stages anyway (four partial rows, one per wave).
+// Software-pipelined as before: the next tile pair is fetched into registers while the matrix cores work on the current one;
+// the triangular mask of the diagonal tile is applied in registers on the way into LDS; panels whose global reads run along k
+// are stored transposed-with-XOR (tile_mma_bswz).
+//   pa, pb : [2 T][N] partial column sums (row 2 I + wr),  kmu : [4][N]
+__global__ void __launch_bounds__(256, 2) k_quadform_fused(const double* __restrict__ Wk, const double* __restrict__ LR,
+                                                        const double* __restrict__ Kuf, const double* __restrict__ mu,
+                                                        double* __restrict__ pa, double* __restrict__ pb, double* __restrict__ kmu,
+                                                        int ld, int T, int64_t N) {
+    __shared__ double lds[2 * TB * PS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int I = blockIdx.y;
     const int64_t n0 = (int64_t)blockIdx.x * TB;
@@ -2509,111 +2522,136 @@ __device__ __forceinline__ void quadform_body(const double* __restrict__ F, cons
     double* Bs = lds + TB * PS;
     Acc4 acc;
     acc_zero(acc);
-    const int kbeg = (MODE == 0) ? 0 : I, kend = (MODE == 0) ? I + 1 : T;
-    // staging maps, 4 passes of 256 threads each.  A, mode 0 (F as stored: contiguous along i): thread -> (kk = t >> 4, rows 4 (t & 15) ..);
-    // A, mode 1 (F^T: contiguous along kk) and B (K_uf columns: contiguous along kk): thread -> (i or j = t >> 4, kk = 4 (t & 15) ..)
+    // staging maps, 4 passes of 256 threads each.  A of the first factor (W_K as stored: contiguous along i): thread -> (kk = t >> 4,
+    // rows 4 (t & 15) ..); A of the second (LR^T: contiguous along kk) and B (K_uf columns: contiguous along kk): thread ->
+    // (i or j = t >> 4, kk = 4 (t & 15) ..)
     double2 ra[4][2], rb[4][2];
-    auto gload = [&](int k) {
+    // (ONE copy of the loads, the LDS stores and the MFMA loop for both factors, the factor a run-time flag: with a copy per
+    // factor the kernel needed 260 registers -- one workgroup per CU instead of two)
+    auto gload_a = [&](int second, int k) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int t = tid + 256 * u, hi = t >> 4, lo4 = (t & 15) * 4;
-            const double* sa = (MODE == 0) ? F + (size_t)(k * TB + hi) * ld + I * TB + lo4        // F[I*64 + lo4 .., k*64 + hi]
-                                           : F + (size_t)(I * TB + hi) * ld + k * TB + lo4;       // F[k*64 + lo4 .., I*64 + hi]
+            const double* sa = second ? LR + (size_t)(I * TB + hi) * ld + k * TB + lo4      // LR[k*64 + lo4 .., I*64 + hi]
+                                      : Wk + (size_t)(k * TB + hi) * ld + I * TB + lo4;     // W_K[I*64 + lo4 .., k*64 + hi]
             ra[u][0] = *reinterpret_cast<const double2*>(sa);
             ra[u][1] = *reinterpret_cast<const double2*>(sa + 2);
-            const int64_t n = n0 + hi;
-            if (n < N) {
-                const double* sb = Kuf + (size_t)n * ld + k * TB + lo4;
-                rb[u][0] = *reinterpret_cast<const double2*>(sb);
-                rb[u][1] = *reinterpret_cast<const double2*>(sb + 2);
-            } else {
-                rb[u][0] = make_double2(0.0, 0.0);
-                rb[u][1] = make_double2(0.0, 0.0);
-            }
         }
     };
-    auto lstore = [&](int k) {
-        const bool dg = (k == I);                     // the diagonal tile of the triangular factor: zero its other half
+    auto gload_b = [&](int k) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + 256 * u, hi = t >> 4, lo4 = (t & 15) * 4;
+            const int64_t n = n0 + hi;
+            const double* sb = Kuf + (size_t)(n < N ? n : N - 1) * ld + k * TB + lo4;     // (clamped: the surplus is zeroed below)
+            rb[u][0] = *reinterpret_cast<const double2*>(sb);
+            rb[u][1] = *reinterpret_cast<const double2*>(sb + 2);
+            if (n >= N) { rb[u][0] = make_double2(0.0, 0.0); rb[u][1] = make_double2(0.0, 0.0); }
+        }
+    };
+    // first factor: As[kk = hi][i = lo4 + q] (lower: kk <= i); second: As[kk = lo4 + q][i = hi, XOR-swizzled] (i <= kk) -- in both
+    // the entries to drop from the DIAGONAL tile are those with lo4 + q < hi
+    auto lstore_a = [&](int second, bool dg) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int t = tid + 256 * u, hi = t >> 4, lo4 = (t & 15) * 4;
             const double va[4] = {ra[u][0].x, ra[u][0].y, ra[u][1].x, ra[u][1].y};
-            const double vb[4] = {rb[u][0].x, rb[u][0].y, rb[u][1].x, rb[u][1].y};
+            double* dst = second ? As + lo4 * PS + (hi ^ (lo4 & 60)) : As + hi * PS + lo4;
+            const int step = second ? PS : 1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (MODE == 0) {
-                    const int kk = hi, i = lo4 + q;                              // As[kk][i] = F[I*64 + i, k*64 + kk], lower: kk <= i
-                    As[kk * PS + i] = (dg && kk > i) ? 0.0 : va[q];
-                } else {
-                    const int i = hi, kk = lo4 + q;                              // As[kk][i] = F[k*64 + kk, I*64 + i], lower: i <= kk
-                    As[kk * PS + (i ^ (lo4 & 60))] = (dg && kk < i) ? 0.0 : va[q];
-                }
-                Bs[(lo4 + q) * PS + (hi ^ (lo4 & 60))] = vb[q];                 // Bs[kk][j] = Kuf[k*64 + kk, n0 + j]
-            }
+            for (int q = 0; q < 4; ++q) dst[q * step] = (dg && lo4 + q < hi) ? 0.0 : va[q];
         }
     };
-    gload(kbeg);
-    for (int k = kbeg; k < kend; ++k) {
+    auto lstore_b = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + 256 * u, j = t >> 4, lo4 = (t & 15) * 4;
+            const double vb[4] = {rb[u][0].x, rb[u][0].y, rb[u][1].x, rb[u][1].y};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Bs[(lo4 + q) * PS + (j ^ (lo4 & 60))] = vb[q];                    // Bs[kk][j] = Kuf[k*64 + kk, n0 + j]
+        }
+    };
+    // k_n . mu from the staged K_uf tile: thread -> (point j = tid & 63, sixteen rows of the tile per wave)
+    const bool kmu_duty = (I == (int)(blockIdx.x % (unsigned)T));
+    double kacc = 0.0;
+    // column sums of squares over the wave's 32 rows -> partial row 2 I + wr
+    auto colsums_out = [&](double* __restrict__ part) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            double cs = 0.0;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs = fma(acc.t[ti][tj][r], acc.t[ti][tj][r], cs);
+            cs += __shfl_xor(cs, 16);
+            cs += __shfl_xor(cs, 32);
+            const int64_t n = n0 + wc * 32 + tj * 16 + lane;
+            if (lane < 16 && n < N) part[(size_t)(2 * I + wr) * N + n] = cs;
+        }
+    };
+    gload_a(0, 0);
+    gload_b(0);
+    const int li = lane & 15, lk = lane >> 4;
+    const int r0 = wr * 32 + li, r1 = r0 + 16, c0 = wc * 32 + li, c1 = c0 + 16;
+#pragma unroll 1
+    for (int s = 0; s <= T; ++s) {                    // steps 0 .. I: first factor, tile column k = s; I + 1 .. T: second, k = s - 1
+        const int second = s > I ? 1 : 0, k = s - second;
         __syncthreads();                              // the previous tile pair has been consumed
-        lstore(k);
+        if (s == I + 1) {                             // the switch: the first factor's column sums leave, the accumulator starts over
+            colsums_out(pa);
+            acc_zero(acc);
+        }
+        lstore_a(second, k == I);
+        if (s != I + 1) lstore_b();                   // (the second factor starts on the K_uf tile that is already staged)
         __syncthreads();
-        if (k + 1 < kend) gload(k + 1);               // in flight while the matrix cores run
-        tile_mma_swz<MODE == 1>(acc, As, Bs, TB, lane, wr, wc);
+        if (s < T) {                                  // the next step's tiles: in flight while the matrix cores run
+            const int sn = s + 1, secn = sn > I ? 1 : 0, kn = sn - secn;
+            gload_a(secn, kn);
+            if (sn != I + 1) gload_b(kn);
+        }
+        if (kmu_duty && s != I + 1) {
+            const int j = tid & 63;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int kk = 16 * wave + q;
+                kacc = fma(Bs[kk * PS + (j ^ (kk & 60))], mu[k * TB + kk], kacc);
+            }
+        }
+        const double* ap = As + lk * PS;
+        const double* bp = Bs + lk * PS;
+#pragma unroll 4
+        for (int kk = 0; kk < TB; kk += 4) {
+            const int x = kk & 60, xa = second ? x : 0;
+            const double a0 = ap[r0 ^ xa], a1 = ap[r1 ^ xa];
+            const double b0 = bp[c0 ^ x], b1 = bp[c1 ^ x];
+            acc.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.t[0][0], 0, 0, 0);
+            acc.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.t[0][1], 0, 0, 0);
+            acc.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.t[1][0], 0, 0, 0);
+            acc.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.t[1][1], 0, 0, 0);
+            ap += 4 * PS;
+            bp += 4 * PS;
+        }
     }
-    // column sums of squares over this block's 64 rows
-    double cs[2] = {0.0, 0.0};
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cs[tj] = fma(acc.t[ti][tj][r], acc.t[ti][tj][r], cs[tj]);
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        cs[tj] += __shfl_xor(cs[tj], 16);
-        cs[tj] += __shfl_xor(cs[tj], 32);
-    }
-    __syncthreads();
-    double* colsum = lds;                             // [4][TB], reusing the panels
-    if (lane < 16) {
-        colsum[wave * TB + (wc * 32) + lane] = cs[0];        // waves (wr,wc): rows wr*32.., cols wc*32..
-        colsum[wave * TB + (wc * 32) + 16 + lane] = cs[1];
-    }
-    __syncthreads();
-    if (tid < TB) {
-        int wcol = tid >> 5;                               // which wc owns this column
-        double s = colsum[(0 * 2 + wcol) * TB + tid] + colsum[(1 * 2 + wcol) * TB + tid];
-        int64_t n = n0 + tid;
-        if (n < N) partial[(size_t)I * N + n] = s;
+    colsums_out(pb);
+    if (kmu_duty) {
+        const int64_t n = n0 + (tid & 63);
+        if (n < N) kmu[(size_t)wave * N + n] = kacc;
     }
 }
 
-__global__ void __launch_bounds__(256) k_quadform_cols(const double* __restrict__ F, const double* __restrict__ Kuf,
-                                                       double* __restrict__ partial, int ld, int T, int64_t N, int mode) {
-    __shared__ double lds[2 * TB * PS];
-    if (mode == 0) quadform_body<0>(F, Kuf, partial, ld, T, N, lds);
-    else quadform_body<1>(F, Kuf, partial, ld, T, N, lds);
-}
-
-// I1_n = sigma2 - sum_I pa[I][n] ;  I2_n = y^2 + v - 2 y (k_n . mu) + sum_I pb[I][n]
+// I1_n = sigma2 - sum_r pa[r][n] ;  I2_n = y^2 + v - 2 y (k_n . mu) + sum_r pb[r][n]      (fixed summation order)
 __global__ void __launch_bounds__(256) k_w_point_finish(const double* __restrict__ pa, const double* __restrict__ pb,
-                                                        const double* __restrict__ Kuf, const double* __restrict__ mu,
-                                                        const double* __restrict__ y, const double* __restrict__ yv,
-                                                        double* __restrict__ I1, double* __restrict__ I2,
-                                                        const Params* __restrict__ P, int M, int Mp, int T, int64_t N) {
-    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+                                                        const double* __restrict__ kmu, const double* __restrict__ y,
+                                                        const double* __restrict__ yv, double* __restrict__ I1,
+                                                        double* __restrict__ I2, const Params* __restrict__ P, int T, int64_t N) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
-    double kmu = 0.0;
-    for (int m = lane; m < M; m += 64) kmu = fma(Kuf[(size_t)n * Mp + m], mu[m], kmu);
-    for (int o = 32; o > 0; o >>= 1) kmu += __shfl_xor(kmu, o);
-    if (lane == 0) {
-        double a = 0.0, b = 0.0;
-        for (int I = 0; I < T; ++I) { a += pa[(size_t)I * N + n]; b += pb[(size_t)I * N + n]; }
-        double yy = y[n], v = yv ? yv[n] : 0.0;
-        if (I1) I1[n] = P->sigma2 - a;
-        if (I2) I2[n] = yy * yy + v - 2.0 * yy * kmu + b;
-    }
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < 2 * T; ++r) { a += pa[(size_t)r * N + n]; b += pb[(size_t)r * N + n]; }
+    const double km = (kmu[n] + kmu[(size_t)N + n]) + (kmu[(size_t)2 * N + n] + kmu[(size_t)3 * N + n]);
+    const double yy = y[n], v = yv ? yv[n] : 0.0;
+    I1[n] = P->sigma2 - a;
+    I2[n] = yy * yy + v - 2.0 * yy * km + b;
 }
 
 // transpose-copy of a square column-major matrix (Uv = L_R^T on the way out)
@@ -2959,20 +2997,23 @@ __global__ void __launch_bounds__(256) k_probit_window(const double* __restrict_
 // `update`: 1 = optimiser step (skipped and counted if a factorisation of this minibatch failed or a device-word wait gave up),
 // 2 = status only (a minibatch without a learning step: a failure is still counted), 0 = only write the parameters (first step
 // of a run).
-// Probit runs (st->kind = 1) first update q(w) = Gamma(a + n / 2, b + (sum I1 + sum I2) / 2) from the sweep's scalars
+// Probit runs (st->kind = 1) first update q(w) = Gamma(a + n / 2, b + (sum I1 + sum I2) / 2) from the sweep's scalars and n = the
+// statistics' node count (`n_window` points at it; nullptr when update = 0)
 // (GPnode/UniSGPnode.jl:219-238 summed over the window); the gradient was formed at the sweep's mean(q_w) and the objective is
 // linear in it, so it is rescaled to the NEW mean (`grad_llh_new!(...; w = mean(qw))`, classification_banana.ipynb cell 9), and
 // the next sweep's noise precision is written with the kernel parameters.
 __global__ void k_train_adamax(TrainState* __restrict__ st, const double* __restrict__ grad, const double* __restrict__ out,
                                Params* __restrict__ src, int D, int n_ell, int update, const int* __restrict__ sync_status,
-                               const Params* __restrict__ swept, double n_window) {
+                               const Params* __restrict__ swept, const double* __restrict__ n_window) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const bool probit = st->kind == 1.0;
     if (update) {
         const bool ok = out[3] == 0.0 && out[4] == 0.0 && (!sync_status || *sync_status == 0);   // SGP_R_INFO_KUU, SGP_R_INFO_LAMBDA
         double gscale = 1.0;
         if (probit && ok) {
-            st->ga += 0.5 * n_window;
+            // (the window's size as the sweep's statistics carry it, SGP_S_N: in a data-sharded run that is the REDUCED scalar --
+            // the whole minibatch, like out[0] + out[1] beside it -- not this rank's slice)
+            st->ga += 0.5 * *n_window;
             st->gb += 0.5 * (out[0] + out[1]);
             gscale = (st->ga / st->gb) / swept->W[0];
         }

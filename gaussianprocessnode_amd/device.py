@@ -6,7 +6,10 @@ Nothing here computes on the CPU: every method is a call into csrc/libsgp_hip.so
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import sys
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -27,6 +30,23 @@ class SweepScalars:
     logdet_lambda: float
 
 
+# Handles that are still open when the interpreter starts to shut down are closed HERE -- an atexit handler runs at the very
+# beginning of finalisation, while ctypes, the HIP runtime, torch and a profiler's tool library are all still alive -- and not
+# from `__del__` during module teardown or, worse, never (a hook closure that references its engine keeps the handle in a
+# reference cycle): a live handle with a registered ctypes hook at exit ended a rocprofv3-profiled run in SIGSEGV inside
+# __cxa_finalize (round 3, tools/hooked_train.py).  The library keeps an exit handler of its own for C / Julia callers.
+_live = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all_at_exit():
+    for dev in list(_live):
+        try:
+            dev.close()
+        except Exception:                                  # pragma: no cover
+            pass
+
+
 class SGPDevice:
     """Owns the device buffers for (n_max points, M inducing points, D dims, d_out outputs)."""
 
@@ -42,17 +62,29 @@ class SGPDevice:
         self.n_max, self.M, self.D, self.d_out, self.device = int(n_max), int(m), int(d), int(d_out), int(device)
         self.Q = self.M * self.d_out
         self.n = 0
+        self._allreduce_cb = None
+        _live.add(self)
 
     def _check(self, rc: int, what: str):
         check(rc, self._h, what, lib=self._lib)
 
     # ---- lifetime
     def close(self):
+        """Destroy the handle (idempotent).  The all-reduce hook goes first: the library must never call a trampoline that is
+        about to be freed, and `sgp_destroy` waits for whatever is still queued."""
         if getattr(self, "_h", None) is not None and self._h.value:
+            if getattr(self, "_allreduce_cb", None) is not None:
+                self._lib.sgp_set_allreduce(self._h, _lib.ALLREDUCE_FN(0), None)
             self._lib.sgp_destroy(self._h)
             self._h = C.c_void_p()
+            self._allreduce_cb = None
+        _live.discard(self)
 
     def __del__(self):
+        # not while the interpreter is finalising: modules this would call into may be half torn down -- the atexit handler
+        # above has closed every live handle before that point
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -283,8 +283,9 @@ int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void* stream, d
 /* ... which = SGP_TIME_GROUP0 + g: the SYRK launch of statistics group g of the overlapped sweep (sgp_overlap_plan), on the stream
  * and the compute units it uses inside the sweep (`stream` is ignored). */
 #define SGP_TIME_GROUP0 100
-/* ... which = SGP_TIME_QUADFORM + mode: the per-point quadratic-form kernel of sgp_w_stats (mode 0: |L^-1 k_n|^2, the Q_ff
- * diagonal of GPnode/UniSGPnode.jl:205-212; mode 1: |Uv k_n|^2, :214), n M (M + 64) flop per launch on the matrix cores. */
+/* ... which = SGP_TIME_QUADFORM: the per-point quadratic-form kernel of sgp_w_stats -- |L^-1 k_n|^2 (the Q_ff diagonal of
+ * GPnode/UniSGPnode.jl:205-212), |Uv k_n|^2 (:214) and k_n . mu in ONE pass over the resident K_uf: 2 n M (M + 64) flop per launch
+ * on the matrix cores. */
 #define SGP_TIME_QUADFORM 120
 /* The overlapped sweep.  For UniSGP problems whose SYRK fills the chip, sgp_sweep(h, NULL) without an all-reduce hook produces the
  * statistics in groups of tile rows of Psi2 -- group 0 on all compute units, the others on a CU-masked queue that leaves 2 CUs

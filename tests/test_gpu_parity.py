@@ -12,6 +12,11 @@ import pytest
 
 from oracle import sgp_oracle as O
 
+# (The experiment lost -- DESIGN.md section 8 -- and lives in a variant library that the default build no longer produces: these
+# tests run only with SGP_TEST_CHAIN=1, which also builds it.)
+CHAIN_TESTS = os.environ.get("SGP_TEST_CHAIN") == "1"
+needs_chain = pytest.mark.skipif(not CHAIN_TESTS, reason="persistent-chain experiment: set SGP_TEST_CHAIN=1 (builds the variant library)")
+
 pytestmark = pytest.mark.gpu
 
 
@@ -176,6 +181,31 @@ def test_sweep_matches_oracle(G, name, N, M, D, w, jit, cls):
     assert abs(obj - ref_obj) <= 1e-7 * abs(ref_obj) + 0.5 * w * tol_I1
 
 
+def test_sweep_with_more_tiles_than_one_round_of_slabs(G):
+    """M = 3000: 47 tile rows = 1128 lower tiles, more than the 4 x 256 workgroups of one SYRK round -- the slab area must hold at
+    least one slab per tile (a fixed 1024-slab capacity refused every M above 2816).  Statistics and posterior
+    against the oracle (GPnode/UniSGPnode.jl:62-73,144-173 batched)."""
+    N, M, D, w, jit = 300, 3000, 8, 50.0, 1e-6
+    X, Xu, y, _ = synth(N, M, D, seed=77)
+    s2, ell = 0.8, np.full(D, 0.9)
+    with G.SGPDevice(N, M, D) as dev:
+        dev.set_inducing(Xu)
+        dev.set_data(X, y)
+        dev.set_kernel(s2, ell, jit)
+        dev.set_prior_isotropic(50.0)
+        dev.set_noise([[w]])
+        dev.sweep()
+        Psi2, B, _ = dev.stats()
+        mu, Sig, Uv = dev.posterior()
+        sc = dev.scalars()
+    ref = O.vmp_sweep(Xu, X, y, None, s2, ell, w, jitter=jit, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
+    assert relF(Psi2, ref.stats.Psi2) < 1e-13 and relF(B, ref.stats.b) < 1e-13
+    tol = post_tol(np.linalg.cond(np.eye(M) / 50.0 + w * ref.stats.Psi2))
+    assert relF(mu, ref.mu_v) < tol and relF(Sig, ref.Sigma_v) < tol and relF(Uv, ref.Uv) < tol
+    assert sc.info_kuu == 0 and sc.info_lambda == 0
+    assert math.isclose(sc.logdet_kuu, 2 * np.log(np.diag(ref.KuuL)).sum(), rel_tol=1e-9, abs_tol=1e-6)
+
+
 SWEEP_SHAPES = [("toy", 50, 20, 1, 100.0, 1e-8), ("ragged", 333, 37, 3, 10.0, 1e-8), ("mid", 700, 130, 2, 30.0, 1e-8)]
 
 
@@ -281,7 +311,8 @@ def test_graph_replay_equals_eager_and_tracks_parameters(G):
     outs = []
     # graph replay against eager launches of the same kernels: bitwise; against the opt-in persistent factorisation launch
     # (SGP_FLAG_PERSISTENT_CHAIN, right-looking): to rounding
-    for use_graph, persistent in ((True, False), (False, False), (False, True)):
+    variants = ((True, False), (False, False), (False, True)) if CHAIN_TESTS else ((True, False), (False, False), (False, False))
+    for use_graph, persistent in variants:
         with G.SGPDevice(N, M, D, use_graph=use_graph, persistent_chain=persistent) as dev:
             dev.set_inducing(Xu)
             dev.set_data(X, y)
@@ -700,6 +731,7 @@ def test_large_m_and_empty_data(G):
 # The opt-in persistent factorisation launch (csrc/sgp_chain.hip.h, SGP_FLAG_PERSISTENT_CHAIN / SGP_CHAIN=persistent):
 # one critical workgroup keeps the diagonal and sub-diagonal tiles in LDS across the steps, helper workgroups feed it through
 # sentinel-tagged mailboxes.  Slower than the launch-per-step default on MI355X but it must stay right.
+@needs_chain
 @pytest.mark.parametrize("n", [1, 64, 100, 192, 300, 512, 700])
 def test_persistent_chain_potrf_potri(G, n, monkeypatch):
     monkeypatch.setenv("SGP_CHAIN", "persistent")
@@ -724,6 +756,7 @@ def test_default_library_has_no_persistent_chain(G):
     assert b"persistent" in lib.sgp_last_error(None)
 
 
+@needs_chain
 def test_persistent_chain_sweep_matches_oracle_and_is_deterministic(G):
     N, M, D, w = 1500, 512, 8, 1e4
     X, Xu, y, _ = synth(N, M, D, seed=11)
@@ -1063,10 +1096,48 @@ def test_a_bounded_wait_that_gives_up_is_reported_not_swallowed(G, overlap, monk
             dev.sweep()
         with pytest.raises(SGPError, match="bounded device-word wait gave up"):
             dev.scalars()
-        # the status word was cleared by the report: the handle is usable again (with a one-poll limit a sweep's own hand-offs
+        # sticky: EVERY getter refuses what that sweep left behind, not only the first one asked
+        for getter in (dev.posterior, dev.stats, dev.kuu_chol, dev.theta_objective):
+            with pytest.raises(SGPError, match="bounded device-word wait gave up"):
+                getter()
+        # the next sweep clears the word: the handle is usable again (with a one-poll limit a sweep's own hand-offs
         # -- statistics groups -> Lambda chain, K_uu chain -> Sigma launch -- may give up too, which is reported the same way)
         dev.sweep()
         try:
             assert np.isfinite(dev.scalars().energy)
         except SGPError as e:
             assert "bounded device-word wait gave up" in str(e)
+
+
+# ------------------------------------------------------------------------------------------------
+# Process exit with a live handle (SIGSEGV inside __cxa_finalize under rocprofv3 when a script left a handle with a
+# registered ctypes all-reduce hook behind).  Teardown must not depend on the caller's tidiness: the Python mirror closes live
+# handles in an atexit handler, the library destroys what is still registered in an exit handler of its own.
+@pytest.mark.parametrize("python_atexit", [True, False], ids=["python-atexit", "library-exit-handler"])
+def test_process_exit_with_a_live_hooked_handle_is_clean(python_atexit):
+    import subprocess
+    import sys
+    code = f"""
+import atexit, sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import numpy as np, torch
+from gaussianprocessnode_amd import device
+from gaussianprocessnode_amd.distributed import HipEngine
+if not {python_atexit}:
+    atexit.unregister(device._close_all_at_exit)      # leave the handle to the library's own exit handler
+rng = np.random.default_rng(0)
+N, M, D = 2000, 128, 3
+X = rng.uniform(-1.7, 1.7, (N, D)); Xu = X[:M].copy(); y = np.sin(X.sum(1))
+eng = HipEngine(N, M, D, 1, device=0)
+eng.install_allreduce(lambda t: t.mul_(1.0))        # a hook: the closure and the engine reference each other
+dev = eng.dev
+dev.set_inducing(Xu); dev.set_data(X, y); dev.set_kernel(0.9, np.full(D, 1.5), 1e-8)
+dev.set_prior_isotropic(50.0); dev.set_noise([[100.0]])
+for _ in range(5):
+    eng.sweep()
+print("energy", dev.scalars().energy, flush=True)
+eng.sweep()                                          # ... and one more sweep still in flight at exit
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert "energy" in r.stdout

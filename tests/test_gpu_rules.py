@@ -605,6 +605,42 @@ def test_sharded_training_step_through_the_allreduce_hook(device_paced):
 
 
 @pytest.mark.gpu
+def test_sharded_probit_training_counts_the_whole_minibatch_in_q_w():
+    """Device-paced CLASSIFICATION, data-sharded: q(w) = Gamma(a + n / 2, b + (sum I1 + sum I2) / 2) must take n --
+    like the two sums -- from the REDUCED statistics (GPnode/UniSGPnode.jl:219-238 summed over the whole minibatch), not from
+    this rank's slice.  The doubling hook stands in for a second rank with the same slice; reference: one rank whose minibatches
+    hold every point twice (experiments/classification_banana.ipynb cells 7-9)."""
+    import torch
+    import gaussianprocessnode_amd as G
+    from gaussianprocessnode_amd.distributed import HipEngine, ShardedDevice
+    from gaussianprocessnode_amd.train import AdaMax, perform_inference_classification
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "banana_fixture.npz"))
+    data = fix["data"]
+    bs, nb = 100, 4
+    X, lab = data[:bs * nb, :2], np.where(data[:bs * nb, 2] < 0, 0.0, data[:bs * nb, 2])
+    Xu = fix["Xu"][:64]
+    th0 = np.log(np.expm1(np.ones(3)))
+    Xd = np.concatenate([np.concatenate([X[o:o + bs], X[o:o + bs]]) for o in range(0, bs * nb, bs)])
+    ld = np.concatenate([np.concatenate([lab[o:o + bs], lab[o:o + bs]]) for o in range(0, bs * nb, bs)])
+    with G.SGPDevice(2 * bs, len(Xu), 2) as one:
+        qv1, ab1, th1 = perform_inference_classification(th0, Xd, ld, Xu, one, batch_size=2 * bs, epochs=1, optimizer=AdaMax(),
+                                                         device_paced=True)
+    eng = HipEngine(bs, len(Xu), 2, 1, device=0)
+    eng.install_allreduce(lambda t: t.mul_(2.0))
+    qv2, ab2, th2 = perform_inference_classification(th0, X, lab, Xu, ShardedDevice(eng.dev, 0, 1), batch_size=bs, epochs=1,
+                                                     optimizer=AdaMax(), device_paced=True)
+    torch.cuda.synchronize()
+    eng.dev.close()
+    assert ab1[0] == ab2[0] == 0.01 + 0.5 * 2 * bs * nb          # the shape counts BOTH ranks' points
+    # (the two runs sum the same statistics in a different order; cond(K_uu) ~ 1e8 with the notebook's jitter turns that into
+    # ~1e-8 per step -- see test_device_paced_classification_steps_match_the_host_loop_to_rounding.  The bug this guards against
+    # moved the shape by a factor of two.)
+    assert math.isclose(ab1[1], ab2[1], rel_tol=1e-6)
+    assert np.max(np.abs(th2 - th1)) < 1e-6 * np.max(np.abs(th1)) and not np.allclose(th1, th0)
+    assert np.linalg.norm(qv2.m - qv1.m) < 1e-5 * np.linalg.norm(qv1.m)
+
+
+@pytest.mark.gpu
 def test_free_energy_trend_of_the_kin40k_run_against_the_saved_trace():
     """`savefiles/FE_kin40k.jld` (tests/golden/misc_fixture.npz): the Bethe free energy the reference recorded over the first 200
     minibatches (10 epochs) of a kin40k run -- an older revision of the notebook with a random w, so the VALUES are not

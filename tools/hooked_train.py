@@ -22,5 +22,6 @@ t0 = time.perf_counter()
 qv, th = perform_inference(np.log(np.expm1(np.ones(D + 1))), X, y, Xu, ShardedDevice(eng.dev, 0, 1), batch_size=bs, epochs=2, w_val=1e4,
                            optimizer=AdaMax())
 torch.cuda.synchronize()
+eng.dev.close()
 print(json.dumps({"minibatches": 2 * (N // bs), "seconds": time.perf_counter() - t0, "hook_calls": len(calls),
                   "hook_payload_doubles": sorted(set(calls)), "theta": [float(v) for v in th]}))

@@ -61,6 +61,20 @@ with G.SGPDevice(bs, M, D) as ref:
 terr = np.max(np.abs(th - th1)) / np.max(np.abs(th1)), np.linalg.norm(qv.m - qv1.m) / np.linalg.norm(qv1.m)
 say(f"sharded training (device-paced, {2 * (N // bs)} steps) vs single rank: theta {terr[0]:.2e}, mu_v {terr[1]:.2e}")
 assert terr[0] < 1e-9 and terr[1] < 1e-6
+# classification (Probit, q(w) carried on the device): shape and rate of q(w) must count the whole minibatch on every rank
+from gaussianprocessnode_amd.train import perform_inference_classification
+lab = (y > 0).astype(np.float64)
+thc = np.log(np.expm1(np.ones(D + 1)))
+eng_c = HipEngine(bs, M, D, 1, device=0)
+sw_c = ShardedSweep(eng_c)
+qc, abc, thc_s = perform_inference_classification(thc, X, lab, Xu, ShardedDevice(eng_c.dev, rank, world), batch_size=bs, epochs=1,
+                                                  optimizer=AdaMax(), device_paced=True)
+eng_c.synchronize()
+with G.SGPDevice(bs, M, D) as ref:
+    qc1, abc1, thc_1 = perform_inference_classification(thc, X, lab, Xu, ref, batch_size=bs, epochs=1, optimizer=AdaMax(), device_paced=True)
+cerr = np.max(np.abs(thc_s - thc_1)) / np.max(np.abs(thc_1)), abs(abc[1] - abc1[1]) / abs(abc1[1])
+say(f"sharded Probit training ({N // bs} steps) vs single rank: theta {cerr[0]:.2e}, q(w) shape {abc[0]} vs {abc1[0]}, rate {cerr[1]:.2e}")
+assert abc[0] == abc1[0] and cerr[0] < 1e-7 and cerr[1] < 1e-7
 dist.barrier()
 dist.destroy_process_group()
 say("ok")

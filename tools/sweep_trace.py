@@ -32,7 +32,7 @@ buf = (C.c_int64 * (256 * 65))()
 _lib.check(lib.sgp_get_sweep_trace(buf), None, "sgp_get_sweep_trace", lib=lib)
 tr = np.array(buf[:], dtype=np.int64).reshape(256, 65)
 names = {0: "prep_xu (stats)", 1: "prep_xu (K_uu)", 2: "gram_uf", 3: "gram_uu", 4: "trmv_mu_scan", 5: "gemm32 Sigma", 6: "gemm32 Kuu^-1",
-         7: "scalars", 8: "join_wait (statM)"}
+         7: "scalars", 8: "join_wait (statM)", 9: "join_wait (K_uu chain's gate)"}
 rows = []
 for s in range(256):
     b, e = tr[s, 0], tr[s, 1:].max()
@@ -52,7 +52,7 @@ for b, e, nm in sorted(rows):
     print(f"{(b - t0) / 100:9.1f} {(e - t0) / 100:9.1f} {(e - b) / 100:7.1f} us  {nm}")
 if os.environ.get("SGP_TRACE_WGS"):
     # the chain steps have fewer than 64 workgroups: slot 1 + blockIdx of a step's record is that workgroup's own exit
-    for s in list(range(16, 25)) + list(range(40, 49)):       # (the launch behind the last step has no form: it shows as K_uu step Tn)
+    for s in list(range(16, 25)) + list(range(40, 49)):
         b = tr[s, 0]
         if not b: continue
         ends = [(int(e) - b) / 100 for e in tr[s, 1:] if e]
