@@ -209,8 +209,12 @@ int sgp_theta_objective(sgp_handle* h, double* value, double* grad);
  * kernel parameters from where the optimiser kernel wrote them, so the host only enqueues and never waits in the loop.
  *   sgp_train_begin  X is n_total x D point-major (row i = point i), y n_total; theta_raw[1 + n_ell] the raw
  *                    (pre-softplus) parameters (sigma2 first); noise, prior and inducing inputs as the setters left them;
- *                    AdaMax(eta, (beta1, beta2), eps) starts from zero state.  UniSGP handles without SGP_FLAG_GRAPH and
- *                    without an all-reduce hook.  Until sgp_train_end every setter, sgp_predict and
+ *                    AdaMax(eta, (beta1, beta2), eps) starts from zero state.  UniSGP handles without SGP_FLAG_GRAPH.  With an
+ *                    all-reduce hook installed (sgp_set_allreduce / sgp_use_rccl) the run is data-sharded: every rank
+ *                    passes ITS slice of each minibatch to sgp_train_step (possibly empty), statistics and the data half
+ *                    of the gradient are summed through the hook, AdaMax runs replicated on identical gradients and every
+ *                    rank ends a step with the same theta (and, for SGP_LIKELIHOOD_PROBIT, the same q(w): its shape
+ *                    counts the whole minibatch).  Until sgp_train_end every setter, sgp_predict and
  *                    sgp_theta_objective return SGP_ERR_ARG.
  *   sgp_train_step   one minibatch = points [offset, offset + n), n <= n_max.  flags: SGP_TRAIN_LEARN = gradient and
  *                    optimiser step (without it theta stays); SGP_TRAIN_RESET_PRIOR = before this minibatch the prior

@@ -12,19 +12,25 @@
 #                                kernel_params = θ -> (softplus(θ[1]), softplus.(θ[2:end])))
 #     end
 #
-# `HipSGPMeta` wraps the reference's meta and owns a device handle.  The methods below dispatch on it: the PointMass-input
-# rules (the hot path: `:v`, the N-fold product, `:w`, the average energy, `:out`) run on the device; every other rule
-# (uncertain inputs, `:in`, `:θ`) forwards to the reference's own method with the wrapped `UniSGPMeta`, whose `Uv` and
-# `counter` the device path keeps up to date exactly as GPnode/UniSGPnode.jl:64-71 does.  `HipMultiSGPMeta` does the same
-# for the MultiSGP node: the cubature Ψ-statistics of a step (GPnode/MultiSGPnode.jl:11-35, 5 Gram columns and 5 rank-1
-# M × M updates per step in the reference) come from the device, the D × D algebra around them stays as the reference has it.
+# `HipSGPMeta` wraps the reference's meta and owns a device handle.  The methods below dispatch on it.  The PointMass-input
+# rules (the hot path: `:v`, the N-fold product, `:w`, the average energy, `:out`) run on the device inside the sweep.  The
+# cold rules run on the device too, call for call like gaussianprocessnode_amd/unisgp.py:183-387: uncertain inputs enter `:v`
+# and `:out` as cubature-weighted data, and the per-node clamped `:w` / average energy of an uncertain input, the `:in`
+# closure and the three `:θ` closures are stand-alone per-point evaluations (`stats_at`: sgp_set_data + sgp_sweep_local +
+# sgp_set_posterior + sgp_w_stats on an auxiliary handle) at whatever q_v / meta.Uv the caller passes -- the wrapped
+# `UniSGPMeta`'s `Uv`, `KuuL` and `counter` are kept up to date exactly as GPnode/UniSGPnode.jl:64-71 does.
+# `HipMultiSGPMeta` does the same for the MultiSGP node: the cubature Ψ-statistics of a step (GPnode/MultiSGPnode.jl:11-35,
+# 5 Gram columns and 5 rank-1 M × M updates per step in the reference) come from the device, and so do the `:in` and `:θ`
+# closures (multisgp.py:169-278); the D × D algebra around them stays as the reference has it.
 module SGPHip
 
 using ReactiveMP, LinearAlgebra
+import Optim                                   # (the reference's MultiSGP(:in) Laplace rule uses it, GPnode/MultiSGPnode.jl:229)
 import ReactiveMP: @rule, @average_energy, @call_rule, GenericProd, PointMass, MvNormalMeanCovariance,
                    MvNormalMeanPrecision, MvNormalWeightedMeanPrecision, NormalMeanPrecision, GammaShapeRate, Wishart,
                    NormalDistributionsFamily, UnivariateGaussianDistributionsFamily, MultivariateNormalDistributionsFamily,
-                   MultivariateGaussianDistributionsFamily, mean, var, cov, mean_cov, AverageEnergy
+                   MultivariateGaussianDistributionsFamily, UnivariateNormalDistributionsFamily, mean, var, cov, mean_cov,
+                   mean_var, AverageEnergy, ContinuousUnivariateLogPdf, ContinuousMultivariateLogPdf, UnspecifiedDomain
 import ..UniSGP, ..UniSGPMeta, ..MultiSGP, ..MultiSGPMeta, ..WishartFast, ..approximate_kernel_expectation!
 
 export HipSGPMeta, HipMultiSGPMeta, predict, theta_objective, carry_posterior!, multisgp_sweep!
@@ -109,6 +115,34 @@ function predict_mean(h::Handle, Xstar::Matrix{Float64}, μ_v::Vector{Float64})
     return out
 end
 
+# q(v) installed from outside for the per-point outputs (include/sgp_hip.h, sgp_set_posterior): mean and the upper factor
+# Uv = chol(Σ_v + μ μ').U, column-major Q × Q -- a Julia Matrix as it is
+set_posterior!(h::Handle, μ_v::Vector{Float64}, Uv::Matrix{Float64}) =
+    check(ccall((:sgp_set_posterior, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h.ptr, μ_v, Uv), h.ptr)
+function kuu_chol(h::Handle)
+    L = zeros(h.m, h.m)
+    check(ccall((:sgp_get_kuu_chol, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, L), h.ptr)
+    return L
+end
+# stand-alone dense building blocks on the device (host in / host out): lower Cholesky factor, SPD inverse, K(A, B)
+function potrf(A::Matrix{Float64}; device = 0)
+    n = size(A, 1); L = zeros(n, n)
+    check(ccall((:sgp_potrf, LIB), Cint, (Int32, Ptr{Float64}, Int32, Ptr{Float64}), device, A, n, L), C_NULL)
+    return L
+end
+function potri(A::Matrix{Float64}; device = 0)
+    n = size(A, 1); Ai = zeros(n, n)
+    check(ccall((:sgp_potri, LIB), Cint, (Int32, Ptr{Float64}, Int32, Ptr{Float64}), device, A, n, Ai), C_NULL)
+    return Ai
+end
+function kernelmatrix_dev(A::Matrix{Float64}, B::Matrix{Float64}, σ², ℓ::Vector{Float64}; device = 0)      # A: D × na, B: D × nb
+    K = zeros(size(A, 2), size(B, 2))
+    check(ccall((:sgp_kernelmatrix, LIB), Cint,
+                (Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Int32, Float64, Ptr{Float64}, Int32, Ptr{Float64}),
+                device, A, size(A, 2), B, size(B, 2), size(A, 1), σ², ℓ, length(ℓ), K), C_NULL)
+    return K
+end
+
 # ------------------------------------------------------------------------------------------------------------------
 # UniSGP
 # ------------------------------------------------------------------------------------------------------------------
@@ -127,12 +161,18 @@ mutable struct HipSGPMeta{R<:UniSGPMeta}
     index::Dict{Vector{Float64},Int}  # point -> column of the last swept batch
     I1::Vector{Float64}               # per-point :w quantities of the last sweep (fetched on first use)
     I2::Vector{Float64}
+    ωs::Vector{Float64}               # cubature weights of the batch being folded (uncertain inputs: one entry per cubature point)
+    uncertain::Bool                   # the batch being folded consists of uncertain-input nodes (GPnode/UniSGPnode.jl:125-140)
+    aux::Union{Nothing,Handle}        # second handle for stand-alone rule evaluations (it replaces data and posterior)
+    device::Int
+    μ_last::Vector{Float64}           # mean of the last swept q(v): the per-point pass belongs to it
 end
 
-function HipSGPMeta(ref::UniSGPMeta; kernel_params, jitter = 0.0, device = 0)
-    h = Handle(ref.N, inducing_matrix(ref.Xu), 1; device = device)
+function HipSGPMeta(ref::UniSGPMeta; kernel_params, jitter = 0.0, device = 0, cubature_points = 21)
+    # (uncertain inputs enter the sweep as `cubature_points` weighted points per node: size the handle for them)
+    h = Handle(ref.N * max(1, cubature_points), inducing_matrix(ref.Xu), 1; device = device)
     return HipSGPMeta(ref, h, kernel_params, Float64(jitter), Vector{Float64}[], Float64[], Float64[], nothing, 1.0, 0.0,
-                      Float64[], Dict{Vector{Float64},Int}(), Float64[], Float64[])
+                      Float64[], Dict{Vector{Float64},Int}(), Float64[], Float64[], Float64[], false, nothing, device, Float64[])
 end
 
 # the token the per-point :v rule returns instead of an M × M message (replaces BufferUniSGP, GPnode/UniSGPnode.jl:56-60)
@@ -163,37 +203,71 @@ function ReactiveMP.prod(::GenericProd, left::NormalDistributionsFamily, right::
     ref.counter < ref.N && return meta.prior                   # nothing consumes the partial products
     h = meta.handle
     X = reduce(hcat, meta.xs)
-    set_data!(h, X, meta.ys, any(!iszero, meta.vs) ? meta.vs : nothing, nothing, -1.0)
+    μ0, Σ0 = mean_cov(meta.prior)
+    if meta.uncertain
+        # cubature points as weighted data, N nodes (unisgp.py:138-147); every one of the N messages carries Ψ2 + 1e-8 I
+        # (GPnode/UniSGPnode.jl:135,138): the prior's precision gains 1e-8 w N on the diagonal
+        set_data!(h, X, meta.ys, nothing, meta.ωs, Float64(ref.N))
+        Λ0 = potri(Matrix{Float64}(Σ0); device = meta.device)
+        ξ0 = Λ0 * collect(Float64, μ0)
+        Λ0 += 1e-8 * meta.w * ref.N * I
+        set_prior!(h, ξ0, Matrix{Float64}(Λ0), 1)
+    else
+        set_data!(h, X, meta.ys, any(!iszero, meta.vs) ? meta.vs : nothing, nothing, -1.0)
+        set_prior!(h, collect(Float64, μ0), Matrix{Float64}(Σ0), 0)
+    end
     σ², ℓ = meta.kernel_params(meta.θ)
     set_kernel!(h, σ², collect(Float64, ℓ), meta.jitter)
     set_noise!(h, fill(meta.w, 1, 1), meta.Elogw)
-    μ0, Σ0 = mean_cov(meta.prior)
-    set_prior!(h, collect(Float64, μ0), Matrix{Float64}(Σ0), 0)
     sweep!(h)
     μ, Σ, Uv = posterior(h)
     ref.Uv = UpperTriangular(Uv)                               # :67-69  meta.Uv = chol(Σ + μμ').U
+    ref.KuuL = LowerTriangular(kuu_chol(h))                    # (the cold rules read meta.KuuL: the factor this sweep used)
     ref.counter = 0                                            # :70
-    meta.index = Dict(x => i for (i, x) in enumerate(meta.xs)); meta.I1 = Float64[]; meta.I2 = Float64[]
-    empty!(meta.xs); empty!(meta.ys); empty!(meta.vs)
+    meta.index = meta.uncertain ? Dict{Vector{Float64},Int}() : Dict(x => i for (i, x) in enumerate(meta.xs))
+    meta.I1 = Float64[]; meta.I2 = Float64[]; meta.μ_last = copy(μ)
+    empty!(meta.xs); empty!(meta.ys); empty!(meta.vs); empty!(meta.ωs); meta.uncertain = false
     return MvNormalMeanCovariance(μ, Σ)
 end
 
+# ---- :v with an uncertain input (GPnode/UniSGPnode.jl:125-140): the node's cubature points join the batch as weighted data --
+cubature_1d(meta::HipSGPMeta, q_in) = (m = mean(q_in); v = var(q_in);
+    (collect(Float64, ReactiveMP.getpoints(meta.ref.method, m, v)), collect(Float64, ReactiveMP.getweights(meta.ref.method, m, v))))
+@rule UniSGP(:v, Marginalisation) (q_out::UnivariateNormalDistributionsFamily, q_in::UnivariateNormalDistributionsFamily, q_w::Any, q_θ::PointMass, meta::HipSGPMeta) = begin
+    isempty(meta.xs) || meta.uncertain || error("PointMass and uncertain inputs mixed in one graph")
+    pts, ω = cubature_1d(meta, q_in)
+    for (p, wt) in zip(pts, ω)
+        push!(meta.xs, [p]); push!(meta.ys, mean(q_out)); push!(meta.vs, 0.0); push!(meta.ωs, wt)
+    end
+    meta.uncertain = true
+    meta.w = mean(q_w); meta.Elogw = elog(q_w); meta.θ = collect(Float64, mean(q_θ))
+    return HipBuffer(length(meta.xs), meta)
+end
+
 # ---- :w and the average energy at PointMass inputs (GPnode/UniSGPnode.jl:196-238, 337-387, 411-436) ---------------
-function point_stats(q_in::PointMass, meta::HipSGPMeta)
-    isempty(meta.I1) && ((meta.I1, meta.I2) = w_stats(meta.handle, length(meta.index)))
-    i = meta.index[point(q_in)]
-    return meta.I1[i], meta.I2[i]
+# (I1_n, I2_n) of one node: from the per-point pass over the last swept batch when the point and q_v belong to it, else
+# evaluated stand-alone at (q_v, meta.Uv) like the reference's rule would (unisgp.py: _point_stats)
+function point_stats(q_out, q_in::PointMass, q_v, q_θ, meta::HipSGPMeta)
+    x = point(q_in)
+    if haskey(meta.index, x) && isapprox(collect(Float64, mean(q_v)), meta.μ_last; rtol = 1e-12, atol = 0)
+        isempty(meta.I1) && ((meta.I1, meta.I2) = w_stats(meta.handle, length(meta.index)))
+        i = meta.index[x]
+        return meta.I1[i], meta.I2[i]
+    end
+    yv = q_out isa PointMass ? nothing : [Float64(var(q_out))]
+    I1, I2 = stats_at(meta, mean(q_θ), reshape(x, :, 1), [Float64(mean(q_out))], yv, collect(Float64, mean(q_v)), Matrix{Float64}(meta.ref.Uv))
+    return I1[1], I2[1]
 end
 @rule UniSGP(:w, Marginalisation) (q_out::PointMass, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_θ::PointMass, meta::HipSGPMeta) =
-    (I = point_stats(q_in, meta); GammaShapeRate(1.5, 0.5 * (I[1] + I[2])))
+    (I = point_stats(q_out, q_in, q_v, q_θ, meta); GammaShapeRate(1.5, 0.5 * (I[1] + I[2])))
 @rule UniSGP(:w, Marginalisation) (q_out::UnivariateGaussianDistributionsFamily, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_θ::PointMass, meta::HipSGPMeta) =
-    (I = point_stats(q_in, meta); GammaShapeRate(1.5, 0.5 * (I[1] + I[2])))
+    (I = point_stats(q_out, q_in, q_v, q_θ, meta); GammaShapeRate(1.5, 0.5 * (I[1] + I[2])))
 
-hip_energy(q_in, q_w, meta) = (I = point_stats(q_in, meta); w = mean(q_w); 0.5 * (I[1] * w - elog(q_w) + log(2π) + I[2] * w))
-@average_energy UniSGP (q_out::PointMass, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_w::GammaShapeRate, q_θ::PointMass, meta::HipSGPMeta) = hip_energy(q_in, q_w, meta)
-@average_energy UniSGP (q_out::UnivariateGaussianDistributionsFamily, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_w::GammaShapeRate, q_θ::PointMass, meta::HipSGPMeta) = hip_energy(q_in, q_w, meta)
-@average_energy UniSGP (q_out::PointMass, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_w::PointMass, q_θ::PointMass, meta::HipSGPMeta) = hip_energy(q_in, q_w, meta)
-@average_energy UniSGP (q_out::UnivariateGaussianDistributionsFamily, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_w::PointMass, q_θ::PointMass, meta::HipSGPMeta) = hip_energy(q_in, q_w, meta)
+hip_energy(q_out, q_in, q_v, q_w, q_θ, meta) = (I = point_stats(q_out, q_in, q_v, q_θ, meta); w = mean(q_w); 0.5 * (I[1] * w - elog(q_w) + log(2π) + I[2] * w))
+@average_energy UniSGP (q_out::PointMass, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_w::GammaShapeRate, q_θ::PointMass, meta::HipSGPMeta) = hip_energy(q_out, q_in, q_v, q_w, q_θ, meta)
+@average_energy UniSGP (q_out::UnivariateGaussianDistributionsFamily, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_w::GammaShapeRate, q_θ::PointMass, meta::HipSGPMeta) = hip_energy(q_out, q_in, q_v, q_w, q_θ, meta)
+@average_energy UniSGP (q_out::PointMass, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_w::PointMass, q_θ::PointMass, meta::HipSGPMeta) = hip_energy(q_out, q_in, q_v, q_w, q_θ, meta)
+@average_energy UniSGP (q_out::UnivariateGaussianDistributionsFamily, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_w::PointMass, q_θ::PointMass, meta::HipSGPMeta) = hip_energy(q_out, q_in, q_v, q_w, q_θ, meta)
 
 # ---- :out at a PointMass input (GPnode/UniSGPnode.jl:96-104); `predict` does a whole test set in one call ---------
 @rule UniSGP(:out, Marginalisation) (q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_w::Any, q_θ::PointMass, meta::HipSGPMeta) = begin
@@ -206,17 +280,96 @@ function predict(meta::HipSGPMeta, Xstar::Matrix{Float64}, μ_v::Vector{Float64}
     return vec(predict_mean(meta.handle, Xstar, μ_v))
 end
 
-# ---- everything else: the reference's own methods, with the wrapped meta -----------------------------------------
-@rule UniSGP(:out, Marginalisation) (q_in::UnivariateGaussianDistributionsFamily, q_v::MultivariateNormalDistributionsFamily, q_w::Any, q_θ::PointMass, meta::HipSGPMeta) =
-    @call_rule UniSGP(:out, Marginalisation) (q_in = q_in, q_v = q_v, q_w = q_w, q_θ = q_θ, meta = meta.ref)
-@rule UniSGP(:in, Marginalisation) (q_out::UnivariateGaussianDistributionsFamily, q_v::MultivariateNormalDistributionsFamily, q_w::Any, q_θ::PointMass, meta::HipSGPMeta) =
-    @call_rule UniSGP(:in, Marginalisation) (q_out = q_out, q_v = q_v, q_w = q_w, q_θ = q_θ, meta = meta.ref)
-@rule UniSGP(:v, Marginalisation) (q_out::UnivariateGaussianDistributionsFamily, q_in::UnivariateGaussianDistributionsFamily, q_w::Any, q_θ::PointMass, meta::HipSGPMeta) =
-    @call_rule UniSGP(:v, Marginalisation) (q_out = q_out, q_in = q_in, q_w = q_w, q_θ = q_θ, meta = meta.ref)
+# ---- the cold rules, device-backed (unisgp.py:183-387; VERDICT r3 item 7) -----------------------------------------------
+# Stand-alone per-point (I1_n, I2_n) of GPnode/UniSGPnode.jl:196-238 for arbitrary points X (D × n), at kernel(θ) and at the
+# q(v) given by (μ_v, Uv = chol(Σ_v + μ μ').U): K_uu chain and K_uf on the device, then the per-point quadratic forms.  On an
+# auxiliary handle: the main one holds the last swept batch.
+function aux_handle!(meta::HipSGPMeta, n::Int)
+    if meta.aux === nothing || meta.aux.n_max < n
+        meta.aux = Handle(max(n, 64), inducing_matrix(meta.ref.Xu), 1; device = meta.device)
+    end
+    return meta.aux
+end
+function stats_at(meta::HipSGPMeta, θ, X::Matrix{Float64}, y::Vector{Float64}, yv, μ_v::Vector{Float64}, Uv)
+    h = aux_handle!(meta, size(X, 2))
+    set_data!(h, X, y, yv, nothing, -1.0)
+    σ², ℓ = meta.kernel_params(θ)
+    set_kernel!(h, σ², collect(Float64, ℓ), meta.jitter)
+    sweep_local!(h)
+    set_posterior!(h, μ_v, Matrix{Float64}(Uv))
+    return w_stats(h, size(X, 2))
+end
+# chol(Σ_v + μ μ').U of an explicit q_v, factored on the device
+uv_of(q_v, meta::HipSGPMeta) = (μ = mean(q_v); Matrix(potrf(Matrix{Float64}(cov(q_v) + μ * μ'); device = meta.device)'))
+
+# (I1, I2) of ONE node whose input is uncertain: Ψ-statistics by the meta's cubature, Ψ2 + jitter_psi2 I, clamped like the
+# reference (GPnode/UniSGPnode.jl:186-190)
+function node_I(q_out, q_in, μ_v, Uv, θ, meta::HipSGPMeta, jitter_psi2, clamped)
+    pts, ω = cubature_1d(meta, q_in)
+    μ_y = mean(q_out); v_y = q_out isa PointMass ? 0.0 : var(q_out)
+    I1q, I2q = stats_at(meta, θ, reshape(pts, 1, :), fill(Float64(μ_y), length(ω)), nothing, collect(Float64, μ_v), Uv)
+    I1 = dot(ω, I1q)
+    I2 = dot(ω, I2q) + μ_y^2 * (1.0 - sum(ω)) + v_y
+    if jitter_psi2 != 0
+        KuuL = Matrix{Float64}(meta.ref.KuuL)
+        I1 -= jitter_psi2 * tr(potri(KuuL * KuuL'; device = meta.device))      # tr(Kuu^-1 (jitter I))
+        I2 += jitter_psi2 * sum(abs2, Uv)                                      # tr(Uv'Uv (jitter I))
+    end
+    clamped && ((I1, I2) = (clamp(I1, 1e-12, 1e12), clamp(I2, 1e-12, 1e12)))
+    return I1, I2
+end
+
+# :out with an uncertain input (GPnode/UniSGPnode.jl:85-93): Ψ1 = Σ_s ω_s K(Xu, x_s), mean = Ψ1 · μ_v
+@rule UniSGP(:out, Marginalisation) (q_in::UnivariateGaussianDistributionsFamily, q_v::MultivariateNormalDistributionsFamily, q_w::Any, q_θ::PointMass, meta::HipSGPMeta) = begin
+    pts, ω = cubature_1d(meta, q_in)
+    f = predict(meta, reshape(pts, 1, :), collect(Float64, mean(q_v)), mean(q_θ))
+    return NormalMeanPrecision(dot(ω, f), mean(q_w))
+end
+# :w with an uncertain input (GPnode/UniSGPnode.jl:177-192): meta.Uv, Ψ2 + 1e-8 I, clamped
 @rule UniSGP(:w, Marginalisation) (q_out::UnivariateGaussianDistributionsFamily, q_in::UnivariateGaussianDistributionsFamily, q_v::MultivariateNormalDistributionsFamily, q_θ::PointMass, meta::HipSGPMeta) =
-    @call_rule UniSGP(:w, Marginalisation) (q_out = q_out, q_in = q_in, q_v = q_v, q_θ = q_θ, meta = meta.ref)
-@rule UniSGP(:θ, Marginalisation) (q_out::Any, q_in::Any, q_v::MultivariateNormalDistributionsFamily, q_w::Any, meta::HipSGPMeta) =
-    @call_rule UniSGP(:θ, Marginalisation) (q_out = q_out, q_in = q_in, q_v = q_v, q_w = q_w, meta = meta.ref)
+    (I = node_I(q_out, q_in, mean(q_v), Matrix{Float64}(meta.ref.Uv), mean(q_θ), meta, 1e-8, true); GammaShapeRate(1.5, 0.5 * (I[1] + I[2])))
+# average energy with an uncertain input: Gamma q_w (GPnode/UniSGPnode.jl:290-313: meta.KuuL / meta.Uv, Ψ2 + 1e-8 I, clamped) and
+# PointMass q_w (:390-409: Σ_v + μ μ' from q_v itself; the reference's `.+ 1e-8` on every entry is not reproduced, < 1e-6)
+@average_energy UniSGP (q_out::UnivariateNormalDistributionsFamily, q_in::UnivariateGaussianDistributionsFamily, q_v::MultivariateNormalDistributionsFamily, q_w::GammaShapeRate, q_θ::PointMass, meta::HipSGPMeta) = begin
+    I1, I2 = node_I(q_out, q_in, mean(q_v), Matrix{Float64}(meta.ref.Uv), mean(q_θ), meta, 1e-8, true)
+    w = mean(q_w)
+    return 0.5 * (I1 * w - elog(q_w) + log(2π) + I2 * w)
+end
+@average_energy UniSGP (q_out::UnivariateNormalDistributionsFamily, q_in::UnivariateGaussianDistributionsFamily, q_v::MultivariateNormalDistributionsFamily, q_w::PointMass, q_θ::PointMass, meta::HipSGPMeta) = begin
+    I1, I2 = node_I(q_out, q_in, mean(q_v), uv_of(q_v, meta), mean(q_θ), meta, 0.0, true)
+    w = mean(q_w)
+    return 0.5 * (I1 * w - elog(q_w) + log(2π) + I2 * w)
+end
+# :in (GPnode/UniSGPnode.jl:107-122): x -> -w/2 A(x) + w μ_y B(x)·μ_v - w/2 |Uv B(x)|² = -w/2 (I1(x) + I2(x) - μ_y²), every
+# evaluation one device pass (K_uu chain, K_uf column, the two quadratic forms); meta.Uv as the reference's rule reads it
+@rule UniSGP(:in, Marginalisation) (q_out::UnivariateNormalDistributionsFamily, q_v::MultivariateNormalDistributionsFamily, q_w::Any, q_θ::PointMass, meta::HipSGPMeta) = begin
+    w = mean(q_w); μ_y = mean(q_out); μ_v = collect(Float64, mean(q_v)); θ = mean(q_θ); Uv = Matrix{Float64}(meta.ref.Uv)
+    log_backwardmess = (x) -> begin
+        I1, I2 = stats_at(meta, θ, reshape(collect(Float64, x), :, 1), [Float64(μ_y)], nothing, μ_v, Uv)
+        -0.5 * w * (I1[1] + I2[1] - μ_y^2)
+    end
+    return ContinuousUnivariateLogPdf(log_backwardmess)
+end
+# :θ (GPnode/UniSGPnode.jl:242-287, three methods): θ -> w μ_y Ψ1(θ)·μ_v - w/2 (Ψ0(θ) + tr(Ψ2(θ) (Rv - Kuu^-1(θ))))
+#    = -w/2 (Σ_q ω_q (I1_q + I2_q) - μ_y² Σ_q ω_q),   Rv from q_v itself
+function theta_closure(q_out, q_in, q_v, q_w, meta::HipSGPMeta)
+    w = mean(q_w); μ_y = Float64(mean(q_out)); μ_v = collect(Float64, mean(q_v)); Uv = uv_of(q_v, meta)
+    pts, ω = q_in isa PointMass ? (point(q_in), [1.0]) : cubature_1d(meta, q_in)
+    X = q_in isa PointMass ? reshape(pts, :, 1) : reshape(pts, 1, :)
+    log_backwardmess = (θ) -> begin
+        I1, I2 = stats_at(meta, θ, X, fill(μ_y, length(ω)), nothing, μ_v, Uv)
+        -0.5 * w * (dot(ω, I1 .+ I2) - μ_y^2 * sum(ω))
+    end
+    return ContinuousMultivariateLogPdf(UnspecifiedDomain(), log_backwardmess)
+end
+@rule UniSGP(:θ, Marginalisation) (q_out::PointMass, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_w::Any, meta::HipSGPMeta) =
+    theta_closure(q_out, q_in, q_v, q_w, meta)
+@rule UniSGP(:θ, Marginalisation) (q_out::UnivariateGaussianDistributionsFamily, q_in::PointMass, q_v::MultivariateNormalDistributionsFamily, q_w::Any, meta::HipSGPMeta) =
+    theta_closure(q_out, q_in, q_v, q_w, meta)
+@rule UniSGP(:θ, Marginalisation) (q_out::UnivariateNormalDistributionsFamily, q_in::UnivariateNormalDistributionsFamily, q_v::MultivariateGaussianDistributionsFamily, q_w::Any, meta::HipSGPMeta) =
+    theta_closure(q_out, q_in, q_v, q_w, meta)
+# (The Gaussian × log-pdf product of GPnode/UniSGPnode.jl:39-54 dispatches on the message types, not on the meta: the reference's
+# own method applies unchanged -- its 21 closure evaluations are 21 device passes.)
 
 # ---- hyper-parameter objective and gradient (neg_log_backwardmess_fast / grad_llh_new!,
 # helper_functions/derivative_helper.jl:23-39,55-63) at the θ of the last sweep, q(v) fixed ---------------------------
@@ -287,13 +440,15 @@ mutable struct HipMultiSGPMeta{R<:MultiSGPMeta}
     step::Handle                      # single-output handle for the per-step Ψ-statistics
     kernel_params::Function
     jitter::Float64
+    aux::Union{Nothing,Handle}        # single-output handle for the :in / :θ closures (it replaces data and posterior)
+    device::Int
 end
 
 function HipMultiSGPMeta(ref::MultiSGPMeta, d_out::Int; kernel_params, n_steps, jitter = 0.0, device = 0)
     Xu = inducing_matrix(ref.Xu)
     npts = 2 * size(Xu, 1) + 1                                 # srcubature: 2 d_in + 1 points per step
     return HipMultiSGPMeta(ref, d_out, Handle(n_steps * npts, Xu, d_out; device = device), Handle(npts, Xu, 1; device = device),
-                           kernel_params, Float64(jitter))
+                           kernel_params, Float64(jitter), nothing, device)
 end
 
 # cubature points / weights of q_in as the reference's approximate_kernel_expectation! walks them (GPnode/MultiSGPnode.jl:11-35)
@@ -358,13 +513,81 @@ end
     return MvNormalMeanPrecision(vec(ω' * F), mean(q_w))
 end
 
-# ---- :in, :θ and the per-step energies: the reference's own methods with the wrapped meta ---------------------------
+# ---- :in and :θ (multisgp.py:169-278) -- both closures are per-point device quantities at a PSEUDO-posterior ------------------
+# s = Σ_d μ_v^(d) (μ_y' W)_d  (sum_diagonal_M) and S = Σ_ij W_ij Rv_blk[i][j]  (create_blockmatrix), Rv = Σ_v + μ μ': what the
+# closures keep of q(v) (GPnode/MultiSGPnode.jl:176-179).  With mean s, factor chol(S).U and pseudo-observations y = 1,
+# sgp_w_stats returns I1(x) = k(x,x) - k' Kuu^-1 k and I2(x) = 1 - 2 s·k + k' S k.
+function second_moment_contraction(q_out, q_v, W, M)
+    μ_y = collect(Float64, mean(q_out)); D = length(μ_y)
+    μ_v, Σ_v = mean_cov(q_v)
+    Rv = Σ_v + μ_v * μ_v'
+    row = μ_y' * W
+    s = sum(view(μ_v, (d-1)*M+1:d*M) .* row[d] for d in 1:D)
+    S = sum(view(Rv, (i-1)*M+1:i*M, (j-1)*M+1:j*M) .* W[i, j] for i in 1:D, j in 1:D)
+    return collect(Float64, s), Matrix{Float64}(0.5 * (S + S'))
+end
+function aux_handle!(meta::HipMultiSGPMeta, n::Int)
+    if meta.aux === nothing || meta.aux.n_max < n
+        meta.aux = Handle(max(n, 64), inducing_matrix(meta.ref.Xu), 1; device = meta.device)
+    end
+    return meta.aux
+end
+function pseudo_stats(meta::HipMultiSGPMeta, X::Matrix{Float64}, σ², ℓ, jitter, s, US)
+    h = aux_handle!(meta, size(X, 2))
+    set_data!(h, X, ones(size(X, 2)), nothing, nothing, -1.0)
+    set_kernel!(h, σ², collect(Float64, ℓ), jitter)
+    sweep_local!(h)
+    set_posterior!(h, s, US)
+    return w_stats(h, size(X, 2))
+end
+# :in (GPnode/MultiSGPnode.jl:162-208): x -> -1/2 tr(W) I1(x) + s·k(x) - 1/2 k(x)' S k(x) = -1/2 tr(W) I1 - 1/2 (I2 - 1)
+function multi_in_closure(q_out, q_v, q_w, q_θ, meta::HipMultiSGPMeta)
+    W = Matrix{Float64}(mean(q_w)); M = meta.step.m
+    s, S = second_moment_contraction(q_out, q_v, W, M)
+    US = Matrix(potrf(S; device = meta.device)')                # upper factor: |US k|² = k' S k
+    σ², ℓ = meta.kernel_params(mean(q_θ))
+    trW = tr(W)
+    return (x) -> begin
+        I1, I2 = pseudo_stats(meta, reshape(collect(Float64, x), :, 1), σ², ℓ, meta.jitter, s, US)
+        -0.5 * trW * I1[1] - 0.5 * (I2[1] - 1.0)
+    end
+end
 @rule MultiSGP(:in, Marginalisation) (q_out::Any, q_v::MultivariateNormalDistributionsFamily, q_w::Any, q_θ::PointMass, meta::HipMultiSGPMeta) =
-    @call_rule MultiSGP(:in, Marginalisation) (q_out = q_out, q_v = q_v, q_w = q_w, q_θ = q_θ, meta = meta.ref)
-@rule MultiSGP(:in, Marginalisation) (q_out::PointMass, q_in::MultivariateGaussianDistributionsFamily, q_v::MultivariateGaussianDistributionsFamily, q_w::Any, q_θ::PointMass, meta::HipMultiSGPMeta) =
-    @call_rule MultiSGP(:in, Marginalisation) (q_out = q_out, q_in = q_in, q_v = q_v, q_w = q_w, q_θ = q_θ, meta = meta.ref)
-@rule MultiSGP(:θ, Marginalisation) (q_out::Any, q_in::MultivariateGaussianDistributionsFamily, q_v::MultivariateGaussianDistributionsFamily, q_w::Any, meta::HipMultiSGPMeta) =
-    @call_rule MultiSGP(:θ, Marginalisation) (q_out = q_out, q_in = q_in, q_v = q_v, q_w = q_w, meta = meta.ref)
+    ContinuousMultivariateLogPdf(UnspecifiedDomain(), multi_in_closure(q_out, q_v, q_w, q_θ, meta))
+# the Laplace variant (:210-236: q_out::PointMass, Gaussian q_in, point-mass q_w) minimises the same closure; the reference's own
+# optimiser code runs unchanged on it -- every evaluation is one device pass
+@rule MultiSGP(:in, Marginalisation) (q_out::PointMass, q_in::MultivariateGaussianDistributionsFamily, q_v::MultivariateGaussianDistributionsFamily, q_w::Any, q_θ::PointMass, meta::HipMultiSGPMeta) = begin
+    f = multi_in_closure(q_out, q_v, q_w, q_θ, meta)
+    neg = (x) -> -f(x)
+    D = length(mean(q_in)); E = Matrix{Float64}(I, D, D); h1 = 1e-5
+    # (the reference differentiates with ForwardDiff / Zygote, :227-231; a ccall cannot be traced, so gradient and Hessian are
+    # central differences of the device-evaluated closure, as in multisgp.py: rule_in_laplace)
+    grad! = (G, x) -> (for a in 1:D; G[a] = (neg(x + h1 * E[:, a]) - neg(x - h1 * E[:, a])) / (2 * h1); end; G)
+    m_z = Optim.optimize(neg, grad!, collect(Float64, mean(q_in)), Optim.LBFGS(), Optim.Options(iterations = 20); inplace = true).minimizer   # :229
+    hh = 1e-4
+    W_z = [(neg(m_z + hh * (E[:, a] + E[:, b])) - neg(m_z + hh * (E[:, a] - E[:, b])) - neg(m_z - hh * (E[:, a] - E[:, b])) + neg(m_z - hh * (E[:, a] + E[:, b]))) / (4 * hh^2)
+           for a in 1:D, b in 1:D]                               # Hessian at the minimiser by central differences (:231-233 uses ForwardDiff)
+    return MvNormalWeightedMeanPrecision(W_z * m_z, W_z)        # :235
+end
+# :θ (GPnode/MultiSGPnode.jl:447-466): θ -> -1/2 tr(W) (Ψ0 - tr(Kuu^-1 Ψ2')) + Ψ1·s - 1/2 tr(Ψ2' S), Ψ2' = Ψ2 + 1e-7 I (:458),
+# Kuu(θ) without jitter (:455): per cubature point the :in closure; the 1e-7 I term adds 1e-7 (tr(W) tr(Kuu^-1) - tr(S)) / 2
+@rule MultiSGP(:θ, Marginalisation) (q_out::Any, q_in::MultivariateGaussianDistributionsFamily, q_v::MultivariateGaussianDistributionsFamily, q_w::Any, meta::HipMultiSGPMeta) = begin
+    W = Matrix{Float64}(mean(q_w)); M = meta.step.m
+    s, S = second_moment_contraction(q_out, q_v, W, M)
+    US = Matrix(potrf(S; device = meta.device)')
+    trW, trS = tr(W), tr(S)
+    X, ω = cubature(meta, q_in)
+    Xu = inducing_matrix(meta.ref.Xu)
+    log_backwardmess = (θ) -> begin
+        σ², ℓ = meta.kernel_params(θ)
+        I1, I2 = pseudo_stats(meta, X, σ², ℓ, 0.0, s, US)
+        tr_kinv = tr(potri(kernelmatrix_dev(Xu, Xu, σ², collect(Float64, ℓ); device = meta.device); device = meta.device))
+        dot(ω, -0.5 * trW .* I1 .- 0.5 .* (I2 .- 1.0)) + 0.5e-7 * (trW * tr_kinv - trS)
+    end
+    return ContinuousMultivariateLogPdf(UnspecifiedDomain(), log_backwardmess)
+end
+# the per-step average energy: the reference's own method with the wrapped meta (its Ψ-statistics buffers were filled by the
+# device through psi_statistics! in the :v / :w rules of the same step)
 @average_energy MultiSGP (q_out::Any, q_in::MultivariateGaussianDistributionsFamily, q_v::MultivariateNormalDistributionsFamily, q_w::Any, q_θ::PointMass, meta::HipMultiSGPMeta) =
     ReactiveMP.score(AverageEnergy(), MultiSGP, Val{(:out, :in, :v, :w, :θ)}(), (q_out, q_in, q_v, q_w, q_θ), meta.ref)
 
