@@ -276,7 +276,7 @@ def main():
     # per statistics group, the first on all CUs, the others on the CU-masked stream -- each is timed alone with HIP events on
     # the stream (and the CUs) it uses inside the sweep; `achieved` = the sweep's SYRK flops / the sum of its launches =
     # (flops per launch) / (average launch duration), the quantity rocprofv3 --kernel-trace --stats shows for k_syrk_stream.
-    plan = dev.overlap_plan() if (world == 1 and not sweep.hooked) else []
+    plan = dev.overlap_plan()            # (hooked sweeps too: one all-reduce per statistics group, include/sgp_hip.h)
     ntiles_all = (M + 63) // 64 * ((M + 63) // 64 + 1) // 2
     # (SGP_BENCH_SKIP_ALONE: the rocprofv3 --pmc passes of tools/measure_round.sh -- every k_syrk_stream launch in their output is
     # then one of the timed sweeps' own; the stand-alone timings are skipped and the roofline block is not meaningful)
@@ -310,6 +310,7 @@ def main():
     peak_at_clock = n_cus * 4 * 32.0 * sclk_mfma * 1e6 / 1e12     # 4 SIMDs x (2048 flop / 64 cycles) per CU at the measured clock
     f1_us = tick_us(_lib.SGP_T_FINISH1)
     Qp = (M + 63) // 64 * 64
+    pack_doubles = (Qp // 64) * (Qp // 64 + 1) // 2 * 4096 + Qp + 8 + 1      # [lower 64 x 64 tiles | B | scalars | Ryy]
     chain_floor_us = Qp * PIVOT_CYCLES / sclk.value              # the pivots of one factorisation, nothing else
 
     out = {
@@ -331,7 +332,10 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: N={N} M={M} D={D} UniSGP regression, ARD-SE kernel at the trained kin40k "
                                f"hyper-parameters, w=1e4, prior N(0,50I), jitter 0",
-                   "points_per_gpu": n_loc, "parallelism": f"data-sharded x{world}, 1 all-reduce of {eng.stats.numel()} f64",
+                   "points_per_gpu": n_loc,
+                   "parallelism": f"data-sharded x{world}, " + (f"{len(plan)} all-reduces per sweep (one per statistics group) of the packed "
+                                                                f"exchange buffer, {pack_doubles} f64 in all" if (plan and sweep.hooked) else
+                                                                f"1 all-reduce of the packed exchange buffer ({pack_doubles} f64)"),
                    "variant": "W' trace form (SURVEY.md Appendix A): sum I1 / sum I2 from the reduced statistics, no per-point "
                               "TRSM / TRMM (their 2 n M^2 flop are not part of the timed sweep)",
                    "collective": {"backend": sweep.backend, "world_size_seen": sweep.world,

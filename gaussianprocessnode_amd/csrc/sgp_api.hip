@@ -95,6 +95,7 @@ enum { WORD_JOIN = 0,      // the K_uu chain of the sweep has finished (k_join_s
        WORD_GATE = 2,      // the streaming SYRK's resident round is on the CUs               -> K_uu chain's first kernel
        WORD_GRAD = 3,      // the K_uu half of the theta gradient is complete                -> k_theta_grad_finish
        WORD_ASM0 = 4,      // group 0's assembly of overlapped sweep number (value) has started     -> the masked statistics stream
+       WORD_BSUM = 5,      // B of overlapped sweep number (value) has been summed on the masked stream (k_sum_b) -> group 0's k_assemble
        WORD_GROUP0 = 8,    // + g: statistics group g of overlapped sweep number (value) is assembled -> Lambda chain, statM
        WORD_COUNT = 8 + LAM_MAX_GROUPS };
 constexpr int RESERVED_CUS_PER_SE = 2;      // of 8: the masked statistics stream runs on 6 CUs per shader engine (192 of 256)
@@ -186,6 +187,7 @@ struct sgp_handle {
     double* dXusK = nullptr;
     hipStream_t own = nullptr, side = nullptr;
     hipEvent_t evSide = nullptr, evDone = nullptr;
+    hipEvent_t evGroup[LAM_MAX_GROUPS] = {nullptr};   // data-sharded overlapped sweep: group g's reduced statistics are in place (statM -> own)
     // Overlapped sweep (plan_overlap): the statistics are produced in groups of tile rows -- the first on the sweep's own stream,
     // the others on statM, a CU-masked queue that leaves RESERVED_CUS_PER_SE compute units per shader engine to the two
     // factorisation chains -- while the Lambda chain already factors the tile columns it has.
@@ -198,6 +200,11 @@ struct sgp_handle {
     int env_overlap = -1;          // SGP_OVERLAP: 0 off, 1 on wherever it is possible; default: where the planner's model says it pays
     int env_g1_mode = 2;           // SGP_G1_AFTER (see enqueue_stats_overlapped)
     int env_syrk_wt = 0;           // SGP_SYRK_WT (see plan_overlap)
+    bool env_syrk_wide = true;     // SGP_SYRK_WIDE=0: the 256-thread SYRK everywhere (A/B switch)
+    bool env_early_b = false;      // SGP_EARLY_B=1: B summed ahead of group 0's k_assemble on the masked stream (A/B switch; measured slower)
+    bool env_kuu_asm = false;      // SGP_KUU_ASM=1: K_uu's Gram at the start of an overlapped sweep, its chain behind group 0's assembly (A/B switch; measured slower)
+    int env_syrk_wide_mode = 1;
+    bool syrk_wide = false;        // the resident problem's SYRK launches are k_syrk_stream16 (set_point_count)
     std::vector<int> env_overlap_cols;   // SGP_OVERLAP_COLS: group boundaries (tile columns of P Lambda P), e.g. "3" or "2,4"
     int nblk = 0, ntiles = 0, num_cus = 256;
     SyrkGeom geom{};               // the plain sweep's single SYRK launch over all tile rows (set_point_count)
@@ -284,16 +291,28 @@ static int quiesce(sgp_handle* h) {
 #ifndef SYRK_RESERVED_CUS
 #define SYRK_RESERVED_CUS 8
 #endif
-static SyrkGeom syrk_geometry(int row_lo, int nrows, int cus, int64_t n) {
+// wide (round 4): the launch is k_syrk_stream16 -- ONE 1024-thread workgroup per CU, whose four wave groups split the item's chunk
+// once more and add their partial tiles up in LDS: a quarter of the slabs for the same split of the point axis.  Any item count
+// works there (its block map pads to a multiple of 8); a chunk is a multiple of 4 KB points.
+static SyrkGeom syrk_geometry(int row_lo, int nrows, int cus, int64_t n, bool wide = false) {
     SyrkGeom g;
     g.row_lo = row_lo;
     g.nrows = nrows;
     g.tile0 = row_lo * (row_lo + 1) / 2;
     g.ntiles = (row_lo + nrows) * (row_lo + nrows + 1) / 2 - g.tile0;
-    g.chunk = KB;
+    g.chunk = wide ? 4 * KB : KB;
     g.nchunks = 0;
     g.write_through = 0;
+    g.wide = wide ? 1 : 0;
     if (n <= 0) return g;
+    if (wide) {
+        const int want = std::max(1, std::max(8, cus) / g.ntiles);
+        int64_t per = (n + want - 1) / want;
+        per = std::max<int64_t>(4 * KB, (per + 4 * KB - 1) / (4 * KB) * (4 * KB));
+        g.chunk = (int)per;
+        g.nchunks = (int)std::max<int64_t>(1, (n + per - 1) / per);
+        return g;
+    }
     const int slots = SYRK_BLOCKS_PER_CU * std::max(8, cus);
     int a = 8;
     for (int q = 2; q <= 8; q *= 2)
@@ -308,6 +327,15 @@ static SyrkGeom syrk_geometry(int row_lo, int nrows, int cus, int64_t n) {
     return g;
 }
 static inline size_t syrk_items(const SyrkGeom& g) { return (size_t)g.ntiles * g.nchunks; }
+static void launch_syrk(const SyrkGeom& g, hipStream_t s, const double* Kuf, const double* omega, double* slabs, int Mp, int64_t n,
+                        int64_t* stamps, long long* gate, long long gate_value) {
+    if (g.wide)
+        hipLaunchKernelGGL(k_syrk_stream16, dim3((unsigned)((syrk_items(g) + 7) / 8 * 8)), dim3(SYRK16_THREADS), 0, s, Kuf, omega, slabs, Mp, n,
+                           g, stamps, gate, gate_value);
+    else
+        hipLaunchKernelGGL(k_syrk_stream, dim3((unsigned)syrk_items(g)), dim3(256), 0, s, Kuf, omega, slabs, Mp, n, g, stamps, gate,
+                           gate_value);
+}
 
 // ------------------------------------------------------------------------------------------------
 // dense building blocks (launch sequences)
@@ -318,9 +346,11 @@ static inline size_t syrk_items(const SyrkGeom& g) { return (size_t)g.ntiles * g
 // form (may be nullptr): step 0 evaluates the matrix on the fly (Lambda = Lambda0 + W (x) Psi2, see LamForm) instead of
 // reading it from A.  Sacc (may be nullptr; needs Winv): collects Sigma = W^T W row by row during the steps
 // (sigma_row_tile); pass the same buffer to launch_ata, which then only adds the last block row.
+// step_wait (may be nullptr): step_wait[j] != nullptr makes the stream wait for that event in front of step j (data-sharded
+// overlapped sweeps: the group of tile columns that step j forms has come back from its all-reduce, see enqueue_stats_overlapped).
 static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, double* scratch, hipStream_t s,
                          double* Winv = nullptr, const LamForm* form = nullptr, double* Sacc = nullptr,
-                         const double* tv_xi = nullptr, double* tv_t = nullptr) {
+                         const double* tv_xi = nullptr, double* tv_t = nullptr, const hipEvent_t* step_wait = nullptr) {
     LamForm none;
     memset(&none, 0, sizeof none);
     none.trace_chain = form ? 1 : 0;
@@ -339,6 +369,7 @@ static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, doub
     };
     for (int j = 0; j < Tn; ++j) {
         const int nt = Tn - j;
+        if (step_wait && step_wait[j]) (void)hipStreamWaitEvent(s, step_wait[j], 0);
         hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + potrf_twins(Tn, j) + extras(j)), dim3(PSTEP_THREADS), 0, s, A, ld, j, Tn, info, n_valid,
                            scratch, Winv, Sacc, tv_xi, tv_t, form ? *form : none);      // (every step: a tile column may be formed later than step 0)
     }
@@ -512,6 +543,9 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         if (const char* ov = getenv("SGP_OVERLAP")) h->env_overlap = atoi(ov);
         if (const char* g1 = getenv("SGP_G1_AFTER")) h->env_g1_mode = atoi(g1);
         if (const char* wt = getenv("SGP_SYRK_WT")) h->env_syrk_wt = atoi(wt);
+        if (const char* sw = getenv("SGP_SYRK_WIDE")) { h->env_syrk_wide = atoi(sw) != 0; h->env_syrk_wide_mode = atoi(sw); }
+        if (const char* eb = getenv("SGP_EARLY_B")) h->env_early_b = atoi(eb) != 0;
+        if (const char* ka = getenv("SGP_KUU_ASM")) h->env_kuu_asm = atoi(ka) != 0;
         if (const char* oc = getenv("SGP_OVERLAP_COLS"))
             for (const char* q = oc; *q;) {
                 h->env_overlap_cols.push_back(atoi(q));
@@ -605,6 +639,12 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         sgp_destroy(h);
         return SGP_ERR_HIP;
     }
+    for (int g = 0; g < LAM_MAX_GROUPS; ++g)
+        if (hipEventCreateWithFlags(&h->evGroup[g], hipEventDisableTiming) != hipSuccess) {
+            g_create_error = "event creation failed";
+            sgp_destroy(h);
+            return SGP_ERR_HIP;
+        }
     // The overlapped sweep's statistics streams.  statM is a CU-masked queue (hipExtStreamCreateWithCUMask): bit i of the mask
     // is CU (i / 8 / 4) of shader engine (i / 8) % 4 of XCD i % 8 (measured with tools/cu_mask_probe.hip), so the first
     // 32 k bits are k CUs on every shader engine of every XCD -- a symmetric mask: an uneven one (e.g. 216 bits) leaves some
@@ -677,6 +717,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
     if (h->hStage) hipHostFree(h->hStage);
     if (h->evSide) hipEventDestroy(h->evSide);
     if (h->evDone) hipEventDestroy(h->evDone);
+    for (hipEvent_t e : h->evGroup) if (e) hipEventDestroy(e);
     if (h->own) hipStreamDestroy(h->own);
     if (h->side) hipStreamDestroy(h->side);
     if (h->statM) hipStreamDestroy(h->statM);
@@ -713,7 +754,10 @@ static double model_overlap_end(const sgp_handle* h, int64_t n, const int* cuts,
     // one SYRK launch = one resident round: its duration follows the points per chunk (0.18 us per point at four workgroups
     // per CU, + ~5 us of launch ramp and tail), whatever the number of tiles -- fewer CUs or an awkward tile count show up as
     // fewer, longer chunks (syrk_geometry)
-    auto syrk_us = [&](int row_lo, int nrows, int cus) { return 5.0 + 0.18 * syrk_geometry(row_lo, nrows, cus, n).chunk; };
+    auto syrk_us = [&](int row_lo, int nrows, int cus) {
+        const SyrkGeom g = syrk_geometry(row_lo, nrows, cus, n, h->syrk_wide);
+        return 5.0 + 0.18 * (g.wide ? g.chunk / 4 : g.chunk);       // (a wave group's share of the chunk)
+    };
     // assembly + gaps behind a group's SYRK (unmasked / masked); a chain step with its launch gap (18 before the step kernel's
     // rework of round 3); and how long before its step a group should be there: a step that finds its group's word unset waits
     // and then reads the statistics past the L2, element by element -- far slower than the wait alone
@@ -770,7 +814,8 @@ static void plan_overlap(sgp_handle* h, int64_t n) {
         G.nrows = G.c1 - G.c0;
         G.masked = g > 0;
         G.form_step = G.c0;
-        G.geom = syrk_geometry(G.row_lo, G.nrows, G.masked ? h->stat_cus_masked : h->num_cus, n);
+        // (SGP_SYRK_WIDE=2, A/B: the in-CU split for group 0 only -- the one on the critical path -- and the 256-thread kernel on the masked queue)
+        G.geom = syrk_geometry(G.row_lo, G.nrows, G.masked ? h->stat_cus_masked : h->num_cus, n, h->syrk_wide && !(G.masked && h->env_syrk_wide_mode == 2));
         // SGP_SYRK_WT (A/B, see k_syrk_stream): 0 plain slab stores (default), 1 write-through in the masked groups, 2 in all
         G.geom.write_through = (h->env_syrk_wt == 2 || (h->env_syrk_wt == 1 && G.masked)) ? 1 : 0;
         G.ntiles = G.geom.ntiles;
@@ -801,7 +846,9 @@ static int set_point_count(sgp_handle* h, int64_t n) {
     // two chains are the sweep, and a late K_uu chain is waited for (C1: -15 %, C5: -2 % with the gate).
     h->gate_side = n * (int64_t)h->ntiles >= 200000 && h->dJoin && !(h->cfg.flags & SGP_FLAG_GRAPH) && !h->use_chain &&
                    !h->env_no_gate;
-    h->geom = syrk_geometry(0, h->T, h->num_cus - (h->gate_side ? 0 : SYRK_RESERVED_CUS), n);
+    // (the in-CU split needs the whole LDS of a CU: only where the K_uu chain is gated behind this launch, i.e. the SYRK fills the chip)
+    h->syrk_wide = h->gate_side && h->env_syrk_wide;
+    h->geom = syrk_geometry(0, h->T, h->num_cus - (h->gate_side ? 0 : SYRK_RESERVED_CUS), n, h->syrk_wide);
     if (syrk_items(h->geom) * TB * TB > h->slab_capacity)
         return fail(h, SGP_ERR_ARG, "sgp_set_data: internal slab capacity exceeded");
     plan_overlap(h, n);
@@ -1035,8 +1082,13 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     // instead of 40 us (its last workgroups share their CUs' issue slots and L2 with the chain's).  Same-box A/B at T,
     // 2 x 1000 sweeps each: 4 312 / 4 317 sweeps/s with the gate first, 4 168 / 4 174 with the Gram first -- the starved Gram is
     // what keeps the chain off the SYRK, so the default stays.
+    // SGP_KUU_ASM=1 (round 4 experiment, off): K_uu itself at the start of an overlapped sweep -- the LDS-free k_gram_uu fits beside
+    // k_gram_uf and the SYRK -- and the FACTORISATION behind the word group 0's k_assemble sets when it starts (group 0's SYRK has
+    // drained).  Measured slower ([9] in profiles/r04_ab_log.txt: 4 215 against 4 424 sweeps/s): K_uu's Gram then runs beside
+    // group 0's SYRK with nothing to starve it, and its FP64 vector work takes the pipe from the SYRK's MFMAs (51 instead of 42 us).
     const bool gate = words && h->gate_side;
-    const bool gate_late = gate && h->env_kuu_early && !h->use_chain;
+    const bool gate_asm = gate && h->overlap_now && h->env_kuu_asm && !h->use_chain;
+    const bool gate_late = gate && (h->env_kuu_early || gate_asm) && !h->use_chain;
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->params_src,
                        h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0,
                        words ? (const long long*)(h->dJoin + WORD_DONE) : (const long long*)nullptr, h->done_epoch,
@@ -1052,11 +1104,12 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     } else
 #endif
     {
-        hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
+        if (gate && !gate_late) hipLaunchKernelGGL(k_gram_uu_lds, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
+        else hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
         // (scheduling only: giving up here costs time, not correctness, so no status bit)
         if (gate_late)
-            hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, s, (const long long*)(h->dJoin + WORD_GATE), h->gate_epoch, h->spin_limit,
-                               (int*)nullptr, 0, 9);
+            hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, s, (const long long*)(h->dJoin + (gate_asm ? WORD_ASM0 : WORD_GATE)),
+                               gate_asm ? h->stat_epoch : h->gate_epoch, h->spin_limit, (int*)nullptr, 0, 9);
         launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk, nullptr, h->dSaccK);
     }
     launch_ata(h->dWk, h->dKinv, Mp, T, s, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->dSaccK);
@@ -1091,17 +1144,16 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
 #ifdef SGP_WITH_PERSISTENT_CHAIN
         if (h->use_chain) gate = h->dChainFlags[0] + CH_F_GATE;
 #endif
-        hipLaunchKernelGGL(k_syrk_stream, dim3((unsigned)syrk_items(h->geom)), dim3(256), 0, s, h->dKuf,
-                           h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->geom,
-                           h->dStamps + STAMP_STRIDE * SGP_T_SYRK, gate, h->gate_epoch);
+        launch_syrk(h->geom, s, h->dKuf, h->has_omega ? h->dOmega : nullptr, h->dSlabs, Mp, h->n, h->dStamps + STAMP_STRIDE * SGP_T_SYRK,
+                    gate, h->gate_epoch);
     }
     SyrkGeom ga = h->geom;
     if (h->n <= 0) { ga = syrk_geometry(0, T, h->num_cus, 0); }       // no data: zero chunks, the statistics are zero
     // (data-sharded sweeps write the exchange buffer instead: lower tiles only, see exchange_stats)
-    hipLaunchKernelGGL(k_assemble, dim3(T, T + 1, 16), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal,
+    hipLaunchKernelGGL(k_assemble, dim3(T, T + 1, 4), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal,
                        h->pack_now ? h->dPack : h->dStats, Mp, T, ga, h->n > 0 ? h->nblk : 0, h->dout,
                        SGP_S_COUNT + h->dout * h->dout, 1, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL, h->dInfo + 1, (long long*)nullptr, 0LL,
-                       h->pack_now ? 1 : 0, h->dBred);
+                       h->pack_now ? 1 : 0, h->dBred, (const long long*)nullptr, 0LL, h->spin_limit, (int*)nullptr);
 }
 
 // The statistics of an overlapped sweep (see plan_overlap): the same kernels, the SYRK and the assembly once per tile-row group.
@@ -1111,9 +1163,18 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
 // sets (group 0's SYRK has drained), a k_join_set behind each masked group's k_assemble writes the sweep's number into the
 // group's word (the kernel boundary in front of it makes the statistics visible device-wide), and the chain step that forms the
 // group polls that word.
-static void enqueue_stats_overlapped(sgp_handle* h, hipStream_t own) {
+static int exchange_stats(sgp_handle* h, hipStream_t s, int tile0, int ntile, bool with_tail);
+// Data-sharded (an all-reduce hook is installed; round 4): the same schedule with ONE reduce per group, on the group's own stream --
+// k_assemble writes the group's lower tiles into the exchange buffer, the hook sums that piece over the ranks (group 0's piece
+// also carries B and the scalars: the last tile rows of Psi2 sit next to the buffer's tail), k_unpack_stats expands it.  Group 0's
+// reduce is in front of the chain in plain stream order; a masked group's is published by an EVENT recorded behind its unpack, and
+// the sweep's stream waits for it in front of the chain step that forms the group (launch_potrf's step_wait) -- not by a device
+// word: words are waited for with a bounded spin, and a collective that builds its rings or waits for a straggler rank may take
+// longer than that.  The chain therefore starts after (statistics of group 0 -> reduce of 0.6 MB) instead of (all statistics ->
+// reduce of 1.18 MB), and the second reduce runs beside it.  Every rank calls the hook in the same order (group 0, 1, ...).
+static int enqueue_stats_overlapped(sgp_handle* h, hipStream_t own) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
-    ++h->stat_epoch;
+    const bool sharded = h->allreduce != nullptr;
     // (as in enqueue_local: a sweep at unchanged parameters starts with the Gram kernel)
     const bool prep = h->main_prep_gen != h->params_gen;
     if (prep) {
@@ -1128,23 +1189,43 @@ static void enqueue_stats_overlapped(sgp_handle* h, hipStream_t own) {
     // CUs as they drain, but group 0's assembly shares them with it: 12.7 instead of 8.7 us on the critical path);
     // 1 = when group 0 is assembled (the chains' whole-CU workgroups settle on the idle masked CUs meanwhile and the masked
     // SYRK no longer fits its single round).  Sweeps/s at T on one box: 3978 / 3975 / 3865.
-    const int g1_mode = h->env_g1_mode;
+    const int g1_mode = sharded ? 2 : h->env_g1_mode;
     const long long* g1_word = h->dJoin + (g1_mode == 0 ? WORD_GATE : (g1_mode == 1 ? WORD_GROUP0 : WORD_ASM0));
+    // B = K_uf (omega o y) does not wait for the SYRK: its partials are complete when k_gram_uf is, so the masked stream -- idle until
+    // group 0's SYRK has drained -- sums them as soon as that SYRK's round is resident (the gate word: k_gram_uf precedes it on the
+    // sweep's stream), and group 0's k_assemble, in front of the Lambda chain, loses the longest thing it did (three dependent
+    // round trips over 157 partial rows).  It only checks the word k_join_set writes behind k_sum_b.
+    // MEASURED (profiles/r04_ab_log.txt [8]) and off by default: the three extra launches sit in front of the masked stream's wait for
+    // group 0's assembly and the masked SYRK starts ~8 us late -- the forming step then waits for its group (chain 159 instead of
+    // 148 us, 4 235 instead of 4 430 sweeps/s) -- while k_assemble without its B role is no shorter (7.2 us either way: it is the
+    // slab reads and the scattered tile stores).
+    const bool early_b = h->env_early_b;
+    if (early_b) {
+        hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, h->statM, (const long long*)(h->dJoin + WORD_GATE), h->gate_epoch, h->spin_limit,
+                           h->dInfo + 3, (int)SYNC_LATE_COLUMN, 10);
+        hipLaunchKernelGGL(k_sum_b, dim3(T * h->dout), dim3(256), 0, h->statM, (const double*)h->dBpart, sharded ? h->dPack : h->dStats, h->dBred,
+                           Mp, T, h->nblk, h->dout, sharded ? 1 : 0);
+        hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, h->statM, h->dJoin + WORD_BSUM, h->stat_epoch);
+    }
     hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, h->statM, g1_word, g1_mode == 0 ? h->gate_epoch : h->stat_epoch,
                        h->spin_limit, h->dInfo + 3, (int)SYNC_LATE_COLUMN, 8);
     for (int g = 0; g < h->ngroups; ++g) {
         const StatGroup& G = h->grp[g];
         hipStream_t s = G.masked ? h->statM : own;
-        hipLaunchKernelGGL(k_syrk_stream, dim3((unsigned)syrk_items(G.geom)), dim3(256), 0, s, h->dKuf, h->has_omega ? h->dOmega : nullptr,
-                           h->dSlabs + G.slab_off, Mp, h->n, G.geom,
-                           h->dStamps + STAMP_STRIDE * SGP_T_SYRK, g == 0 ? h->dJoin + WORD_GATE : (long long*)nullptr, h->gate_epoch);
-        hipLaunchKernelGGL(k_assemble, dim3(G.nrows, T + (g == 0 ? 1 : 0), 16), dim3(256), 0, s, h->dSlabs + G.slab_off, h->dBpart,
-                           h->dDataScal, h->dStats, Mp, T, G.geom, h->nblk, h->dout,
-                           SGP_S_COUNT + h->dout * h->dout, g == 0 ? 1 : 0, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL,
-                           g == 0 ? h->dInfo + 1 : (int*)nullptr, g == 0 ? h->dJoin + WORD_ASM0 : (long long*)nullptr, h->stat_epoch, 0,
-                           h->dBred);
-        if (G.masked || g1_mode == 1) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_GROUP0 + g, h->stat_epoch);
+        launch_syrk(G.geom, s, h->dKuf, h->has_omega ? h->dOmega : nullptr, h->dSlabs + G.slab_off, Mp, h->n,
+                    h->dStamps + STAMP_STRIDE * SGP_T_SYRK, g == 0 ? h->dJoin + WORD_GATE : (long long*)nullptr, h->gate_epoch);
+        hipLaunchKernelGGL(k_assemble, dim3(G.nrows, T + (g == 0 ? 1 : 0), 4), dim3(256), 0, s, h->dSlabs + G.slab_off, h->dBpart,
+                           h->dDataScal, sharded ? h->dPack : h->dStats, Mp, T, G.geom, h->nblk, h->dout,
+                           SGP_S_COUNT + h->dout * h->dout, g == 0 ? (early_b ? 2 : 1) : 0, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL,
+                           g == 0 ? h->dInfo + 1 : (int*)nullptr, g == 0 ? h->dJoin + WORD_ASM0 : (long long*)nullptr, h->stat_epoch,
+                           sharded ? 1 : 0, h->dBred, (const long long*)(h->dJoin + WORD_BSUM), h->stat_epoch, h->spin_limit, h->dInfo + 3);
+        if (sharded) {
+            if (int xrc = exchange_stats(h, s, G.geom.tile0, G.geom.ntiles, g == 0)) return xrc;
+            if (G.masked && hipEventRecord(h->evGroup[g], s) != hipSuccess) return fail(h, SGP_ERR_HIP, "hipEventRecord failed (statistics group)");
+        } else if (G.masked || g1_mode == 1)
+            hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_GROUP0 + g, h->stat_epoch);
     }
+    return 0;
 }
 
 static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
@@ -1161,18 +1242,23 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
     form.spin_limit = h->spin_limit;
     form.sync_status = h->dInfo + 3;
     form.trace_chain = 1;
+    hipEvent_t step_wait[LAM_MAX_COLS] = {nullptr};
+    bool any_wait = false;
     if (h->overlap_now) {
         // the statistics arrive group by group while the chain runs (enqueue_stats_overlapped): step G.form_step forms group G.
         // Group 0 was summed on this very stream: nothing to wait for.  (A step 0 resident from the start of the sweep and
         // waiting for its statistics itself was measured too: on T + 1 CUs it keeps group 0's SYRK from its full single round,
         // 54 instead of 35 us.)
+        // (data-sharded: the masked groups arrive through events the stream waits for in front of their forming step -- nothing
+        // for the kernel to poll, every column is "in stream order")
         form.col_words = h->dJoin + WORD_GROUP0;
         form.col_need = h->stat_epoch;
         for (int g = 0; g < h->ngroups; ++g) {
             for (int c = h->grp[g].c0; c < h->grp[g].c1; ++c) {
                 form.form_step[c] = (unsigned char)h->grp[g].form_step;
-                form.col_group[c] = h->grp[g].masked ? (unsigned char)g : (unsigned char)0xff;
+                form.col_group[c] = (h->grp[g].masked && !h->allreduce) ? (unsigned char)g : (unsigned char)0xff;
             }
+            if (h->grp[g].masked && h->allreduce) { step_wait[h->grp[g].form_step] = h->evGroup[g]; any_wait = true; }
         }
     }
     double* uvt0 = h->dUvWork + 2 * (size_t)Qp;     // t = W' P xi, advanced block by block during the factorisation
@@ -1182,7 +1268,8 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
         launch_chain(h, 1, h->dLam, h->dLamAlt, Qp, TQ, h->dInfo + 1, Qp, s, h->dWl, &form, h->dTmp, h->dXi, uvt0, nullptr, nullptr, 0, 0);
     } else
 #endif
-        launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + POTRF_SCRATCH, s, h->dWl, &form, h->dTmp, h->dXi, uvt0);
+        launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + POTRF_SCRATCH, s, h->dWl, &form, h->dTmp, h->dXi, uvt0,
+                     any_wait ? step_wait : nullptr);
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
     // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
     double* uvp = h->dXi;                    // xi is consumed by the forward solve; p lands in the same vector afterwards
@@ -1314,7 +1401,7 @@ static int sweep_local_impl(sgp_handle* h, void* stream, bool overlapped) {
     // the words are waited for with a BOUNDED spin (~1 s), and a collective that builds its rings or waits for a straggler
     // rank may take longer than that.
     const bool graph = (h->cfg.flags & SGP_FLAG_GRAPH) != 0;
-    const bool hooked = h->allreduce != nullptr && !overlapped;
+    const bool hooked = h->allreduce != nullptr;
     h->dev_words = !graph;
     // (a caller's stream as well: two-phase callers -- sgp_sweep_local, their own reduce, sgp_sweep_finish -- may sit in a collective
     // between the halves for longer than the bounded words wait, exactly like the hook)
@@ -1332,22 +1419,34 @@ static int sweep_local_impl(sgp_handle* h, void* stream, bool overlapped) {
         ++h->join_epoch;
     }
     ++h->gate_epoch;
+    if (overlapped) ++h->stat_epoch;                            // (what the words of this sweep's statistics groups receive)
 #ifdef SGP_WITH_PERSISTENT_CHAIN
     h->gate_kuu = h->use_chain && h->n > 0;                    // (a SYRK launch follows on the main stream and opens the gate)
 #endif
+    // Host order of the enqueues.  The K_uu chain is 14 launches (~50 us of host time).  Where it is gated behind the SYRK anyway
+    // (gate_side) the data-sized kernels go out FIRST: a sweep that starts on an idle GPU -- the drop-in's pattern: sweep, fetch
+    // something, next sweep -- otherwise has its Gram kernel wait ~50 us for the host to get through launches the GPU cannot run
+    // yet.  (Back-to-back sweeps are enqueued a sweep ahead either way.)  Small problems keep the chain first: there the two chains
+    // are the sweep.  With an all-reduce hook too: the hook is a host callback that may block (gloo), the chain should be queued by then.
+    const bool stats_first = h->gate_side && h->n > 0 && !graph && !h->allreduce;
+    auto enqueue_stats = [&]() -> int {
+        if (overlapped) {
+            if (int orc = enqueue_stats_overlapped(h, s)) return orc;
+            HIPCHK(h, hipGetLastError());
+            return 0;
+        }
+        return run_sequence(h, h->gLocal, enqueue_local, s);
+    };
+    if (stats_first)
+        if (int src = enqueue_stats()) return src;
     rc = run_sequence(h, h->gKuu, enqueue_kuu, h->side);
 #ifdef SGP_WITH_PERSISTENT_CHAIN
     h->gate_kuu = false;
 #endif
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->evSide, h->side));
-    if (overlapped) {
-        enqueue_stats_overlapped(h, s);
-        HIPCHK(h, hipGetLastError());
-    } else {
-        rc = run_sequence(h, h->gLocal, enqueue_local, s);
-        if (rc) return rc;
-    }
+    if (!stats_first)
+        if (int src = enqueue_stats()) return src;
     h->stats_dirty = false;
     h->swept_params = *h->hParams;
     h->swept_data_gen = h->data_gen;
@@ -1380,23 +1479,32 @@ extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
 // The one exchange step of a data-sharded sweep: the ranks sum the exchange buffer k_assemble just wrote -- the LOWER tiles of
 // Psi2, B and the scalars: 1.18 MB at M = 512 where the full symmetric statistics are 2.10 MB -- through the hook, on the sweep's
 // stream (the K_uu chain keeps running on the side stream meanwhile); one more launch expands the sum into the statistics buffer.
-static int exchange_stats(sgp_handle* h, hipStream_t s) {
-    if (h->allreduce(h->allreduce_ctx, h->dPack, h->pack_count, s)) return fail(h, SGP_ERR_HIP, "the all-reduce hook failed (statistics)");
-    hipLaunchKernelGGL(k_unpack_stats, dim3(h->ntiles + 1), dim3(256), 0, s, (const double*)h->dPack, h->dStats, h->Mp, h->T,
-                       (int)(h->Mp * h->dout + SGP_S_COUNT + h->dout * h->dout));
+// (tile0, ntile: the lower tiles of the piece, in the row-major triangle order of the exchange buffer; with_tail: B and the scalars,
+// which follow the last tile, travel with it -- the whole buffer in the plain order, one piece per statistics group in the
+// overlapped order, the first group's piece being [its tiles | B | scalars]: the LAST tile rows of Psi2 sit next to the tail)
+static int exchange_stats(sgp_handle* h, hipStream_t s, int tile0, int ntile, bool with_tail) {
+    const int tail = (int)(h->Mp * h->dout + SGP_S_COUNT + h->dout * h->dout);
+    const int64_t count = (int64_t)ntile * TB * TB + (with_tail ? tail : 0);
+    if (with_tail && tile0 + ntile != h->ntiles) return fail(h, SGP_ERR_ARG, "internal: the tail of the exchange buffer follows its last tile");
+    if (h->allreduce(h->allreduce_ctx, h->dPack + (size_t)tile0 * TB * TB, count, s))
+        return fail(h, SGP_ERR_HIP, "the all-reduce hook failed (statistics)");
+    hipLaunchKernelGGL(k_unpack_stats, dim3(ntile + 1), dim3(256), 0, s, (const double*)h->dPack, h->dStats, h->Mp, h->T,
+                       with_tail ? tail : 0, tile0, ntile);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
+static int exchange_stats(sgp_handle* h, hipStream_t s) { return exchange_stats(h, s, 0, h->ntiles, true); }
 
 extern "C" int sgp_sweep(sgp_handle* h, void* stream) {
     if (!h) return SGP_ERR_ARG;
     // single GPU, the library's own streams, a problem that qualifies: statistics and Lambda chain overlapped
-    const bool overlapped = h->overlap && !h->allreduce && !stream && h->n > 0 && !h->training;
+    // (with an all-reduce hook as well: one reduce per statistics group, see enqueue_stats_overlapped)
+    const bool overlapped = h->overlap && !stream && h->n > 0 && !h->training;
     h->pack_now = h->allreduce != nullptr;
     int rc = sweep_local_impl(h, stream, overlapped);
     h->pack_now = false;
     if (rc) return rc;
-    if (h->allreduce) {
+    if (h->allreduce && !overlapped) {
         rc = exchange_stats(h, stream ? static_cast<hipStream_t>(stream) : h->own);
         if (rc) return rc;
     }
@@ -1727,8 +1835,8 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
             hipLaunchKernelGGL(k_quadform_fused, dim3(h->nblk, h->T), dim3(256), 0, s, h->dWk, h->dUvT, h->dKuf, h->dMu, h->dPa, h->dPb,
                                h->dKmu, h->Mp, h->T, h->n);
         else if (G)
-            hipLaunchKernelGGL(k_syrk_stream, dim3((unsigned)syrk_items(G->geom)), dim3(256), 0, s, h->dKuf, h->has_omega ? h->dOmega : nullptr,
-                               h->dSlabs + G->slab_off, h->Mp, h->n, G->geom, (int64_t*)nullptr, (long long*)nullptr, 0LL);
+            launch_syrk(G->geom, s, h->dKuf, h->has_omega ? h->dOmega : nullptr, h->dSlabs + G->slab_off, h->Mp, h->n, (int64_t*)nullptr,
+                        (long long*)nullptr, 0LL);
         else if (which == SGP_T_GRAM && h->D <= 8)
             hipLaunchKernelGGL(k_gram_uf<8>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr, (int64_t*)nullptr);
@@ -1736,9 +1844,8 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
             hipLaunchKernelGGL(k_gram_uf<MAXD>, dim3(h->nblk, h->T), dim3(256), 0, s, h->dXus, h->dX, h->dYw, h->dKuf, h->dBpart,
                                h->dParams, h->M, h->Mp, h->D, h->n, h->dout, (int64_t*)nullptr, (int64_t*)nullptr);
         else
-            hipLaunchKernelGGL(k_syrk_stream, dim3((unsigned)syrk_items(h->geom)), dim3(256), 0, s, h->dKuf,
-                               h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, h->geom,
-                               (int64_t*)nullptr, (long long*)nullptr, 0LL);
+            launch_syrk(h->geom, s, h->dKuf, h->has_omega ? h->dOmega : nullptr, h->dSlabs, h->Mp, h->n, (int64_t*)nullptr,
+                        (long long*)nullptr, 0LL);
     };
     if (!G && qmode < 0 && which != SGP_T_GRAM && which != SGP_T_SYRK)
         return fail(h, SGP_ERR_ARG, "sgp_time_kernel: which must be SGP_T_GRAM, SGP_T_SYRK or SGP_TIME_GROUP0 + g");
@@ -1758,7 +1865,7 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
 // points per chunk, 1 if it runs on the CU-masked stream, CUs it may use, the Lambda-chain step that forms it.
 extern "C" int sgp_overlap_plan(const sgp_handle* h, int32_t* ngroups, int32_t* info) {
     if (!h || !ngroups) return SGP_ERR_ARG;
-    const bool on = h->overlap && !h->allreduce && !h->training;
+    const bool on = h->overlap && !h->training;
     *ngroups = on ? h->ngroups : 0;
     if (!on || !info) return 0;
     for (int g = 0; g < h->ngroups; ++g) {

@@ -237,7 +237,13 @@ __global__ void k_prep_xu(const double* __restrict__ Xu, double* __restrict__ Xu
 // ------------------------------------------------------------------------------------------------
 // K_uu (+ jitter I), padded with the identity.  One 64 x 64 tile per block, 16 entries per thread.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_gram_uu(const double* __restrict__ Xus, double* __restrict__ Kuu,
+// Two forms.  k_gram_uu_lds (coordinate panels in 32 KB of LDS) is what a sweep whose SYRK fills the chip launches: it is queued
+// behind the gate, i.e. while that SYRK holds every byte of LDS, and therefore gets a CU only as SYRK workgroups leave -- which is
+// the point: FP64 vector work beside the SYRK takes the FP64 pipe from its MFMAs, and that SYRK is on the sweep's critical path
+// (round 4, profiles/r04_ab_log.txt [9]: the LDS-free form beside it, 51 instead of 42 us for group 0's launch).  k_gram_uu (no
+// LDS; thread = row i with its D coordinates in registers, a column's coordinates wave-uniform scalar loads) is for the small
+// problems, where the K_uu chain starts with the sweep and nothing is there to wait for (C1: 20 300 instead of 17 500 sweeps/s).
+__global__ void __launch_bounds__(256) k_gram_uu_lds(const double* __restrict__ Xus, double* __restrict__ Kuu,
                                                  const Params* __restrict__ P, int M, int Mp, int D) {
     __shared__ double ui[MAXD * TB];
     __shared__ double uj[MAXD * TB];
@@ -257,6 +263,31 @@ __global__ void __launch_bounds__(256) k_gram_uu(const double* __restrict__ Xus,
         double d2 = 0.0;
         for (int d = 0; d < D; ++d) { double t = ui[d * TB + i] - uj[d * TB + j]; d2 = fma(t, t, d2); }
         int gi = I + i, gj = J + j;
+        double v;
+        if (gi < M && gj < M) v = s2 * exp(-0.5 * d2) + (gi == gj ? jit : 0.0);
+        else v = (gi == gj) ? 1.0 : 0.0;
+        Kuu[(size_t)gj * Mp + gi] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gram_uu(const double* __restrict__ Xus, double* __restrict__ Kuu,
+                                                 const Params* __restrict__ P, int M, int Mp, int D) {
+    TraceScope trace(3);
+    const int I = blockIdx.x * TB, J = blockIdx.y * TB;
+    const int i = threadIdx.x & 63;
+    const int jg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double ui[MAXD];
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) ui[d] = (d < D) ? Xus[(size_t)d * Mp + I + i] : 0.0;
+    const double s2 = P->sigma2, jit = P->jitter;
+    const int gi = I + i;
+    for (int jj = 0; jj < 16; ++jj) {
+        const int gj = J + jg * 16 + jj;
+        const double* uj = Xus + gj;                                   // (wave-uniform address)
+        double d2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < MAXD; ++d)
+            if (d < D) { const double t = ui[d] - uj[(size_t)d * Mp]; d2 = fma(t, t, d2); }
         double v;
         if (gi < M && gj < M) v = s2 * exp(-0.5 * d2) + (gi == gj ? jit : 0.0);
         else v = (gi == gj) ? 1.0 : 0.0;
@@ -565,6 +596,9 @@ __device__ __forceinline__ void syrk_item(const double* __restrict__ Kuf, const 
         if (s + 1 < stages) lstore(buf ^ 1);
         __syncthreads();
     }
+#ifdef SGP_EXP_QUARTER_SLABS      // timing experiment only (results are wrong): what would a quarter of the slab traffic buy?
+    if (chunk_id & 3) return;
+#endif
     if constexpr (!DIAG) {
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
@@ -614,6 +648,7 @@ struct SyrkGeom {
     int tile0, ntiles;              // their lower tiles
     int chunk, nchunks;             // split of the point axis
     int write_through;              // slabs stored past the L2 (launches that run beside the factorisation chains)
+    int wide;                       // 1: launched as k_syrk_stream16 (one 1024-thread workgroup per CU, `chunk` points = 4 sub-chunks)
 };
 __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
                                                      double* __restrict__ slabs, int Mp, int64_t N, SyrkGeom g, int64_t* stamps,
@@ -650,29 +685,209 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same work item with the split of the point axis continued INSIDE the workgroup (round 4): 1024 threads = four groups of four
+// waves; group q streams sub-chunk q of the item's chunk exactly as a 256-thread workgroup of k_syrk_stream would (its own
+// double-buffered LDS panels: the CU holds the same 16 waves and the same LDS as with four 256-thread workgroups), and the four
+// partial tiles meet in LDS at the end -- summed in fixed order -- so that ONE slab leaves the CU instead of four.  The slabs were
+// the sweep's wasted traffic (123 MB per sweep against 43 MB algorithmic): 1 728 slabs of 32 KB written by the two
+// group launches and read back by k_assemble, whose 7 us in front of the Lambda chain are those reads.
+// LDS: four groups x 2 buffers x 2 panels x KB x PS doubles = 163 840 bytes, all a CU has; the reduction reuses it (a group's
+// 64 x 64 partial tile fits in its own 40 960 bytes).
+constexpr int PSS = PS;
+constexpr int SYRK16_THREADS = 1024;
+__global__ void __launch_bounds__(SYRK16_THREADS) k_syrk_stream16(const double* __restrict__ Kuf, const double* __restrict__ omega,
+                                                                  double* __restrict__ slabs, int Mp, int64_t N, SyrkGeom g,
+                                                                  int64_t* stamps, long long* gate, long long gate_value) {
+    __shared__ __attribute__((aligned(16))) double lds[4 * 2 * 2 * KB * PSS];
+    TraceScope trace(64 + g.tile0);
+    stamp_enter(stamps);
+    // XCD-aware block -> item map for ANY item count: the items, ordered chunk-major, are cut into 8 runs of `per` items, one per
+    // XCD (workgroups are dealt round-robin over the XCDs); the grid has 8 * per blocks, the surplus ones leave
+    const int nitems = g.ntiles * g.nchunks, per = (nitems + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (gate && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        __hip_atomic_store(gate, gate_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (item >= nitems) return;                       // (whole workgroup: no barrier is left behind)
+    const int chunk_id = item / g.ntiles, tile_id = item % g.ntiles;
+    int I, J;
+    tile_from_index(g.tile0 + tile_id, I, J);
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int sub = g.chunk >> 2;                     // points per group (a multiple of KB)
+    const int64_t nbeg = (int64_t)chunk_id * g.chunk + (int64_t)grp * sub;
+    int64_t nend = nbeg + sub;
+    if (nend > N) nend = N;
+    // every group runs the SAME number of stages (the workgroup barrier below is shared): the longest group's, empty stages are zeros
+    const int64_t wg_beg = (int64_t)chunk_id * g.chunk;
+    const int64_t wg_len = (N > wg_beg) ? ((N - wg_beg < (int64_t)sub) ? (N - wg_beg) : (int64_t)sub) : 0;
+    const int stages = (int)((wg_len + KB - 1) / KB);
+    double* my = lds + grp * (2 * 2 * KB * PSS);
+    const int p = tid >> 4, rq = tid & 15;            // staging map: thread -> (point p, row quad rq): 32 B of one K_uf column
+    Acc4 acc;
+    acc_zero(acc);
+    double ra[4], rb[4];
+    auto gload = [&](int s) {
+        const int64_t n = nbeg + (int64_t)s * KB + p;
+        if (n < nend) {
+            const double* src = Kuf + (size_t)n * Mp + I * TB + rq * 4;
+            const double2 v0 = *reinterpret_cast<const double2*>(src), v1 = *reinterpret_cast<const double2*>(src + 2);
+            ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
+            const double w = omega ? omega[n] : 1.0;
+            if (I != J) {
+                const double* sb = Kuf + (size_t)n * Mp + J * TB + rq * 4;
+                const double2 u0 = *reinterpret_cast<const double2*>(sb), u1 = *reinterpret_cast<const double2*>(sb + 2);
+                rb[0] = u0.x * w; rb[1] = u0.y * w; rb[2] = u1.x * w; rb[3] = u1.y * w;
+            } else {
+                rb[0] = ra[0] * w; rb[1] = ra[1] * w; rb[2] = ra[2] * w; rb[3] = ra[3] * w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ra[q] = 0.0; rb[q] = 0.0; }
+        }
+    };
+    auto lstore = [&](int buf) {
+        double* A = my + buf * (2 * KB * PSS) + p * PSS + rq * 4;
+        double* B = A + KB * PSS;
+        *reinterpret_cast<double2*>(A) = make_double2(ra[0], ra[1]);
+        *reinterpret_cast<double2*>(A + 2) = make_double2(ra[2], ra[3]);
+        *reinterpret_cast<double2*>(B) = make_double2(rb[0], rb[1]);
+        *reinterpret_cast<double2*>(B + 2) = make_double2(rb[2], rb[3]);
+    };
+    // The four groups are independent pipelines: a workgroup barrier per stage would make all sixteen waves wait for the slowest
+    // group's loads (measured: 44.7 instead of 41.9 us for group 0's launch, 57 instead of 45 for the masked one).  Each group meets
+    // on its own LDS counter instead -- lane 0 of a wave adds one behind the wave's LDS stores (a wave's LDS instructions execute in
+    // order, so the add follows them), everyone polls until the four adds of this round are in.  The counters sit in the unused
+    // padding columns of the very last panel row (there is no other LDS left).
+#ifndef SGP_SYRK16_WG_BARRIER
+    typedef __attribute__((address_space(3))) unsigned lds_uint;
+    lds_uint* cnt = (lds_uint*)(lds + 4 * 2 * 2 * KB * PSS - 2) + grp;
+    if (threadIdx.x < 4) ((lds_uint*)(lds + 4 * 2 * 2 * KB * PSS - 2))[threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned epoch = 0;
+    auto group_sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        epoch += 4;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+#else
+    auto group_sync = [&]() { __syncthreads(); };
+#endif
+    if (stages > 0) {
+        gload(0);
+        lstore(0);
+    }
+    group_sync();
+    const int li = lane & 15, lk = lane >> 4;
+    for (int s = 0; s < stages; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < stages) gload(s + 1);
+        const double* ap = my + buf * (2 * KB * PSS) + lk * PSS + wr * 32 + li;
+        const double* bp = ap + KB * PSS + (wc - wr) * 32;
+#pragma unroll
+        for (int k = 0; k < KB; k += 4) {
+            const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
+            acc.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.t[0][0], 0, 0, 0);
+            acc.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.t[0][1], 0, 0, 0);
+            acc.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.t[1][0], 0, 0, 0);
+            acc.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.t[1][1], 0, 0, 0);
+            ap += 4 * PSS;
+            bp += 4 * PSS;
+        }
+        if (s + 1 < stages) lstore(buf ^ 1);
+        group_sync();
+    }
+    // the four partial tiles meet in LDS ([i][j], 64 doubles per row, each group in its own region), summed in the order of the
+    // sub-chunks; thread t of the workgroup owns entries 4 t .. 4 t + 3 of the slab (two 16-byte stores)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) my[acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj)] = acc.t[ti][tj][r];
+    __syncthreads();
+    {
+        const int e = 4 * (int)threadIdx.x;
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double* src = lds + q * (2 * 2 * KB * PSS) + e;
+            const double2 x0 = *reinterpret_cast<const double2*>(src), x1 = *reinterpret_cast<const double2*>(src + 2);
+            v[0] += x0.x; v[1] += x0.y; v[2] += x1.x; v[3] += x1.y;
+        }
+        double* out = slabs + ((size_t)chunk_id * g.ntiles + tile_id) * (TB * TB) + e;
+        *reinterpret_cast<double2*>(out) = make_double2(v[0], v[1]);
+        *reinterpret_cast<double2*>(out + 2) = make_double2(v[2], v[3]);
+    }
+    stamp_exit(stamps);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sum the SYRK slabs and the B partials into the packed statistics buffer (the all-reduce payload):
 //   stats = [Psi2 (Mp x Mp, full symmetric) | B (Mp x d_out) | scalars]
 // ------------------------------------------------------------------------------------------------
+// B = sum of the per-block partials of k_gram_uf: workgroup `bid` of `nb` takes the (row block, output) pairs bid, bid + nb, ...;
+// 4 threads per entry -- one per wave, so that a wave reads 512-byte runs -- walk the partials with a stride of 4, up to 32
+// independent loads in flight (round 3 had 16: three dependent round trips for the 157 partial rows of N = 10 000, the longest
+// thing k_assemble did), and are combined in a fixed order.  The four waves meet through a few hundred bytes of GLOBAL scratch
+// (`bscratch`, written, workgroup barrier, read back by wave 0 on the same CU), not through LDS: any LDS in a launch that runs
+// beside a SYRK keeps a fourth SYRK workgroup off every CU that still holds one of its blocks, and the next group's SYRK then
+// needs a second round (measured: +15 us on the statistics).  (Four adjacent lanes per entry and shuffles instead: 430 instead
+// of 180 us for the 15 625 partial rows of N = 10^6.)
+__device__ __forceinline__ void sum_b_pairs(const double* __restrict__ bpart, double* __restrict__ B, double* __restrict__ bscratch,
+                                            int Mp, int T, int nblk, int d_out, int bid, int nb) {
+    const int tid = threadIdx.x, m = tid & 63, part = tid >> 6;
+    for (int pair = bid; pair < T * d_out; pair += nb) {
+        const int Ib = pair % T, o = pair / T;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        int b = part;
+        for (; b + 124 < nblk; b += 128) {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + Ib * TB + m];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc[u & 3] += v[u];
+        }
+        for (; b + 28 < nblk; b += 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + Ib * TB + m];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u & 3] += v[u];
+        }
+        for (; b < nblk; b += 4) acc[0] += bpart[((size_t)b * d_out + o) * Mp + Ib * TB + m];
+        double* red = bscratch + (size_t)pair * (4 * TB);
+        red[part * TB + m] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        __syncthreads();                                     // (waits for the stores: a workgroup-scope release)
+        if (part == 0) B[(size_t)o * Mp + Ib * TB + m] = (red[m] + red[TB + m]) + (red[2 * TB + m] + red[3 * TB + m]);
+    }
+}
+// B on its own (overlapped sweep): launched on the masked statistics stream as soon as k_gram_uf has finished, beside group 0's SYRK
+// -- no LDS, so it fits on CUs whose LDS that SYRK holds.  `packed`: into the exchange buffer's tail (data-sharded sweeps).
+__global__ void __launch_bounds__(256) k_sum_b(const double* __restrict__ bpart, double* __restrict__ stats, double* __restrict__ bscratch,
+                                               int Mp, int T, int nblk, int d_out, int packed) {
+    double* B = stats + (packed ? (size_t)(T * (T + 1) / 2) * (TB * TB) : (size_t)Mp * Mp);
+    sum_b_pairs(bpart, B, bscratch, Mp, T, nblk, d_out, (int)blockIdx.x, (int)gridDim.x);
+}
+
 __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ slabs, const double* __restrict__ bpart,
                                                   const double* __restrict__ data_scalars, double* __restrict__ stats,
                                                   int Mp, int T, SyrkGeom g, int nblk, int d_out,
                                                   int nscal, int do_b, int64_t* stamps, int* __restrict__ info_reset,
                                                   long long* start_word, long long start_value, int packed,
-                                                  double* __restrict__ bscratch) {
-    // grid (rows, T + do_b, 16): blocks (x, y < T, z) sum rows [4 z, 4 z + 4) of the slab tile (I, J) = (row_lo + x, y), I >= J --
-    // one entry per thread, up to 12 chunk loads in flight (the kernel is latency-bound: the first version, 4 entries per
-    // thread in rounds of 4 chunks on a quarter of the workgroups, took 12 us for 28 MB) -- and write both mirror images.
+                                                  double* __restrict__ bscratch, const long long* b_word, long long b_need,
+                                                  int spin_limit, int* sync_status) {
+    // grid (rows, T + do_b, 4): blocks (x, y < T, z) sum rows [16 z, 16 z + 16) of the slab tile (I, J) = (row_lo + x, y), I >= J --
+    // four entries per thread (see below), 48 loads in flight -- and write both mirror images.
     // `slabs` / `g`: the slab area and geometry of this launch's tile rows (k_syrk_stream).  Blocks with y == T (do_b) sum the
     // B partials and copy the data scalars.
     // packed (data-sharded sweeps): `stats` is the exchange buffer [lower tiles, row-major triangle, 64 x 64 column-major each |
     // B | scalars] -- what the ranks sum-all-reduce (1.18 MB at M = 512 instead of the 2.10 MB of the full symmetric matrix);
     // k_unpack_stats expands the reduced buffer into the layout the rest of the sweep reads.
     // NO LDS on purpose: in the overlapped sweep this kernel runs while the NEXT group's SYRK already holds every byte of LDS on
-    // its CUs (4 x 40 KB); a block that needs none fits beside those workgroups.  Thread = (row il = tid >> 6, column j = tid & 63):
-    // a wave reads one 512-byte slab row per chunk and writes the mirror image (the upper triangle -- the part the Lambda chain
-    // and the trace epilogue read) as one 512-byte run; the tile itself goes out as 64 scattered 8-byte stores per wave, 0.5 MB
-    // in all at M = 512.  (Adjacent lanes down a column instead -- 32-byte runs both ways -- made the loads irregular across the
-    // wave and the kernel twice as slow: 15 instead of 7.7 us.)
+    // its CUs; a block that needs none fits beside those workgroups.  (Adjacent LANES down a column -- 32-byte runs both ways -- made
+    // the loads irregular across the wave and the kernel twice as slow in round 3, 15 instead of 7.7 us; the layout below keeps the
+    // lanes along a row and gives each THREAD four rows.)
     // (Publishing the results to a kernel that is ALREADY running on another stream from inside this one was tried -- a counter
     // bumped by every block: with __threadfence() each block writes the whole L2 back, which the next group's SYRK keeps filling
     // with dirty slab lines (70 us for this kernel instead of 5); with write-through stores 13 us for 21 tiles.  The kernel
@@ -687,73 +902,65 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
     const int I = row_lo + blockIdx.x, J = blockIdx.y, z = blockIdx.z;
     const int tid = threadIdx.x;
     if (J < T && I >= J) {
-        const int il = tid >> 6, j = tid & 63;
+        // thread = (column j = tid & 63, FOUR consecutive rows 4 zr .. 4 zr + 3, zr = 4 z + (tid >> 6)): a wave reads one 512-byte
+        // slab row per (row, chunk) -- coalesced, every load of a batch independent -- and owns 4 x 64 entries whose images in the
+        // statistics are 32-byte runs down a column (two 16-byte stores per thread) and, mirrored, 512-byte runs along a row.
+        // (Round 3 had one entry per thread: the column side went out as 8-byte stores scattered over 64 lines per instruction.)
+        const int zr = 4 * z + (tid >> 6), j = tid & 63;
         const int t = I * (I + 1) / 2 + J - g.tile0;
-        const double* base = slabs + (size_t)t * (TB * TB) + (z * 4 + il) * TB + j;
+        const double* base = slabs + (size_t)t * (TB * TB) + (size_t)(4 * zr) * TB + j;
+#ifdef SGP_EXP_QUARTER_SLABS
+        const size_t cstride = (size_t)g.ntiles * (TB * TB) * 4;
+        const int nchunks = (g.nchunks + 3) / 4;
+#else
         const size_t cstride = (size_t)g.ntiles * (TB * TB);
         const int nchunks = g.nchunks;
-        double s = 0.0;
+#endif
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
         int c = 0;
-        for (; c + 24 <= nchunks; c += 24) {                 // (24 loads in flight: the groups of the overlapped sweep have 48 - 72 chunks)
-            double v[24];
+        for (; c + 12 <= nchunks; c += 12) {                 // 48 loads in flight; fixed summation order: chunk 0, 1, 2, ...
+            double v[12][4];
 #pragma unroll
-            for (int u = 0; u < 24; ++u) v[u] = base[(size_t)(c + u) * cstride];
+            for (int u = 0; u < 12; ++u)
 #pragma unroll
-            for (int u = 0; u < 24; ++u) s += v[u];          // fixed summation order: chunk 0, 1, 2, ...
-        }
-        for (; c + 12 <= nchunks; c += 12) {
-            double v[12];
+                for (int r = 0; r < 4; ++r) v[u][r] = base[(size_t)(c + u) * cstride + r * TB];
 #pragma unroll
-            for (int u = 0; u < 12; ++u) v[u] = base[(size_t)(c + u) * cstride];
+            for (int u = 0; u < 12; ++u)
 #pragma unroll
-            for (int u = 0; u < 12; ++u) s += v[u];
+                for (int r = 0; r < 4; ++r) s[r] += v[u][r];
         }
         for (; c + 4 <= nchunks; c += 4) {
-            double v[4];
+            double v[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = base[(size_t)(c + u) * cstride];
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s += v[u];
+                for (int r = 0; r < 4; ++r) v[u][r] = base[(size_t)(c + u) * cstride + r * TB];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[r] += v[u][r];
         }
-        for (; c < nchunks; ++c) s += base[(size_t)c * cstride];
-        if (packed) stats[(size_t)(I * (I + 1) / 2 + J) * (TB * TB) + j * TB + z * 4 + il] = s;
-        else {
-            stats[(size_t)(J * TB + j) * Mp + I * TB + z * 4 + il] = s;
-            if (I != J) stats[(size_t)(I * TB + z * 4 + il) * Mp + J * TB + j] = s;
-        }
+        for (; c < nchunks; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] += base[(size_t)c * cstride + r * TB];
+        double* col = packed ? stats + (size_t)(I * (I + 1) / 2 + J) * (TB * TB) + (size_t)j * TB + 4 * zr
+                             : stats + (size_t)(J * TB + j) * Mp + I * TB + 4 * zr;
+        *reinterpret_cast<double2*>(col) = make_double2(s[0], s[1]);
+        *reinterpret_cast<double2*>(col + 2) = make_double2(s[2], s[3]);
+        if (!packed && I != J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stats[(size_t)(I * TB + 4 * zr + r) * Mp + J * TB + j] = s[r];
     }
-    // B = sum of the per-block partials: the blocks of the extra grid row take the (row block, output) pairs; 4 threads per
-    // entry -- one per wave, so that a wave reads 512-byte runs -- walk the partials with a stride of 4 (16 independent loads in
-    // flight) and are combined in a fixed order.  The four waves meet through a few hundred bytes of GLOBAL scratch (`bscratch`,
-    // written, workgroup barrier, read back by wave 0 on the same CU), not through LDS: any LDS in this launch -- static, or
-    // dynamic for the whole grid -- keeps a fourth SYRK workgroup off every CU that still holds one of its blocks, and the next
-    // group's SYRK then needs a second round (measured: +15 us on the statistics).  (Four adjacent lanes per entry and
-    // shuffles instead: 430 instead of 180 us for the 15 625 partial rows of N = 10^6.)
+    // B = sum of the per-block partials (sum_b_pairs): by the blocks of the extra grid row -- or, in the overlapped sweep, by k_sum_b
+    // ahead of this launch (do_b == 2)
     if (do_b && J == T) {
         double* B = stats + (packed ? (size_t)(T * (T + 1) / 2) * (TB * TB) : (size_t)Mp * Mp);
-        const int m = tid & 63, part = tid >> 6;
-        const int bid = blockIdx.x * 16 + z, nb = gridDim.x * 16;
-        for (int pair = bid; pair < T * d_out; pair += nb) {
-            const int Ib = pair % T, o = pair / T;
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            int b = part;
-            for (; b + 60 < nblk; b += 64) {
-                double v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + Ib * TB + m];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) acc[u & 3] += v[u];
-            }
-            for (; b + 12 < nblk; b += 16) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] += bpart[((size_t)(b + 4 * u) * d_out + o) * Mp + Ib * TB + m];
-            }
-            for (; b < nblk; b += 4) acc[0] += bpart[((size_t)b * d_out + o) * Mp + Ib * TB + m];
-            double* red = bscratch + (size_t)pair * (4 * TB);
-            red[part * TB + m] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            __syncthreads();                                     // (waits for the stores: a workgroup-scope release)
-            if (part == 0) B[(size_t)o * Mp + Ib * TB + m] = (red[m] + red[TB + m]) + (red[2 * TB + m] + red[3 * TB + m]);
-        }
+        const int bid = blockIdx.x * gridDim.z + z, nb = gridDim.x * gridDim.z;
+        // do_b == 2 (overlapped sweep, round 4): B was summed by k_sum_b on the masked statistics stream while the SYRK in front of
+        // this launch was still running; this launch only makes sure that has happened before anything behind it reads B (one
+        // thread, bounded; the word is normally long set) and copies the scalars
+        if (do_b == 1) sum_b_pairs(bpart, B, bscratch, Mp, T, nblk, d_out, bid, nb);
+        else if (bid == 0 && tid == 0) spin_until(b_word, b_need, spin_limit, sync_status, SYNC_LATE_COLUMN);
         if (bid == 0)
             for (int e = tid; e < nscal; e += 256) B[(size_t)Mp * d_out + e] = data_scalars[e];
     }
@@ -763,17 +970,19 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
 
 // the reduced exchange buffer (k_assemble, packed) -> the packed statistics layout [Psi2 full symmetric | B | scalars]
 __global__ void __launch_bounds__(256) k_unpack_stats(const double* __restrict__ pack, double* __restrict__ stats, int Mp, int T,
-                                                      int tail) {
-    // grid (T (T + 1) / 2 + 1): block t < ntiles copies lower tile t to both mirror positions; the last block copies B and the scalars
+                                                      int tail, int tile0, int count) {
+    // grid (count + 1): block b < count copies lower tile tile0 + b to both mirror positions; the last block copies B and the
+    // scalars (tail > 0: the launch that carries them -- the whole buffer, or the first group of an overlapped data-sharded sweep)
     const int ntiles = T * (T + 1) / 2, tid = threadIdx.x;
-    if ((int)blockIdx.x == ntiles) {
+    if ((int)blockIdx.x == count) {
         for (int e = tid; e < tail; e += 256) stats[(size_t)Mp * Mp + e] = pack[(size_t)ntiles * (TB * TB) + e];
         return;
     }
+    const int t = tile0 + (int)blockIdx.x;
     int I, J;
-    tile_from_index(blockIdx.x, I, J);
+    tile_from_index(t, I, J);
     __shared__ double tile[TB * LT];
-    const double* src = pack + (size_t)blockIdx.x * (TB * TB);
+    const double* src = pack + (size_t)t * (TB * TB);
     for (int e = tid; e < TB * TB; e += 256) {
         const int j = e >> 6, i = e & 63;                    // element (i, j) of the tile: column-major in the exchange buffer
         const double v = src[e];

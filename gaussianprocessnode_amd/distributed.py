@@ -129,10 +129,11 @@ class HipEngine:
         self._hooked = True
 
     def sweep(self):
-        """local statistics -> installed all-reduce hook -> replicated tail: ONE library call.  Without a hook (one rank)
-        nothing has to be ordered against a collective, so the sweep runs on the library's own streams (NULL stream) -- where
-        it may overlap the statistics with the Lambda chain (include/sgp_hip.h, sgp_overlap_plan); the getters wait for it."""
-        self.dev.sweep(self.stream.cuda_stream if self._hooked else 0)
+        """local statistics -> installed all-reduce hook -> replicated tail: ONE library call on the library's own streams (NULL
+        stream), where it may overlap the statistics with the Lambda chain (include/sgp_hip.h, sgp_overlap_plan) -- hooked or not:
+        the hook is handed the stream each piece of the exchange buffer must be reduced on (one piece per statistics group in the
+        overlapped order) and enters it, so the collective is ordered where the library needs it; the getters wait for the sweep."""
+        self.dev.sweep(0)
 
     def synchronize(self):
         self.torch.cuda.synchronize()

@@ -851,6 +851,68 @@ def test_theta_objective_gradient_length_follows_the_kernel(G):
         assert g.shape == (4,) and np.all(np.isfinite(g))
 
 
+def test_overlapped_sweep_with_one_reduce_per_statistics_group(G):
+    """The data-sharded sweep in the OVERLAPPED order (round 4): with an all-reduce hook and the library's own streams the
+    statistics are reduced group by group -- the hook is called once per tile-row group, each time with a contiguous piece of the
+    exchange buffer on the stream that group runs on (group 0: [its tiles | B | scalars] on the sweep's stream, in front of the
+    Lambda chain; the masked group: its tiles on the CU-masked stream, beside the chain), and the chain step that forms a masked
+    group waits for an event behind that group's reduce.  On one GPU the hook adds the other shard's pieces, captured from a
+    second handle.  Result: the two-shard posterior of the whole data set (GPnode/UniSGPnode.jl:62-63: the product is a sum)."""
+    torch = pytest.importorskip("torch")
+    from gaussianprocessnode_amd.distributed import device_tensor
+    N, M, D, w = 20000, 512, 8, 1e4
+    X, Xu, y, _ = synth(N, M, D, seed=31)
+    s2, ell = 0.9, np.linspace(1.5, 3.0, D)
+    cut = N // 2
+
+    def make(sl):
+        d = G.SGPDevice(N, M, D)
+        d.set_inducing(Xu); d.set_data(X[sl], y[sl]); d.set_kernel(s2, ell, 0.0)
+        d.set_prior_isotropic(50.0); d.set_noise([[w]])
+        return d
+    other, mine = make(slice(cut, N)), make(slice(0, cut))
+    plan = mine.overlap_plan()
+    assert len(plan) >= 2, plan                      # the shard qualifies for the overlapped order, hook or not
+    T = (M + 63) // 64
+    tail = T * 64 + 8 + 1
+    sizes = [g["tiles"] * 4096 + (tail if i == 0 else 0) for i, g in enumerate(plan)]
+    captured, streams = [], []
+
+    def capture(ptr, n, stream):
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            captured.append(device_tensor(ptr, n).clone())
+        streams.append(stream)
+    other.set_allreduce(capture)
+    other.sweep()
+    torch.cuda.synchronize()
+    assert [c.numel() for c in captured] == sizes and len(set(streams)) == len(plan)      # one call per group, each on its own stream
+    calls = []
+
+    def hook(ptr, n, stream):
+        k = len(calls) % len(plan)
+        calls.append(n)
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            device_tensor(ptr, n).add_(captured[k])
+    mine.set_allreduce(hook)
+    outs = []
+    for _ in range(3):
+        mine.sweep()
+        outs.append(mine.posterior())
+    sc = mine.scalars()
+    Psi2, B, scal = mine.stats()
+    mine.close(); other.close()
+    assert calls == sizes * 3
+    for a, b in zip(outs[0], outs[2]):
+        assert np.array_equal(a, b)                   # bitwise reproducible sweep to sweep
+    ref = O.vmp_sweep(Xu, X, y, None, s2, ell, w, jitter=0.0, Lambda0=np.eye(M) / 50.0, xi0=np.zeros(M))
+    assert relF(Psi2, ref.stats.Psi2) < 1e-13 and np.array_equal(Psi2, Psi2.T) and scal[2] == N
+    assert relF(B, np.reshape(ref.stats.b, B.shape)) < 1e-13
+    tol = post_tol(np.linalg.cond(np.eye(M) / 50.0 + w * ref.stats.Psi2))
+    mu, Sig, Uv = outs[0]
+    assert relF(mu, ref.mu_v) < tol and relF(Sig, ref.Sigma_v) < tol and relF(Uv, ref.Uv) < tol
+    assert abs(sc.energy - ref.energy) <= max(1e-7, tol) * abs(ref.energy) + 1e-6
+
+
 def test_sweep_with_the_allreduce_hook_inside_the_library(G):
     """The C ABI's multi-GPU form (sgp_set_allreduce): ONE sgp_sweep call = local statistics -> hook -> replicated tail.  On one GPU
     the hook adds the exchange buffer of the other shard (captured beforehand from a second handle's sweep) -- what a

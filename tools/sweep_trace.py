@@ -32,7 +32,7 @@ buf = (C.c_int64 * (256 * 65))()
 _lib.check(lib.sgp_get_sweep_trace(buf), None, "sgp_get_sweep_trace", lib=lib)
 tr = np.array(buf[:], dtype=np.int64).reshape(256, 65)
 names = {0: "prep_xu (stats)", 1: "prep_xu (K_uu)", 2: "gram_uf", 3: "gram_uu", 4: "trmv_mu_scan", 5: "gemm32 Sigma", 6: "gemm32 Kuu^-1",
-         7: "scalars", 8: "join_wait (statM)", 9: "join_wait (K_uu chain's gate)"}
+         7: "scalars", 8: "join_wait (statM)", 9: "join_wait (K_uu chain's gate)", 10: "join_wait (statM: Gram done, B sum may start)"}
 rows = []
 for s in range(256):
     b, e = tr[s, 0], tr[s, 1:].max()

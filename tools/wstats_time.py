@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Where the time of the per-point path goes: wall time of sgp_sweep + sgp_get_scalars, of sgp_w_stats behind a
+finished sweep, and of the two in a loop, at T and at the banana shape.    python tools/wstats_time.py"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gaussianprocessnode_amd as G
+from gaussianprocessnode_amd import _lib
+
+for name, N, M, D in (("T", 10000, 512, 8), ("C4", 4000, 128, 2)):
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1.7, 1.7, (N, D)); Xu = rng.uniform(-1.7, 1.7, (M, D)); y = np.sin(X.sum(1))
+    with G.SGPDevice(N, M, D, keep_kuf=True) as dev:
+        dev.set_inducing(Xu); dev.set_data(X, y); dev.set_kernel(1.0, np.full(D, 1.5), 1e-6)
+        dev.set_prior_isotropic(50.0); dev.set_noise([[10.0]])
+        for _ in range(20):
+            dev.sweep(); dev.w_stats()
+        reps = 200
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dev.sweep(); dev.scalars()
+        t_sweep = (time.perf_counter() - t0) / reps
+        dev.sweep(); dev.scalars()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dev.w_stats()
+        t_w = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dev.sweep(); dev.w_stats()
+        t_both = (time.perf_counter() - t0) / reps
+        q = dev.time_kernel(_lib.SGP_TIME_QUADFORM, 20)
+        print(f"{name}: sweep + get_scalars (one at a time) {1e6 * t_sweep:.1f} us | w_stats alone {1e6 * t_w:.1f} us (k_quadform_fused {q:.1f} us) | "
+              f"sweep + w_stats {1e6 * t_both:.1f} us = {1 / t_both:.0f} it/s")
