@@ -48,7 +48,7 @@ PIVOT_CYCLES = 127             # dependent cycles per pivot of the factorisation
 def pmc_traffic(workload, world):
     """HBM/fabric bytes per SYRK launch from this round's rocprofv3 --pmc passes (tools/measure_round.sh writes the file next to
     the raw summaries it was computed from; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane reads)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     try:
         rec = json.load(open(path))
     except Exception:

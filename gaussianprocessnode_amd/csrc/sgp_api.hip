@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -95,7 +96,6 @@ enum { WORD_JOIN = 0,      // the K_uu chain of the sweep has finished (k_join_s
        WORD_GATE = 2,      // the streaming SYRK's resident round is on the CUs               -> K_uu chain's first kernel
        WORD_GRAD = 3,      // the K_uu half of the theta gradient is complete                -> k_theta_grad_finish
        WORD_ASM0 = 4,      // group 0's assembly of overlapped sweep number (value) has started     -> the masked statistics stream
-       WORD_BSUM = 5,      // B of overlapped sweep number (value) has been summed on the masked stream (k_sum_b) -> group 0's k_assemble
        WORD_GROUP0 = 8,    // + g: statistics group g of overlapped sweep number (value) is assembled -> Lambda chain, statM
        WORD_COUNT = 8 + LAM_MAX_GROUPS };
 constexpr int RESERVED_CUS_PER_SE = 2;      // of 8: the masked statistics stream runs on 6 CUs per shader engine (192 of 256)
@@ -153,7 +153,6 @@ struct sgp_handle {
 #endif
     // environment switches (diagnostics / A-B), read once in sgp_create
     bool env_no_gate = false, env_join_event = false, env_grad_one_stream = false;
-    bool env_kuu_early = false;    // SGP_KUU_EARLY=1: K_uu's Gram in front of the gate (A/B switch; measured slower, see enqueue_kuu)
     int spin_limit = JOIN_SPIN_LIMIT;   // polls before a bounded device-word wait gives up (SGP_SPIN_LIMIT: tests shorten it)
     double* dCall = nullptr;       // scratch of the per-call outputs (sgp_predict, sgp_w_stats): grows, never shrinks
     size_t call_capacity = 0;
@@ -201,9 +200,6 @@ struct sgp_handle {
     int env_g1_mode = 2;           // SGP_G1_AFTER (see enqueue_stats_overlapped)
     int env_syrk_wt = 0;           // SGP_SYRK_WT (see plan_overlap)
     bool env_syrk_wide = true;     // SGP_SYRK_WIDE=0: the 256-thread SYRK everywhere (A/B switch)
-    bool env_early_b = false;      // SGP_EARLY_B=1: B summed ahead of group 0's k_assemble on the masked stream (A/B switch; measured slower)
-    bool env_kuu_asm = false;      // SGP_KUU_ASM=1: K_uu's Gram at the start of an overlapped sweep, its chain behind group 0's assembly (A/B switch; measured slower)
-    int env_syrk_wide_mode = 1;
     bool syrk_wide = false;        // the resident problem's SYRK launches are k_syrk_stream16 (set_point_count)
     std::vector<int> env_overlap_cols;   // SGP_OVERLAP_COLS: group boundaries (tile columns of P Lambda P), e.g. "3" or "2,4"
     int nblk = 0, ntiles = 0, num_cus = 256;
@@ -265,11 +261,35 @@ static int call_scratch(sgp_handle* h, size_t count, double** out) {
     return 0;
 }
 
+// Host waits of the hot loop's getters.  hipStreamSynchronize / hipDeviceSynchronize may put the calling thread to sleep until an
+// interrupt arrives (the runtime's choice of wait mode): tens of microseconds of wake-up latency behind a 230 us sweep, paid by
+// every "sweep, fetch something, next sweep" iteration of a host-paced caller (measured with tools/wstats_time.py: a sweep +
+// sgp_get_scalars took 300-350 us of wall time for 223 us of device time).  The waits below first POLL hipStreamQuery for up to ~2 ms
+// -- several sweeps' worth -- and only then fall back to the blocking call.  SGP_SPIN_WAIT=0 restores the plain blocking waits.
+static bool g_spin_wait = [] { const char* e = getenv("SGP_SPIN_WAIT"); return !(e && atoi(e) == 0); }();
+static hipError_t wait_stream(hipStream_t s) {
+    if (g_spin_wait) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; ++it) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e != hipErrorNotReady) return e;
+            if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    return hipStreamSynchronize(s);
+}
+// the library's own streams first, polled; the device-wide call behind them returns at once unless foreign work is still queued
+static hipError_t drain_device(sgp_handle* h) {
+    for (hipStream_t s : {h->own, h->side, h->statM})
+        if (s) { const hipError_t e = wait_stream(s); if (e != hipSuccess) return e; }
+    return hipDeviceSynchronize();
+}
+
 static int quiesce(sgp_handle* h) {
     if (h->training) return fail(h, SGP_ERR_ARG, "a device-paced training run is open on this handle: call sgp_train_end first");
     if (h->in_flight) {
         HIPCHK(h, hipSetDevice(h->cfg.device));
-        HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, drain_device(h));
         h->in_flight = false;
     }
     return 0;
@@ -327,6 +347,9 @@ static SyrkGeom syrk_geometry(int row_lo, int nrows, int cus, int64_t n, bool wi
     return g;
 }
 static inline size_t syrk_items(const SyrkGeom& g) { return (size_t)g.ntiles * g.nchunks; }
+// k_assemble's third grid dimension: 4 (four entries per thread, all chunk loads of a thread in flight at once) while a tile has few
+// slabs, 16 (one entry per thread) when the point axis is cut into many chunks
+static inline unsigned assemble_z(const SyrkGeom& g) { return g.nchunks <= 24 ? 4u : 16u; }
 static void launch_syrk(const SyrkGeom& g, hipStream_t s, const double* Kuf, const double* omega, double* slabs, int Mp, int64_t n,
                         int64_t* stamps, long long* gate, long long gate_value) {
     if (g.wide)
@@ -362,7 +385,7 @@ static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, doub
         int e = 0;
         if (j >= 2) {
             e += 2 * (j - 1) * (j < Tn ? 2 : 1);
-            if (Sacc) e += (j - 1) * j / 2;
+            if (Sacc && j < Tn) e += (j - 1) * j / 2;           // (row Tn - 2 of Sigma: left to the product launch, see k_potrf_step)
         }
         if (tv_t && j >= 1) e += 1;
         return e;
@@ -421,7 +444,7 @@ static int launch_chain(sgp_handle* h, int which, double* A, double* A_next, int
         int e = 0;
         if (j >= 2) {
             e += 2 * (j - 1) * (j < Tn ? 2 : 1);
-            if (Sacc) e += (j - 1) * j / 2;
+            if (Sacc && j < Tn) e += (j - 1) * j / 2;
         }
         if (tv_t) e += 1;
         if (e > 0) hipLaunchKernelGGL(k_chain_extras, dim3(e), dim3(256), 0, s, A, ld, j, Tn, Winv, Sacc, tv_xi, tv_t);
@@ -538,14 +561,11 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         h->env_no_gate = getenv("SGP_NO_GATE") != nullptr;
         h->env_join_event = getenv("SGP_JOIN_EVENT") != nullptr;
         h->env_grad_one_stream = getenv("SGP_GRAD_ONE_STREAM") != nullptr;
-        if (const char* ke = getenv("SGP_KUU_EARLY")) h->env_kuu_early = atoi(ke) != 0;
         if (const char* lim = getenv("SGP_SPIN_LIMIT")) h->spin_limit = std::max(1, atoi(lim));
         if (const char* ov = getenv("SGP_OVERLAP")) h->env_overlap = atoi(ov);
         if (const char* g1 = getenv("SGP_G1_AFTER")) h->env_g1_mode = atoi(g1);
         if (const char* wt = getenv("SGP_SYRK_WT")) h->env_syrk_wt = atoi(wt);
-        if (const char* sw = getenv("SGP_SYRK_WIDE")) { h->env_syrk_wide = atoi(sw) != 0; h->env_syrk_wide_mode = atoi(sw); }
-        if (const char* eb = getenv("SGP_EARLY_B")) h->env_early_b = atoi(eb) != 0;
-        if (const char* ka = getenv("SGP_KUU_ASM")) h->env_kuu_asm = atoi(ka) != 0;
+        if (const char* sw = getenv("SGP_SYRK_WIDE")) h->env_syrk_wide = atoi(sw) != 0;
         if (const char* oc = getenv("SGP_OVERLAP_COLS"))
             for (const char* q = oc; *q;) {
                 h->env_overlap_cols.push_back(atoi(q));
@@ -814,8 +834,8 @@ static void plan_overlap(sgp_handle* h, int64_t n) {
         G.nrows = G.c1 - G.c0;
         G.masked = g > 0;
         G.form_step = G.c0;
-        // (SGP_SYRK_WIDE=2, A/B: the in-CU split for group 0 only -- the one on the critical path -- and the 256-thread kernel on the masked queue)
-        G.geom = syrk_geometry(G.row_lo, G.nrows, G.masked ? h->stat_cus_masked : h->num_cus, n, h->syrk_wide && !(G.masked && h->env_syrk_wide_mode == 2));
+        // (the 16-wave kernel for the masked groups as well: with the 256-thread kernel there the sweep was 1 % slower, profiles/r04_ab_log.txt [9])
+        G.geom = syrk_geometry(G.row_lo, G.nrows, G.masked ? h->stat_cus_masked : h->num_cus, n, h->syrk_wide);
         // SGP_SYRK_WT (A/B, see k_syrk_stream): 0 plain slab stores (default), 1 write-through in the masked groups, 2 in all
         G.geom.write_through = (h->env_syrk_wt == 2 || (h->env_syrk_wt == 1 && G.masked)) ? 1 : 0;
         G.ntiles = G.geom.ntiles;
@@ -1074,25 +1094,18 @@ extern "C" int sgp_bind_stats(sgp_handle* h, void* stats_dev) {
 static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
     const bool words = h->dev_words && s == h->side;
-    // Where the gate sits (the chain's whole-CU workgroups stay off the chip until the SYRK's resident round is on it).  Default:
-    // inside k_prep_xu, in front of K_uu's Gram -- k_gram_uu then starts together with the SYRK, is starved beside it (35 us for a
-    // 512 x 512 matrix) and the chain's first step begins just as the SYRK drains.  SGP_KUU_EARLY=1 (round 4)
-    // puts k_gram_uu in front of the gate, at the start of the sweep beside k_gram_uf: the chain is then ready ~35 us earlier, its
-    // step 0 starts while group 0's SYRK is still running -- and that SYRK, which is on the sweep's critical path, takes 52
-    // instead of 40 us (its last workgroups share their CUs' issue slots and L2 with the chain's).  Same-box A/B at T,
-    // 2 x 1000 sweeps each: 4 312 / 4 317 sweeps/s with the gate first, 4 168 / 4 174 with the Gram first -- the starved Gram is
-    // what keeps the chain off the SYRK, so the default stays.
-    // SGP_KUU_ASM=1 (round 4 experiment, off): K_uu itself at the start of an overlapped sweep -- the LDS-free k_gram_uu fits beside
-    // k_gram_uf and the SYRK -- and the FACTORISATION behind the word group 0's k_assemble sets when it starts (group 0's SYRK has
-    // drained).  Measured slower ([9] in profiles/r04_ab_log.txt: 4 215 against 4 424 sweeps/s): K_uu's Gram then runs beside
-    // group 0's SYRK with nothing to starve it, and its FP64 vector work takes the pipe from the SYRK's MFMAs (51 instead of 42 us).
+    // The gate (the chain's whole-CU workgroups stay off the chip until the SYRK's resident round is on it) sits inside k_prep_xu, in
+    // front of K_uu's Gram: k_gram_uu_lds then starts together with the SYRK, gets a CU only as SYRK workgroups leave (it needs LDS, the
+    // SYRK holds all of it) and the chain's first step begins a few microseconds after the SYRK has drained.  Round 4 tried to start
+    // the chain earlier -- K_uu's Gram at the start of the sweep in front of the gate; an LDS-free Gram beside the SYRK with the
+    // factorisation behind the word group 0's k_assemble sets -- and both cost the sweep 3 - 5 %: whatever FP64 work runs beside
+    // group 0's SYRK, or whole-CU workgroups in its tail, lengthens that SYRK, which is on the critical path, by more than the
+    // K_uu chain gains (profiles/r04_ab_log.txt [1], [9]).
     const bool gate = words && h->gate_side;
-    const bool gate_asm = gate && h->overlap_now && h->env_kuu_asm && !h->use_chain;
-    const bool gate_late = gate && (h->env_kuu_early || gate_asm) && !h->use_chain;
     hipLaunchKernelGGL(k_prep_xu, dim3((Mp + 255) / 256), dim3(256), 0, s, h->dXu, h->dXusK, h->params_src,
                        h->dParamsK, h->dInfo + 0, M, Mp, D, (int64_t*)nullptr, 0, 0,
                        words ? (const long long*)(h->dJoin + WORD_DONE) : (const long long*)nullptr, h->done_epoch,
-                       (gate && !gate_late) ? (const long long*)(h->dJoin + WORD_GATE) : (const long long*)nullptr,
+                       gate ? (const long long*)(h->dJoin + WORD_GATE) : (const long long*)nullptr,
                        h->gate_epoch, h->spin_limit, h->dInfo + 3);
 #ifdef SGP_WITH_PERSISTENT_CHAIN
     if (h->use_chain) {
@@ -1104,12 +1117,8 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
     } else
 #endif
     {
-        if (gate && !gate_late) hipLaunchKernelGGL(k_gram_uu_lds, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
+        if (gate) hipLaunchKernelGGL(k_gram_uu_lds, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
         else hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
-        // (scheduling only: giving up here costs time, not correctness, so no status bit)
-        if (gate_late)
-            hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, s, (const long long*)(h->dJoin + (gate_asm ? WORD_ASM0 : WORD_GATE)),
-                               gate_asm ? h->stat_epoch : h->gate_epoch, h->spin_limit, (int*)nullptr, 0, 9);
         launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk, nullptr, h->dSaccK);
     }
     launch_ata(h->dWk, h->dKinv, Mp, T, s, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->dSaccK);
@@ -1150,10 +1159,10 @@ static void enqueue_local(sgp_handle* h, hipStream_t s) {
     SyrkGeom ga = h->geom;
     if (h->n <= 0) { ga = syrk_geometry(0, T, h->num_cus, 0); }       // no data: zero chunks, the statistics are zero
     // (data-sharded sweeps write the exchange buffer instead: lower tiles only, see exchange_stats)
-    hipLaunchKernelGGL(k_assemble, dim3(T, T + 1, 4), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal,
+    hipLaunchKernelGGL(k_assemble, dim3(T, T + 1, assemble_z(ga)), dim3(256), 0, s, h->dSlabs, h->dBpart, h->dDataScal,
                        h->pack_now ? h->dPack : h->dStats, Mp, T, ga, h->n > 0 ? h->nblk : 0, h->dout,
                        SGP_S_COUNT + h->dout * h->dout, 1, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL, h->dInfo + 1, (long long*)nullptr, 0LL,
-                       h->pack_now ? 1 : 0, h->dBred, (const long long*)nullptr, 0LL, h->spin_limit, (int*)nullptr);
+                       h->pack_now ? 1 : 0, h->dBred);
 }
 
 // The statistics of an overlapped sweep (see plan_overlap): the same kernels, the SYRK and the assembly once per tile-row group.
@@ -1191,22 +1200,6 @@ static int enqueue_stats_overlapped(sgp_handle* h, hipStream_t own) {
     // SYRK no longer fits its single round).  Sweeps/s at T on one box: 3978 / 3975 / 3865.
     const int g1_mode = sharded ? 2 : h->env_g1_mode;
     const long long* g1_word = h->dJoin + (g1_mode == 0 ? WORD_GATE : (g1_mode == 1 ? WORD_GROUP0 : WORD_ASM0));
-    // B = K_uf (omega o y) does not wait for the SYRK: its partials are complete when k_gram_uf is, so the masked stream -- idle until
-    // group 0's SYRK has drained -- sums them as soon as that SYRK's round is resident (the gate word: k_gram_uf precedes it on the
-    // sweep's stream), and group 0's k_assemble, in front of the Lambda chain, loses the longest thing it did (three dependent
-    // round trips over 157 partial rows).  It only checks the word k_join_set writes behind k_sum_b.
-    // MEASURED (profiles/r04_ab_log.txt [8]) and off by default: the three extra launches sit in front of the masked stream's wait for
-    // group 0's assembly and the masked SYRK starts ~8 us late -- the forming step then waits for its group (chain 159 instead of
-    // 148 us, 4 235 instead of 4 430 sweeps/s) -- while k_assemble without its B role is no shorter (7.2 us either way: it is the
-    // slab reads and the scattered tile stores).
-    const bool early_b = h->env_early_b;
-    if (early_b) {
-        hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, h->statM, (const long long*)(h->dJoin + WORD_GATE), h->gate_epoch, h->spin_limit,
-                           h->dInfo + 3, (int)SYNC_LATE_COLUMN, 10);
-        hipLaunchKernelGGL(k_sum_b, dim3(T * h->dout), dim3(256), 0, h->statM, (const double*)h->dBpart, sharded ? h->dPack : h->dStats, h->dBred,
-                           Mp, T, h->nblk, h->dout, sharded ? 1 : 0);
-        hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, h->statM, h->dJoin + WORD_BSUM, h->stat_epoch);
-    }
     hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, h->statM, g1_word, g1_mode == 0 ? h->gate_epoch : h->stat_epoch,
                        h->spin_limit, h->dInfo + 3, (int)SYNC_LATE_COLUMN, 8);
     for (int g = 0; g < h->ngroups; ++g) {
@@ -1214,11 +1207,11 @@ static int enqueue_stats_overlapped(sgp_handle* h, hipStream_t own) {
         hipStream_t s = G.masked ? h->statM : own;
         launch_syrk(G.geom, s, h->dKuf, h->has_omega ? h->dOmega : nullptr, h->dSlabs + G.slab_off, Mp, h->n,
                     h->dStamps + STAMP_STRIDE * SGP_T_SYRK, g == 0 ? h->dJoin + WORD_GATE : (long long*)nullptr, h->gate_epoch);
-        hipLaunchKernelGGL(k_assemble, dim3(G.nrows, T + (g == 0 ? 1 : 0), 4), dim3(256), 0, s, h->dSlabs + G.slab_off, h->dBpart,
+        hipLaunchKernelGGL(k_assemble, dim3(G.nrows, T + (g == 0 ? 1 : 0), assemble_z(G.geom)), dim3(256), 0, s, h->dSlabs + G.slab_off, h->dBpart,
                            h->dDataScal, sharded ? h->dPack : h->dStats, Mp, T, G.geom, h->nblk, h->dout,
-                           SGP_S_COUNT + h->dout * h->dout, g == 0 ? (early_b ? 2 : 1) : 0, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL,
+                           SGP_S_COUNT + h->dout * h->dout, g == 0 ? 1 : 0, h->dStamps + STAMP_STRIDE * SGP_T_LOCAL,
                            g == 0 ? h->dInfo + 1 : (int*)nullptr, g == 0 ? h->dJoin + WORD_ASM0 : (long long*)nullptr, h->stat_epoch,
-                           sharded ? 1 : 0, h->dBred, (const long long*)(h->dJoin + WORD_BSUM), h->stat_epoch, h->spin_limit, h->dInfo + 3);
+                           sharded ? 1 : 0, h->dBred);
         if (sharded) {
             if (int xrc = exchange_stats(h, s, G.geom.tile0, G.geom.ntiles, g == 0)) return xrc;
             if (G.masked && hipEventRecord(h->evGroup[g], s) != hipSuccess) return fail(h, SGP_ERR_HIP, "hipEventRecord failed (statistics group)");
@@ -1315,7 +1308,9 @@ static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
     hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, partK, nK, (const double*)traceR, nR, h->dMu, h->dKuu,
                        h->dLam, h->dInfo, h->dParams, h->dOut, h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q,
                        h->dStamps + STAMP_STRIDE * SGP_T_FINISH2, h->dStamps, h->dStampTotals,
-                       (h->cfg.flags & SGP_FLAG_GRAPH) ? (long long*)nullptr : h->dJoin + WORD_DONE, h->done_epoch);
+                       (h->cfg.flags & SGP_FLAG_GRAPH) ? (long long*)nullptr : h->dJoin + WORD_DONE, h->done_epoch,
+                       h->use_chain ? (const double*)nullptr : (const double*)(h->dScratch + POTRF_LOGDET), h->T,
+                       h->use_chain ? (const double*)nullptr : (const double*)(h->dScratch + POTRF_SCRATCH + POTRF_LOGDET), TQ);
 }
 
 static int set_device_checked(int device) {
@@ -1620,7 +1615,7 @@ extern "C" int sgp_measure_clocks(int32_t device, double* out) {
 // ------------------------------------------------------------------------------------------------
 static int sync_all(sgp_handle* h) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, drain_device(h));
     h->in_flight = false;
     return 0;
 }
@@ -1907,7 +1902,7 @@ extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) 
     // were ~60 us of a 280 us call at n = 10 000)
     const bool staged = h->hStage && 2 * (size_t)n <= h->stage_doubles;
     if (staged) HIPCHK(h, hipMemcpyAsync(h->hStage, dI1, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, wait_stream(s));
     HIPCHK(h, hipGetLastError());
     if (int src = check_sync_status(h)) return src;          // (the sweep whose q(v) these are: a hand-off that gave up voids them too)
     if (staged) {
@@ -1943,7 +1938,7 @@ extern "C" int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const
     if (h->training) return fail(h, SGP_ERR_ARG, "sgp_predict: a device-paced training run is open (sgp_train_end first)");
     if (ns == 0) return 0;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, drain_device(h));
     h->in_flight = false;
     hipStream_t s = h->own;
     double *dXs = nullptr, *dMean = nullptr, *dMuTmp = nullptr;
@@ -2057,7 +2052,7 @@ static int theta_objective_eval(sgp_handle* h, hipStream_t s, double* value) {
     hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, (const double*)h->dTrace, (int)TRACE_BLOCKS,
                        (const double*)(h->dTrace + TRACE_BLOCKS), (int)TRACE_BLOCKS, h->dMu, h->dKuu, h->dLam, h->dInfo, h->dParams,
                        h->dOut2, h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q, (int64_t*)nullptr, (int64_t*)nullptr,
-                       (int64_t*)nullptr, (long long*)nullptr, 0LL);
+                       (int64_t*)nullptr, (long long*)nullptr, 0LL, (const double*)nullptr, 0, (const double*)nullptr, 0);
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     double out[SGP_R_COUNT], sc[SGP_S_COUNT];
@@ -2074,7 +2069,7 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
     if (!h->have_data || !h->have_kernel) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: data and kernel must be set");
     if (h->training) return fail(h, SGP_ERR_ARG, "sgp_theta_objective: a device-paced training run is open (sgp_train_end first)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, drain_device(h));
     h->in_flight = false;
     if (int src = check_sync_status(h)) return src;
     hipStream_t s = h->own;
@@ -2103,7 +2098,7 @@ extern "C" int sgp_theta_objective(sgp_handle* h, double* value, double* grad) {
         if (rc || !grad) { h->swept_local = true; return rc; }
     }
     if (int grc = enqueue_theta_grad(h, s)) return grc;
-    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, wait_stream(s));
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpy(grad, h->dGrad, sizeof(double) * (1 + h->n_ell), hipMemcpyDeviceToHost));
     for (int i = 0; i <= h->n_ell; ++i) grad[i] *= wscale;

@@ -1131,7 +1131,7 @@ __global__ void __launch_bounds__(256) k_chain_extras(double* __restrict__ A, in
     int e = blockIdx.x;
     const int nfin = (j >= 2) ? 2 * (j - 1) : 0;
     const int npre = (j < Tn) ? nfin : 0;
-    const int nsig = (Sacc && j >= 2) ? (j - 1) * j / 2 : 0;
+    const int nsig = (Sacc && j >= 2 && j < Tn) ? (j - 1) * j / 2 : 0;     // (the last launch leaves row Tn - 2 to the product launch, see k_potrf_step)
     if (e < nfin) winv_row_tile(A, Winv, ld, j - 1, e >> 1, e & 1, lds, 2);
     else if (e < nfin + npre) { e -= nfin; winv_row_tile(A, Winv, ld, j, e >> 1, e & 1, lds, 1); }
     else if (e < nfin + npre + nsig) {

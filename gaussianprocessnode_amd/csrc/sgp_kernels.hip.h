@@ -514,6 +514,25 @@ __device__ __forceinline__ void load_panel_n(double* panel, const double* __rest
 // panel[k][i] = G[(row0 + k) + (col0 + i) * ld]  (contiguous along k in memory: transposing load)
 __device__ __forceinline__ void load_panel_t(double* panel, const double* __restrict__ G, size_t ld, int row0, int col0,
                                              int kcount, int tid) {
+    if (kcount == TB) {                         // (all global loads before the first LDS store: one memory latency, not four)
+        double2 v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + 256 * u, g = t & 15, i = t >> 4;
+            const double* src = G + (size_t)(col0 + i) * ld + row0 + g * 4;
+            v0[u] = *reinterpret_cast<const double2*>(src);
+            v1[u] = *reinterpret_cast<const double2*>(src + 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + 256 * u, g = t & 15, i = t >> 4;
+            panel[(g * 4 + 0) * PS + i] = v0[u].x;
+            panel[(g * 4 + 1) * PS + i] = v0[u].y;
+            panel[(g * 4 + 2) * PS + i] = v1[u].x;
+            panel[(g * 4 + 3) * PS + i] = v1[u].y;
+        }
+        return;
+    }
     const int kq = kcount >> 2;                 // groups of 4 consecutive k
     for (int t = tid; t < kq * 64; t += 256) {
         int g = t % kq, i = t / kq;
@@ -862,23 +881,15 @@ __device__ __forceinline__ void sum_b_pairs(const double* __restrict__ bpart, do
         if (part == 0) B[(size_t)o * Mp + Ib * TB + m] = (red[m] + red[TB + m]) + (red[2 * TB + m] + red[3 * TB + m]);
     }
 }
-// B on its own (overlapped sweep): launched on the masked statistics stream as soon as k_gram_uf has finished, beside group 0's SYRK
-// -- no LDS, so it fits on CUs whose LDS that SYRK holds.  `packed`: into the exchange buffer's tail (data-sharded sweeps).
-__global__ void __launch_bounds__(256) k_sum_b(const double* __restrict__ bpart, double* __restrict__ stats, double* __restrict__ bscratch,
-                                               int Mp, int T, int nblk, int d_out, int packed) {
-    double* B = stats + (packed ? (size_t)(T * (T + 1) / 2) * (TB * TB) : (size_t)Mp * Mp);
-    sum_b_pairs(bpart, B, bscratch, Mp, T, nblk, d_out, (int)blockIdx.x, (int)gridDim.x);
-}
-
 __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ slabs, const double* __restrict__ bpart,
                                                   const double* __restrict__ data_scalars, double* __restrict__ stats,
                                                   int Mp, int T, SyrkGeom g, int nblk, int d_out,
                                                   int nscal, int do_b, int64_t* stamps, int* __restrict__ info_reset,
                                                   long long* start_word, long long start_value, int packed,
-                                                  double* __restrict__ bscratch, const long long* b_word, long long b_need,
-                                                  int spin_limit, int* sync_status) {
-    // grid (rows, T + do_b, 4): blocks (x, y < T, z) sum rows [16 z, 16 z + 16) of the slab tile (I, J) = (row_lo + x, y), I >= J --
-    // four entries per thread (see below), 48 loads in flight -- and write both mirror images.
+                                                  double* __restrict__ bscratch) {
+    // grid (rows, T + do_b, 4 or 16): blocks (x, y < T, z) sum rows [64 z / grid.z, ...) of the slab tile (I, J) = (row_lo + x, y),
+    // I >= J -- four entries per thread and 48 loads in flight (grid.z = 4: few chunks) or one entry per thread (grid.z = 16: many
+    // chunks), see below -- and write both mirror images.
     // `slabs` / `g`: the slab area and geometry of this launch's tile rows (k_syrk_stream).  Blocks with y == T (do_b) sum the
     // B partials and copy the data scalars.
     // packed (data-sharded sweeps): `stats` is the exchange buffer [lower tiles, row-major triangle, 64 x 64 column-major each |
@@ -901,7 +912,39 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
         __hip_atomic_store(start_word, start_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int I = row_lo + blockIdx.x, J = blockIdx.y, z = blockIdx.z;
     const int tid = threadIdx.x;
-    if (J < T && I >= J) {
+    if (J < T && I >= J && gridDim.z == 16) {
+        // MANY chunks (small problems: a few tiles, the point axis cut into hundreds of 16-point chunks): one entry per thread, sixteen
+        // blocks per tile -- the chunk loop is the long part and wants as many threads as there are entries.  Thread = (row 4 z +
+        // (tid >> 6), column j = tid & 63); the column side goes out as scattered 8-byte stores (a few KB here).
+        const int il = tid >> 6, j = tid & 63;
+        const int t = I * (I + 1) / 2 + J - g.tile0;
+        const double* base = slabs + (size_t)t * (TB * TB) + (z * 4 + il) * TB + j;
+        const size_t cstride = (size_t)g.ntiles * (TB * TB);
+        const int nchunks = g.nchunks;
+        double s = 0.0;
+        int c = 0;
+        for (; c + 24 <= nchunks; c += 24) {                 // 24 loads in flight; fixed summation order: chunk 0, 1, 2, ...
+            double v[24];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) v[u] = base[(size_t)(c + u) * cstride];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) s += v[u];
+        }
+        for (; c + 4 <= nchunks; c += 4) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = base[(size_t)(c + u) * cstride];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        for (; c < nchunks; ++c) s += base[(size_t)c * cstride];
+        if (packed) stats[(size_t)(I * (I + 1) / 2 + J) * (TB * TB) + j * TB + z * 4 + il] = s;
+        else {
+            stats[(size_t)(J * TB + j) * Mp + I * TB + z * 4 + il] = s;
+            if (I != J) stats[(size_t)(I * TB + z * 4 + il) * Mp + J * TB + j] = s;
+        }
+    } else if (J < T && I >= J) {
+        // FEW chunks (grid.z == 4; the sweeps whose SYRK fills the chip: 12 chunks per tile with the 16-wave SYRK).
         // thread = (column j = tid & 63, FOUR consecutive rows 4 zr .. 4 zr + 3, zr = 4 z + (tid >> 6)): a wave reads one 512-byte
         // slab row per (row, chunk) -- coalesced, every load of a batch independent -- and owns 4 x 64 entries whose images in the
         // statistics are 32-byte runs down a column (two 16-byte stores per thread) and, mirrored, 512-byte runs along a row.
@@ -951,16 +994,13 @@ __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ sla
 #pragma unroll
             for (int r = 0; r < 4; ++r) stats[(size_t)(I * TB + 4 * zr + r) * Mp + J * TB + j] = s[r];
     }
-    // B = sum of the per-block partials (sum_b_pairs): by the blocks of the extra grid row -- or, in the overlapped sweep, by k_sum_b
-    // ahead of this launch (do_b == 2)
+    // B = sum of the per-block partials (sum_b_pairs), by the blocks of the extra grid row.  (Two ways of taking this off the path in
+    // front of the Lambda chain were built and measured in round 4 -- B summed on the masked stream ahead of this launch, and B
+    // summed by extra workgroups of the chain's step 0 -- and neither paid: profiles/r04_ab_log.txt [8], [12].)
     if (do_b && J == T) {
         double* B = stats + (packed ? (size_t)(T * (T + 1) / 2) * (TB * TB) : (size_t)Mp * Mp);
         const int bid = blockIdx.x * gridDim.z + z, nb = gridDim.x * gridDim.z;
-        // do_b == 2 (overlapped sweep, round 4): B was summed by k_sum_b on the masked statistics stream while the SYRK in front of
-        // this launch was still running; this launch only makes sure that has happened before anything behind it reads B (one
-        // thread, bounded; the word is normally long set) and copies the scalars
-        if (do_b == 1) sum_b_pairs(bpart, B, bscratch, Mp, T, nblk, d_out, bid, nb);
-        else if (bid == 0 && tid == 0) spin_until(b_word, b_need, spin_limit, sync_status, SYNC_LATE_COLUMN);
+        sum_b_pairs(bpart, B, bscratch, Mp, T, nblk, d_out, bid, nb);
         if (bid == 0)
             for (int e = tid; e < nscal; e += 256) B[(size_t)Mp * d_out + e] = data_scalars[e];
     }
@@ -1640,7 +1680,7 @@ __device__ __forceinline__ void winv_half_mma(d4& c0a, d4& c1a, d4& c0b, d4& c1b
 // mode 1 (one launch early): T' = sum_{k=c}^{i-2} L_ik W_kc, parked in W's own (i, c) tile;
 // mode 2 (finish):           W_ic = - W_ii (T' + L_{i,i-1} W_{i-1,c})   -- two products instead of up to i - c + 1.
 __device__ __forceinline__ void winv_row_tile(const double* __restrict__ L, double* __restrict__ W, int ld, int i, int c, int h,
-                                              double* lds, int mode) {
+                                              double* lds, int mode, double* lds2 = nullptr) {
     double* As = lds;                                     // As[kk][r], 64 x 64, stride PS
     double* Bs = lds + TB * PS;                           // Bs[kk][jj], 64 x 32, stride PS32
     double* Os = Bs;                                      // Os[jj][r], stride LT: staging for coalesced tile-half I/O
@@ -1649,6 +1689,78 @@ __device__ __forceinline__ void winv_row_tile(const double* __restrict__ L, doub
     const int col0 = c * TB + 32 * h;
     const d4 Z = (d4){0.0, 0.0, 0.0, 0.0};
     d4 t0a = Z, t1a = Z, t0b = Z, t1b = Z;
+    if (mode == 2 && lds2) {
+        // The finishing step with EVERY operand requested before the first wait (round 4): the parked partial sum straight into
+        // the accumulator layout, the two panels of the one remaining product L_{i,i-1} W_{i-1,c}, and W_ii into a second panel
+        // buffer -- one memory round trip where the general path below has three (partial -> panels -> W_ii).  This is the launch
+        // behind the last Cholesky step: nothing hides it, the sweep waits for it (7.0 - 7.4 us per workgroup before).
+        double* As2 = lds2;                               // As2[kk][r] = W_ii[r][kk], stride PS
+        const int k = i - 1;
+        double2 a0[4], a1[4], w0[4], w1[4], b0[2], b1[2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + 256 * u, kk = t >> 4, rq = t & 15;
+            const double* sa = L + (size_t)(k * TB + kk) * ld + i * TB + rq * 4;
+            const double* sw = W + (size_t)(i * TB + kk) * ld + i * TB + rq * 4;
+            a0[u] = *reinterpret_cast<const double2*>(sa); a1[u] = *reinterpret_cast<const double2*>(sa + 2);
+            w0[u] = *reinterpret_cast<const double2*>(sw); w1[u] = *reinterpret_cast<const double2*>(sw + 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tid + 256 * u, ii = t & 31, g = t >> 5;
+            const double* sb = W + (size_t)(col0 + ii) * ld + k * TB + g * 4;
+            b0[u] = *reinterpret_cast<const double2*>(sb); b1[u] = *reinterpret_cast<const double2*>(sb + 2);
+        }
+        if (c <= i - 2) {                                 // (the parked partial: T' of mode 1, in W's own (i, c) tile)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * TB + wave * 16 + lk + 4 * r;
+                t0a[r] = W[(size_t)(col0 + li) * ld + row];
+                t1a[r] = W[(size_t)(col0 + 16 + li) * ld + row];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + 256 * u, kk = t >> 4, rq = t & 15;
+            double* da = As + kk * PS + rq * 4;
+            double* dw = As2 + kk * PS + rq * 4;
+            da[0] = a0[u].x; da[1] = a0[u].y; da[2] = a1[u].x; da[3] = a1[u].y;
+            dw[0] = w0[u].x; dw[1] = w0[u].y; dw[2] = w1[u].x; dw[3] = w1[u].y;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tid + 256 * u, ii = t & 31, g = t >> 5;
+            Bs[(g * 4 + 0) * PS32 + ii] = b0[u].x;
+            Bs[(g * 4 + 1) * PS32 + ii] = b0[u].y;
+            Bs[(g * 4 + 2) * PS32 + ii] = b1[u].x;
+            Bs[(g * 4 + 3) * PS32 + ii] = b1[u].y;
+        }
+        __syncthreads();
+        winv_half_mma(t0a, t1a, t0b, t1b, As, Bs, lane, wave);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + lk + 4 * r;
+            Bs[row * PS32 + li] = t0a[r] + t0b[r];
+            Bs[row * PS32 + 16 + li] = t1a[r] + t1b[r];
+        }
+        __syncthreads();
+        d4 o0a = Z, o1a = Z, o0b = Z, o1b = Z;
+        winv_half_mma(o0a, o1a, o0b, o1b, As2, Bs, lane, wave);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + lk + 4 * r;
+            Os[li * LT + row] = -(o0a[r] + o0b[r]);
+            Os[(16 + li) * LT + row] = -(o1a[r] + o1b[r]);
+        }
+        __syncthreads();
+        for (int e = tid; e < 32 * TB; e += 256) {
+            const int jj = e >> 6, r = e & 63;
+            W[(size_t)(col0 + jj) * ld + i * TB + r] = Os[jj * LT + r];
+        }
+        return;
+    }
     const int kbeg = (mode == 2) ? i - 1 : c, kend = (mode == 1) ? i - 1 : i;      // [kbeg, kend)
     if (mode == 2 && c <= i - 2) {                        // resume from the parked partial sum
         for (int e = tid; e < 32 * TB; e += 256) {
@@ -1707,7 +1819,8 @@ __device__ __forceinline__ void winv_row_tile(const double* __restrict__ L, doub
 // Sigma = W^T W rides along as well: Sigma(I,J) = sum_{k >= I} W(k,I)^T W(k,J), and block row k of W is final one launch
 // after step k.  Extra workgroups of launch j add row j - 2's contribution W(j-2,I)^T W(j-2,J) to every lower tile (I, J),
 // I <= j - 2, of the accumulator Sacc (first contribution of a tile: plain store), one 64 x 64 x 64 product each.  The
-// product launch after the factorisation (k_gemm32 mode 0) then only adds the LAST block row and runs its epilogue.
+// product launch after the factorisation (k_gemm32 mode 0) then only adds the last TWO block rows (the launch behind the last step
+// carries no Sigma workgroups, see k_potrf_step) and runs its epilogue.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sigma_row_tile(const double* __restrict__ W, double* __restrict__ Sacc, int ld, int i, int I,
                                                int J, double* panels, double* tile) {
@@ -1748,7 +1861,21 @@ __device__ __forceinline__ void tvec_role(const double* __restrict__ L, const do
     double* rvec = lds + 4 * TB;        // [64]
     const int tid = threadIdx.x, r = tid & 63, part = tid >> 6;
     double acc = 0.0;
-    for (int k = 0; k < i; ++k) {
+    int k = 0;
+    for (; k + 2 <= i; k += 2) {                // two block columns' loads in flight (64 per thread with t); the FMAs keep the order k, u
+        double v[2][16], tv[2][16];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const double* base = L + (size_t)((k + q) * TB + 16 * part) * ld + i * TB + r;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { v[q][u] = base[(size_t)u * ld]; tv[q][u] = t[(k + q) * TB + 16 * part + u]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = fma(v[q][u], tv[q][u], acc);
+    }
+    for (; k < i; ++k) {
         const double* base = L + (size_t)(k * TB + 16 * part) * ld + i * TB + r;
         double v[16];
 #pragma unroll
@@ -1833,7 +1960,11 @@ __host__ __device__ constexpr int potrf_twins(int Tn, int j) { return (Tn - j >=
 // once its tile is in LDS, and the owner stores only when all twins have (it polls early: the answer is normally there long
 // before it is needed; bounded, and a give-up is reported through `info` like any other, as -1).  Two words behind the three
 // scratch tiles, by the step's parity; the diagonal block of step j clears the word of step j + 1.
-constexpr int POTRF_SCRATCH = 3 * TB * TB + 64;     // doubles of scratch per factorisation chain
+constexpr int POTRF_SCRATCH = 3 * TB * TB + 64 + 64;   // doubles of scratch per factorisation chain
+// ... [3 TB^2 + 64 + j]: sum of log L_cc over the 64 pivots of step j, written by the step's diagonal workgroup (1 / L_cc is in
+// LDS there anyway): the sweep's closing kernel adds T numbers up instead of fetching 512 diagonal entries of each factor, one
+// cache line apiece, and taking their logarithms on the sweep's critical path
+constexpr int POTRF_LOGDET = 3 * TB * TB + 64;
 __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict__ A, int ld, int j, int Tn, int* __restrict__ info,
                                                     int n_valid, double* __restrict__ scratch, double* __restrict__ Winv,
                                                     double* __restrict__ Sacc, const double* __restrict__ tv_xi,
@@ -1854,8 +1985,12 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             int e = blockIdx.x - npot;                    // then pre-accumulate block row j; Sigma = W^T W collects the
             const int nfin = (j >= 2) ? 2 * (j - 1) : 0;  // contribution of block row j - 2 (sigma_row_tile); and one
             const int npre = (j < Tn) ? nfin : 0;         // workgroup advances the forward solve t = W (P xi) (tvec_role)
-            const int nsig = (Sacc && j >= 2) ? (j - 1) * j / 2 : 0;
-            if (e < nfin) winv_row_tile(A, Winv, ld, j - 1, e >> 1, e & 1, lds, 2);
+            // (not in the launch behind the last step, j == Tn: nothing hides that launch, and a 64^3 product per workgroup --
+            // 64 dependent-issue MFMAs per wave, 2.8 us -- made its Sigma workgroups the last to leave, 7.7 us against the 5.1 of
+            // the inverse factor's; the product launch behind it, whose workgroups are a quarter of the size, adds the last TWO
+            // block rows instead)
+            const int nsig = (Sacc && j >= 2 && j < Tn) ? (j - 1) * j / 2 : 0;
+            if (e < nfin) winv_row_tile(A, Winv, ld, j - 1, e >> 1, e & 1, lds, 2, tiles);
             else if (e < nfin + npre) { e -= nfin; winv_row_tile(A, Winv, ld, j, e >> 1, e & 1, lds, 1); }
             else if (e < nfin + npre + nsig) {
                 int I, J;
@@ -1971,6 +2106,11 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
             };
             potf2_tile(S, dprep, rinv, info, j0, n_valid, idle);
             STEP_TRACE(3);
+            if (a == 0 && wave == 3) {                     // (the diagonal workgroup is not the one the launch waits for)
+                double lg = -log(rinv[lane]);
+                for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
+                if (lane == 0) scratch[POTRF_LOGDET + j] = lg;
+            }
             if (fcount > 0) {
                 fsyrk(3);
 #pragma unroll
@@ -2217,7 +2357,7 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
     int I, J, kbeg, kend;
     if (mode == 0) {
         tile_from_index(blockIdx.x >> 2, I, J);
-        kbeg = Sacc ? max(I, Tn - 1) : I;                                // with Sacc only the last block row is left to add
+        kbeg = Sacc ? max(I, Tn - 2) : I;                                // with Sacc only the last two block rows are left to add
         kend = Tn;
     } else {                                                             // mode 3: general C = A B, every tile
         const int t = blockIdx.x >> 2;
@@ -2226,7 +2366,7 @@ __global__ void __launch_bounds__(256) k_gemm32(const double* __restrict__ A, co
     const int r0 = I * TB + qi * 32, c0 = J * TB + qj * 32;
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
     const int li = lane & 15, lk = lane >> 4;
-    if (mode == 0 && Sacc && I < Tn - 1) {                               // the block rows before the last, collected by
+    if (mode == 0 && Sacc && I < Tn - 2) {                               // the block rows before the last two, collected by
 #pragma unroll                                                           // sigma_row_tile during the factorisation
         for (int r = 0; r < 4; ++r) acc[r] = Sacc[(size_t)(c0 + wc * 16 + li) * ld + r0 + wr * 16 + lk + 4 * r];
     }
@@ -2492,7 +2632,10 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
                                                  const Params* __restrict__ P, double* __restrict__ out,
                                                  double* __restrict__ wishart, int M, int Mp, int d_out, int Q, int Qp,
                                                  int lam_off, int64_t* stamps, int64_t* all_stamps,
-                                                 int64_t* totals, long long* done_word, long long done_value) {
+                                                 int64_t* totals, long long* done_word, long long done_value,
+                                                 const double* __restrict__ ldK, int nldK, const double* __restrict__ ldL, int nldL) {
+    // ldK / ldL (may be nullptr: then the diagonals of Lkuu / Llam are read): per-step sums of log L_cc left by the factorisation
+    // launches (POTRF_LOGDET)
     // done_word (may be nullptr): set to done_value once this kernel -- the sweep's last reader of the K_uu chain's outputs --
     // has read them; the next sweep's chain waits for it in its first kernel (k_prep_xu) instead of on an event, which
     // between two kernels of this stream cost ~6 us of idle time
@@ -2517,10 +2660,12 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
         for (int b = tid; b < nK; b += 256) v[0] += partK[b];
         for (int b = tid; b < nR; b += 256) v[1] += partR[b];
         for (int e = tid; e < M; e += 256) {
-            v[2] += log(Lkuu[(size_t)e * Mp + e]);
+            if (!ldK) v[2] += log(Lkuu[(size_t)e * Mp + e]);
             v[4] = fma(B[e], mu[e], v[4]);
         }
-        for (int e = tid; e < Q; e += 256) v[3] += log(Llam[(size_t)(e + lam_off) * Qp + e + lam_off]);
+        if (ldK) for (int e = tid; e < nldK; e += 256) v[2] += ldK[e];
+        if (ldL) for (int e = tid; e < nldL; e += 256) v[3] += ldL[e];
+        else for (int e = tid; e < Q; e += 256) v[3] += log(Llam[(size_t)(e + lam_off) * Qp + e + lam_off]);
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
@@ -2567,8 +2712,10 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
     const double n = sc[2];
     const double sum_I1 = s_kk - tr[0];
     double ld_k = 0.0, ld_l = 0.0;
-    for (int e = tid; e < M; e += 256) ld_k += log(Lkuu[(size_t)e * Mp + e]);
-    for (int e = tid; e < Q; e += 256) ld_l += log(Llam[(size_t)(e + lam_off) * Qp + e + lam_off]);
+    if (ldK) { for (int e = tid; e < nldK; e += 256) ld_k += ldK[e]; }
+    else for (int e = tid; e < M; e += 256) ld_k += log(Lkuu[(size_t)e * Mp + e]);
+    if (ldL) { for (int e = tid; e < nldL; e += 256) ld_l += ldL[e]; }
+    else for (int e = tid; e < Q; e += 256) ld_l += log(Llam[(size_t)(e + lam_off) * Qp + e + lam_off]);
     ld_k = 2.0 * block_sum(ld_k, red);
     ld_l = 2.0 * block_sum(ld_l, red);
     const double LOG2PI = 1.8378770664093454835606594728112;
