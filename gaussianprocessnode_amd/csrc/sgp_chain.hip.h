@@ -1139,7 +1139,7 @@ __global__ void __launch_bounds__(256) k_chain_extras(double* __restrict__ A, in
         tile_from_index(e - nfin - npre, I, J);
         sigma_row_tile(Winv, Sacc, ld, j - 2, I, J, lds, tiles);
     } else {
-        tvec_role(A, Winv, tv_xi, tv_t, ld, j - 1, lds);
+        tvec_role<4>(A, Winv, tv_xi, tv_t, ld, j - 1, lds);
     }
 }
 

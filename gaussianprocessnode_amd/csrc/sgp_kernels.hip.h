@@ -1855,46 +1855,64 @@ __device__ __forceinline__ void sigma_row_tile(const double* __restrict__ W, dou
 // computable one launch after step i (W_ii) -- so t is complete when the factorisation is, and mu = P W^T t (and p = P t for
 // the closed-form Uv) follow with ONE mat-vec launch instead of two.
 // ------------------------------------------------------------------------------------------------
+// NP waves (4: a 256-thread launch; 8: all 512 threads of a k_potrf_step workgroup): wave `part` takes 64 / NP of the 64 columns of
+// every block.  Round 4: eight waves, four block columns' loads in flight (the whole of row 7 at M = 512 in two rounds), W_ii requested
+// with the first of them -- in the launch behind the last step this one workgroup was the last to leave (6.7 us against 5.2).
+template <int NP>
 __device__ __forceinline__ void tvec_role(const double* __restrict__ L, const double* __restrict__ W,
                                           const double* __restrict__ xi, double* __restrict__ t, int ld, int i, double* lds) {
-    double* red = lds;                  // [4][64]
-    double* rvec = lds + 4 * TB;        // [64]
+    constexpr int CP = TB / NP;         // columns per wave
+    double* red = lds;                  // [NP][64]
+    double* rvec = lds + NP * TB;       // [64]
     const int tid = threadIdx.x, r = tid & 63, part = tid >> 6;
+    const double* wb = W + (size_t)(i * TB + CP * part) * ld + i * TB + r;       // W_ii: lower triangular, zeros above
+    double wv[CP];
+#pragma unroll
+    for (int u = 0; u < CP; ++u) wv[u] = wb[(size_t)u * ld];
     double acc = 0.0;
     int k = 0;
-    for (; k + 2 <= i; k += 2) {                // two block columns' loads in flight (64 per thread with t); the FMAs keep the order k, u
-        double v[2][16], tv[2][16];
+    for (; k + 4 <= i; k += 4) {                // four block columns' loads in flight; the FMAs keep the order k, u
+        double v[4][CP], tv[4][CP];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const double* base = L + (size_t)((k + q) * TB + 16 * part) * ld + i * TB + r;
+        for (int q = 0; q < 4; ++q) {
+            const double* base = L + (size_t)((k + q) * TB + CP * part) * ld + i * TB + r;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { v[q][u] = base[(size_t)u * ld]; tv[q][u] = t[(k + q) * TB + 16 * part + u]; }
+            for (int u = 0; u < CP; ++u) { v[q][u] = base[(size_t)u * ld]; tv[q][u] = t[(k + q) * TB + CP * part + u]; }
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc = fma(v[q][u], tv[q][u], acc);
+            for (int u = 0; u < CP; ++u) acc = fma(v[q][u], tv[q][u], acc);
     }
     for (; k < i; ++k) {
-        const double* base = L + (size_t)(k * TB + 16 * part) * ld + i * TB + r;
-        double v[16];
+        const double* base = L + (size_t)(k * TB + CP * part) * ld + i * TB + r;
+        double v[CP];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = base[(size_t)u * ld];
+        for (int u = 0; u < CP; ++u) v[u] = base[(size_t)u * ld];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc = fma(v[u], t[k * TB + 16 * part + u], acc);
+        for (int u = 0; u < CP; ++u) acc = fma(v[u], t[k * TB + CP * part + u], acc);
     }
+    auto tree = [&](int row) {          // fixed order over the waves
+        double a[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) a[q] = red[q * TB + row];
+#pragma unroll
+        for (int w = 1; w < NP; w <<= 1)
+#pragma unroll
+            for (int q = 0; q + w < NP; q += 2 * w) a[q] += a[q + w];
+        return a[0];
+    };
     red[part * TB + r] = acc;
     __syncthreads();
-    if (part == 0) rvec[r] = xi[ld - 1 - (i * TB + r)] - ((red[r] + red[TB + r]) + (red[2 * TB + r] + red[3 * TB + r]));
+    if (part == 0) rvec[r] = xi[ld - 1 - (i * TB + r)] - tree(r);
     __syncthreads();
-    const double* wb = W + (size_t)(i * TB + 16 * part) * ld + i * TB + r;       // W_ii: lower triangular, zeros above
     double s = 0.0;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) s = fma(wb[(size_t)u * ld], rvec[16 * part + u], s);
+    for (int u = 0; u < CP; ++u) s = fma(wv[u], rvec[CP * part + u], s);
     __syncthreads();
     red[part * TB + r] = s;
     __syncthreads();
-    if (part == 0) t[i * TB + r] = (red[r] + red[TB + r]) + (red[2 * TB + r] + red[3 * TB + r]);
+    if (part == 0) t[i * TB + r] = tree(r);
 }
 
 // xi = xi0 + vec(B W) of the Lambda chain's step 0 (one workgroup, 256 threads)
@@ -1981,23 +1999,23 @@ __global__ void __launch_bounds__(PSTEP_THREADS) k_potrf_step(double* __restrict
     {
         const int npot = (Tn - j) * (Tn - j + 1) / 2 + potrf_twins(Tn, j);   // this step's own tiles (and the twins of the
         if ((int)blockIdx.x >= npot) {                    // block below the diagonal); the workgroups beyond them work on
-            if (xgroup) return;                           // the inverse factor (winv_row_tile): finish block row j - 1,
-            int e = blockIdx.x - npot;                    // then pre-accumulate block row j; Sigma = W^T W collects the
-            const int nfin = (j >= 2) ? 2 * (j - 1) : 0;  // contribution of block row j - 2 (sigma_row_tile); and one
-            const int npre = (j < Tn) ? nfin : 0;         // workgroup advances the forward solve t = W (P xi) (tvec_role)
+            int e = blockIdx.x - npot;                    // the inverse factor (winv_row_tile): finish block row j - 1,
+            const int nfin = (j >= 2) ? 2 * (j - 1) : 0;  // then pre-accumulate block row j; Sigma = W^T W collects the
+            const int npre = (j < Tn) ? nfin : 0;         // contribution of block row j - 2 (sigma_row_tile); and one
+                                                          // workgroup advances the forward solve t = W (P xi) (tvec_role)
             // (not in the launch behind the last step, j == Tn: nothing hides that launch, and a 64^3 product per workgroup --
             // 64 dependent-issue MFMAs per wave, 2.8 us -- made its Sigma workgroups the last to leave, 7.7 us against the 5.1 of
             // the inverse factor's; the product launch behind it, whose workgroups are a quarter of the size, adds the last TWO
             // block rows instead)
             const int nsig = (Sacc && j >= 2 && j < Tn) ? (j - 1) * j / 2 : 0;
+            if (e >= nfin + npre + nsig) { tvec_role<8>(A, Winv, tv_xi, tv_t, ld, j - 1, lds); return; }     // (all eight waves)
+            if (xgroup) return;
             if (e < nfin) winv_row_tile(A, Winv, ld, j - 1, e >> 1, e & 1, lds, 2, tiles);
             else if (e < nfin + npre) { e -= nfin; winv_row_tile(A, Winv, ld, j, e >> 1, e & 1, lds, 1); }
             else if (e < nfin + npre + nsig) {
                 int I, J;
                 tile_from_index(e - nfin - npre, I, J);   // I >= J, I <= j - 2
                 sigma_row_tile(Winv, Sacc, ld, j - 2, I, J, lds, tiles);
-            } else {
-                tvec_role(A, Winv, tv_xi, tv_t, ld, j - 1, lds);
             }
             return;
         }

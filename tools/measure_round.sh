@@ -1,24 +1,26 @@
 #!/bin/bash
-# Every measurement behind profiles/r04_* and DESIGN.md's measured-state section, in one GPU call:
-#   gpurun --timeout 1200 -- 'bash tools/measure_round.sh 2>&1 | tail -40'
-# Outputs land under gpurun_out/final4/ (tests, bench line, rocprofv3 kernel trace + stats, per-launch SYRK list, the PMC passes,
-# the traffic record bench.py reads, in-kernel sweep timelines, BASELINE config rates, accuracy sweep, the training runs, a hooked
-# training run's kernel counts); copy what is judged into profiles/.
+# Every measurement behind profiles/r04_* and DESIGN.md's measured-state section, in TWO GPU calls (one call may run 20 minutes):
+#   gpurun --timeout 1200 -- 'bash tools/measure_round.sh prof'     tests, the rocprofv3 passes (PMC counters, kernel trace + stats)
+#   gpurun --timeout 1200 -- 'bash tools/measure_round.sh rest'     bench lines, in-kernel timelines, config rates, accuracy, training
+# Outputs land under gpurun_out/final4/; copy what is judged into profiles/ (tools/collect_profiles.py).
+# Under the profiler bench.py times ONE block (--blocks 1): the counter passes serialise the kernels, and 15 blocks of sweeps whose
+# streams meet through device words took longer than the passes' 300 s limit.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final4; mkdir -p $O
 cd $R
+if [ "$1" = "prof" ]; then
 timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c && SGP_BENCH_SKIP_ALONE=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/pmc_$c.err
+  rm -rf /tmp/pmc_$c && SGP_BENCH_SKIP_ALONE=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --steps 20 --warmup 3 --blocks 1 --no-cpu-baseline > /dev/null 2> $O/pmc_$c.err
   h=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1); cp $h $O/pmc_$c.csv; python3 $R/tools/pmc_summary.py $h $c > $O/pmc_$c.txt 2>&1; echo "pmc $c done"
 done
 python3 $R/tools/pmc_traffic_json.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv T $O/pmc_traffic.json; cp $O/pmc_traffic.json $R/profiles/r04_pmc_traffic.json
-rm -rf /tmp/pmc_m && SGP_BENCH_SKIP_ALONE=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_m -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/pmc_mfma.err
+rm -rf /tmp/pmc_m && SGP_BENCH_SKIP_ALONE=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_m -- python3 $R/bench.py --steps 20 --warmup 3 --blocks 1 --no-cpu-baseline > /dev/null 2> $O/pmc_mfma.err
 h=$(find /tmp/pmc_m -name "*counter_collection.csv" | head -1); python3 $R/tools/pmc_mfma_summary.py $h > $O/pmc_mfma.txt 2>&1; echo "pmc mfma done"
-rm -rf /tmp/pmc_v && SGP_BENCH_SKIP_ALONE=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_v -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/pmc_valu.err
+rm -rf /tmp/pmc_v && SGP_BENCH_SKIP_ALONE=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_v -- python3 $R/bench.py --steps 20 --warmup 3 --blocks 1 --no-cpu-baseline > /dev/null 2> $O/pmc_valu.err
 h=$(find /tmp/pmc_v -name "*counter_collection.csv" | head -1); python3 $R/tools/pmc_valu_summary.py $h > $O/pmc_valu.txt 2>&1; echo "pmc valu done"
-rm -rf /tmp/kt && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline > $O/kt.json 2> $O/kt.err
+rm -rf /tmp/kt && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 60 --warmup 10 --blocks 1 --no-cpu-baseline > $O/kt.json 2> $O/kt.err
 f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); g=$(find /tmp/kt -name "*kernel_stats.csv" | head -1)
 python3 $R/tools/syrk_launches.py $f > $O/syrk_launches.txt 2>&1; cp $g $O/kernel_stats.csv; python3 $R/tools/kstats.py $g auto > $O/kernel_stats_per_sweep.txt 2>&1
 echo "trace done"
@@ -26,6 +28,8 @@ echo "trace done"
 rm -rf /tmp/kh && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kh -- python3 $R/tools/hooked_train.py > $O/hooked_train.json 2> $O/hooked_train.err
 echo "profiled hooked_train exit code: $?" > $O/hooked_train_rc.txt; cat $O/hooked_train_rc.txt
 g=$(find /tmp/kh -name "*kernel_stats.csv" | head -1); python3 $R/tools/kstats.py $g auto > $O/hooked_train_kernel_stats.txt 2>&1; echo "hooked train done"
+fi
+if [ "$1" = "rest" ]; then
 cd $R
 timeout -k 10 300 python bench.py > $O/bench_T.json 2> $O/bench_T.err; tail -c 400 $O/bench_T.json; echo
 SGP_OVERLAP=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_T_plain_order.json 2> /dev/null
@@ -45,3 +49,5 @@ timeout -k 10 200 python tools/wstats_time.py 2>&1 | grep -v amdgpu > $O/wstats_
 SGP_SYRK_WIDE=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_T_syrk_256_threads.json 2> /dev/null
 [ -f gaussianprocessnode_amd/csrc/libsgp_hip_base.so ] && cp gaussianprocessnode_amd/csrc/libsgp_hip.so gaussianprocessnode_amd/csrc/libsgp_hip_fin.so && bash tools/ab_multi.sh 3 "round3_library|base|" "round4_library|fin|" "round4_256_thread_syrk|fin|SGP_SYRK_WIDE=0" > $O/ab_r3_vs_r4.txt 2>&1; cat $O/ab_r3_vs_r4.txt
 echo "measure_round done"
+
+fi
