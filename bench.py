@@ -152,7 +152,7 @@ def scaling_leg(world, rank, local_rank, barrier):
     sw = ShardedSweep(eng)
     for _ in range(3):
         sw.sweep()
-    barrier()
+    dev.wait(); barrier()
     dev.phase_totals(reset=True)
     steps, block_s = 10, []
     for _ in range(3):
@@ -160,7 +160,7 @@ def scaling_leg(world, rank, local_rank, barrier):
         t0 = time.perf_counter()
         for _ in range(steps):
             sw.sweep()
-        barrier()
+        dev.wait(); barrier()
         block_s.append(time.perf_counter() - t0)
     if world > 1:
         t = torch.tensor(block_s, dtype=torch.float64, device="cuda")
@@ -234,6 +234,10 @@ def main():
     sweep = ShardedSweep(eng)
 
     def barrier():
+        # (sgp_wait first: it POLLS the library's streams, so the blocking synchronize behind it returns at once -- a blocking wait
+        # alone may sleep until an interrupt, tens of microseconds that are the host's, not the sweep's, and that weigh on a block
+        # of 20 sweeps.  The bracket the contract asks for -- synchronize, barrier, synchronize -- is unchanged.)
+        dev.wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

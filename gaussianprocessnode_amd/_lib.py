@@ -29,7 +29,7 @@ EXPORTS = [
     "sgp_get_kuu_chol", "sgp_get_wishart_invscale", "sgp_w_stats", "sgp_predict", "sgp_theta_objective", "sgp_carry_posterior", "sgp_set_posterior",
     "sgp_kernelmatrix", "sgp_potrf", "sgp_potri", "sgp_get_timestamps", "sgp_get_phase_totals", "sgp_time_kernel", "sgp_get_chain_trace", "sgp_set_allreduce", "sgp_use_rccl", "sgp_measure_sclk_mhz",
     "sgp_train_begin", "sgp_train_step", "sgp_train_end", "sgp_get_step_trace", "sgp_measure_clocks", "sgp_overlap_plan",
-    "sgp_get_sweep_trace", "sgp_train_likelihood", "sgp_train_get_gamma",
+    "sgp_get_sweep_trace", "sgp_train_likelihood", "sgp_train_get_gamma", "sgp_wait",
 ]
 SGP_TIME_GROUP0 = 100
 SGP_TIME_QUADFORM = 120
@@ -129,6 +129,7 @@ def load(build_if_missing: bool = True, variant=None):
     lib.sgp_get_sweep_trace.argtypes = [C.POINTER(C.c_int64)]
     lib.sgp_train_likelihood.argtypes = [vp, C.c_int32, C.c_double, C.c_double]
     lib.sgp_train_get_gamma.argtypes = [vp, dp]
+    lib.sgp_wait.argtypes = [vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "sgp_last_error":

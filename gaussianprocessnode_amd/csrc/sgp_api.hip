@@ -1623,6 +1623,11 @@ static int sync_all(sgp_handle* h) {
 // A bounded wait on a device word gave up somewhere since the last check (dInfo[3], see SYNC_LATE_* in sgp_kernels.hip.h): what
 // the wait protected -- the buffers the two streams hand each other -- cannot be trusted, so the results are refused by EVERY
 // getter, until the next sweep is enqueued (sweep_local_impl clears the word then).  Call after a device synchronisation.
+extern "C" int sgp_wait(sgp_handle* h) {
+    if (!h) return SGP_ERR_ARG;
+    return sync_all(h);
+}
+
 static int check_sync_status(sgp_handle* h) {
     int bits = 0;
     HIPCHK(h, hipMemcpy(&bits, h->dInfo + 3, sizeof(int), hipMemcpyDeviceToHost));

@@ -1870,27 +1870,20 @@ __device__ __forceinline__ void tvec_role(const double* __restrict__ L, const do
 #pragma unroll
     for (int u = 0; u < CP; ++u) wv[u] = wb[(size_t)u * ld];
     double acc = 0.0;
-    int k = 0;
-    for (; k + 4 <= i; k += 4) {                // four block columns' loads in flight; the FMAs keep the order k, u
-        double v[4][CP], tv[4][CP];
+    for (int k = 0; k < i; k += 4) {            // four block columns' loads in flight; the FMAs keep the order k, u.  (A short last batch
+        double v[4][CP], tv[4][CP];             // is padded with clamped loads that are multiplied away: no one-column rounds.)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const double* base = L + (size_t)((k + q) * TB + CP * part) * ld + i * TB + r;
+            const int kq = (k + q < i) ? k + q : i - 1;
+            const double live = (k + q < i) ? 1.0 : 0.0;
+            const double* base = L + (size_t)(kq * TB + CP * part) * ld + i * TB + r;
 #pragma unroll
-            for (int u = 0; u < CP; ++u) { v[q][u] = base[(size_t)u * ld]; tv[q][u] = t[(k + q) * TB + CP * part + u]; }
+            for (int u = 0; u < CP; ++u) { v[q][u] = base[(size_t)u * ld]; tv[q][u] = t[kq * TB + CP * part + u] * live; }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int u = 0; u < CP; ++u) acc = fma(v[q][u], tv[q][u], acc);
-    }
-    for (; k < i; ++k) {
-        const double* base = L + (size_t)(k * TB + CP * part) * ld + i * TB + r;
-        double v[CP];
-#pragma unroll
-        for (int u = 0; u < CP; ++u) v[u] = base[(size_t)u * ld];
-#pragma unroll
-        for (int u = 0; u < CP; ++u) acc = fma(v[u], t[k * TB + CP * part + u], acc);
     }
     auto tree = [&](int row) {          // fixed order over the waves
         double a[NP];

@@ -175,6 +175,10 @@ class SGPDevice:
     def sweep(self, stream: int = 0):
         self._check(self._lib.sgp_sweep(self._h, C.c_void_p(stream)), "sgp_sweep")
 
+    def wait(self):
+        """Returns when everything this handle has enqueued has finished (polled, then blocking: sgp_wait)."""
+        self._check(self._lib.sgp_wait(self._h), "sgp_wait")
+
     def stats_layout(self):
         p, cnt, mp = C.c_void_p(), C.c_int64(), C.c_int32()
         self._check(self._lib.sgp_stats_layout(self._h, C.byref(p), C.byref(cnt), C.byref(mp)), "sgp_stats_layout")

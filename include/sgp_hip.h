@@ -195,6 +195,12 @@ int sgp_w_stats(sgp_handle* h, double* I1 /* n */, double* I2 /* n */, void* str
  * mu_v (host, d_out*M) or NULL to use the handle's current posterior; mean is ns x d_out. */
 int sgp_predict(sgp_handle* h, const double* Xstar, int64_t ns, const double* mu_v, double* mean);
 
+/* sgp_wait: returns when everything this handle has enqueued -- on its own streams or the caller's -- has finished: what a caller
+ * does between `infer` calls when it wants the sweep to be over but none of its results yet.  The library's streams are polled
+ * (hipStreamQuery, up to ~2 ms, then the blocking call): a blocking hipDeviceSynchronize may put the thread to sleep until an
+ * interrupt, tens of microseconds behind a 0.22 ms sweep.  The getters wait the same way. */
+int sgp_wait(sgp_handle* h);
+
 /* sgp_theta_objective: neg_log_backwardmess_fast (helper_functions/derivative_helper.jl:23-39) evaluated at the CURRENT
  * kernel parameters (sgp_set_kernel) with q(v) -- mu_v and Uv'Uv -- held at the last finished sweep, as the notebooks use
  * it (experiments/regression_kin40k.ipynb:212-221).  grad (may be NULL): d/d(sigma2, ell_1..ell_n_ell), 1 + n_ell

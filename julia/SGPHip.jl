@@ -82,6 +82,7 @@ set_prior!(h::Handle, vec, mat::Matrix{Float64}, form) =
     check(ccall((:sgp_set_prior, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32), h.ptr, vec, mat, form), h.ptr)
 sweep!(h::Handle) = check(ccall((:sgp_sweep, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h.ptr, C_NULL), h.ptr)
 sweep_local!(h::Handle) = check(ccall((:sgp_sweep_local, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h.ptr, C_NULL), h.ptr)
+wait!(h::Handle) = check(ccall((:sgp_wait, LIB), Cint, (Ptr{Cvoid},), h.ptr), h.ptr)      # polled drain of the handle's streams
 
 function posterior(h::Handle)
     Q = h.m * h.d_out
