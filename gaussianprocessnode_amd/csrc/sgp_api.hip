@@ -200,6 +200,7 @@ struct sgp_handle {
     int env_g1_mode = 2;           // SGP_G1_AFTER (see enqueue_stats_overlapped)
     int env_syrk_wt = 0;           // SGP_SYRK_WT (see plan_overlap)
     bool env_syrk_wide = true;     // SGP_SYRK_WIDE=0: the 256-thread SYRK everywhere (A/B switch)
+    int64_t gate_min = 200000;     // points x lower tiles from which the SYRK is taken to fill the chip (SGP_GATE_MIN: A/B switch)
     bool syrk_wide = false;        // the resident problem's SYRK launches are k_syrk_stream16 (set_point_count)
     std::vector<int> env_overlap_cols;   // SGP_OVERLAP_COLS: group boundaries (tile columns of P Lambda P), e.g. "3" or "2,4"
     int nblk = 0, ntiles = 0, num_cus = 256;
@@ -566,6 +567,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         if (const char* g1 = getenv("SGP_G1_AFTER")) h->env_g1_mode = atoi(g1);
         if (const char* wt = getenv("SGP_SYRK_WT")) h->env_syrk_wt = atoi(wt);
         if (const char* sw = getenv("SGP_SYRK_WIDE")) h->env_syrk_wide = atoi(sw) != 0;
+        if (const char* gm = getenv("SGP_GATE_MIN")) h->gate_min = atoll(gm);
         if (const char* oc = getenv("SGP_OVERLAP_COLS"))
             for (const char* q = oc; *q;) {
                 h->env_overlap_cols.push_back(atoi(q));
@@ -864,7 +866,7 @@ static int set_point_count(sgp_handle* h, int64_t n) {
     // (enqueue_kuu), so nothing is reserved for it and the grid is sized for all CUs (T: 25 -> 28 chunks, 62.7 -> 57.4 us; the
     // chain then runs after the SYRK and still ends ~9 us before its join).  Small problems keep the early chain: there the
     // two chains are the sweep, and a late K_uu chain is waited for (C1: -15 %, C5: -2 % with the gate).
-    h->gate_side = n * (int64_t)h->ntiles >= 200000 && h->dJoin && !(h->cfg.flags & SGP_FLAG_GRAPH) && !h->use_chain &&
+    h->gate_side = n * (int64_t)h->ntiles >= h->gate_min && h->dJoin && !(h->cfg.flags & SGP_FLAG_GRAPH) && !h->use_chain &&
                    !h->env_no_gate;
     // (the in-CU split needs the whole LDS of a CU: only where the K_uu chain is gated behind this launch, i.e. the SYRK fills the chip)
     h->syrk_wide = h->gate_side && h->env_syrk_wide;
