@@ -201,7 +201,7 @@ struct sgp_handle {
     int env_syrk_wt = 0;           // SGP_SYRK_WT (see plan_overlap)
     bool env_syrk_wide = true;     // SGP_SYRK_WIDE=0: the 256-thread SYRK everywhere (A/B switch)
     int64_t gate_min = 200000;     // points x lower tiles from which the SYRK is taken to fill the chip (SGP_GATE_MIN: A/B switch)
-    bool syrk_wide = false;        // the resident problem's SYRK launches are k_syrk_stream16 (set_point_count)
+    bool syrk_wide = false;        // the resident problem's SYRK launches are k_syrk_direct (set_point_count)
     std::vector<int> env_overlap_cols;   // SGP_OVERLAP_COLS: group boundaries (tile columns of P Lambda P), e.g. "3" or "2,4"
     int nblk = 0, ntiles = 0, num_cus = 256;
     SyrkGeom geom{};               // the plain sweep's single SYRK launch over all tile rows (set_point_count)
@@ -312,16 +312,16 @@ static int quiesce(sgp_handle* h) {
 #ifndef SYRK_RESERVED_CUS
 #define SYRK_RESERVED_CUS 8
 #endif
-// wide (round 4): the launch is k_syrk_stream16 -- ONE 1024-thread workgroup per CU, whose four wave groups split the item's chunk
-// once more and add their partial tiles up in LDS: a quarter of the slabs for the same split of the point axis.  Any item count
-// works there (its block map pads to a multiple of 8); a chunk is a multiple of 4 KB points.
+// wide (round 4): the launch is k_syrk_direct -- ONE 512-thread workgroup per CU, whose eight waves take the item's k-steps (4 points)
+// round-robin, each with the whole tile in its accumulators, and add their partial tiles up in LDS: one slab per CU.  Any item count
+// works there (its block map pads to a multiple of 8); a chunk is a multiple of 4 SYRK_WAVES points (whole rounds of k-steps).
 static SyrkGeom syrk_geometry(int row_lo, int nrows, int cus, int64_t n, bool wide = false) {
     SyrkGeom g;
     g.row_lo = row_lo;
     g.nrows = nrows;
     g.tile0 = row_lo * (row_lo + 1) / 2;
     g.ntiles = (row_lo + nrows) * (row_lo + nrows + 1) / 2 - g.tile0;
-    g.chunk = wide ? 4 * KB : KB;
+    g.chunk = wide ? 4 * SYRK_WAVES : KB;
     g.nchunks = 0;
     g.write_through = 0;
     g.wide = wide ? 1 : 0;
@@ -329,7 +329,7 @@ static SyrkGeom syrk_geometry(int row_lo, int nrows, int cus, int64_t n, bool wi
     if (wide) {
         const int want = std::max(1, std::max(8, cus) / g.ntiles);
         int64_t per = (n + want - 1) / want;
-        per = std::max<int64_t>(4 * KB, (per + 4 * KB - 1) / (4 * KB) * (4 * KB));
+        per = std::max<int64_t>(4 * SYRK_WAVES, (per + 4 * SYRK_WAVES - 1) / (4 * SYRK_WAVES) * (4 * SYRK_WAVES));
         g.chunk = (int)per;
         g.nchunks = (int)std::max<int64_t>(1, (n + per - 1) / per);
         return g;
@@ -354,7 +354,7 @@ static inline unsigned assemble_z(const SyrkGeom& g) { return g.nchunks <= 24 ? 
 static void launch_syrk(const SyrkGeom& g, hipStream_t s, const double* Kuf, const double* omega, double* slabs, int Mp, int64_t n,
                         int64_t* stamps, long long* gate, long long gate_value) {
     if (g.wide)
-        hipLaunchKernelGGL(k_syrk_stream16, dim3((unsigned)((syrk_items(g) + 7) / 8 * 8)), dim3(SYRK16_THREADS), 0, s, Kuf, omega, slabs, Mp, n,
+        hipLaunchKernelGGL(k_syrk_direct, dim3((unsigned)((syrk_items(g) + 7) / 8 * 8)), dim3(SYRK_DIRECT_THREADS), 0, s, Kuf, omega, slabs, Mp, n,
                            g, stamps, gate, gate_value);
     else
         hipLaunchKernelGGL(k_syrk_stream, dim3((unsigned)syrk_items(g)), dim3(256), 0, s, Kuf, omega, slabs, Mp, n, g, stamps, gate,
@@ -773,12 +773,14 @@ extern "C" int sgp_set_inducing(sgp_handle* h, const double* Xu) {
 //     order stays (huge N: the masked groups' lost CUs cost more than the chain's early start saves).
 static double model_overlap_end(const sgp_handle* h, int64_t n, const int* cuts, int ncuts, double* classic_end) {
     const int T = h->T;
-    // one SYRK launch = one resident round: its duration follows the points per chunk (0.18 us per point at four workgroups
-    // per CU, + ~5 us of launch ramp and tail), whatever the number of tiles -- fewer CUs or an awkward tile count show up as
+    // one SYRK launch = one resident round: its duration follows the points per chunk (k_syrk_stream: 0.18 us per point at four
+    // workgroups per CU, + ~5 us of launch ramp and tail; k_syrk_direct: 0.029 us per point -- eight waves share the chunk, two to a
+    // SIMD, 16 MFMAs of 64 cycles per 4 points each, at the 71 TFLOP/s it attains -- + ~13 us of ramp, first loads, the partial
+    // tiles' meeting in LDS and the slab store), whatever the number of tiles -- fewer CUs or an awkward tile count show up as
     // fewer, longer chunks (syrk_geometry)
     auto syrk_us = [&](int row_lo, int nrows, int cus) {
         const SyrkGeom g = syrk_geometry(row_lo, nrows, cus, n, h->syrk_wide);
-        return 5.0 + 0.18 * (g.wide ? g.chunk / 4 : g.chunk);       // (a wave group's share of the chunk)
+        return g.wide ? 13.0 + 0.029 * g.chunk : 5.0 + 0.18 * g.chunk;
     };
     // assembly + gaps behind a group's SYRK (unmasked / masked); a chain step with its launch gap (18 before the step kernel's
     // rework of round 3); and how long before its step a group should be there: a step that finds its group's word unset waits

@@ -573,33 +573,36 @@ __device__ __forceinline__ void syrk_item(const double* __restrict__ Kuf, const 
     const int p = tid >> 4, rq = tid & 15;
     Acc4 acc;
     acc_zero(acc);
-    double ra[4], rb[4];
+    // (gload only REQUESTS stage s + 1; the values are first touched in lstore, behind stage s's products: the weighting by omega
+    // used to sit in gload, and the s_waitcnt vmcnt(0) it needs then lands in FRONT of the MFMAs -- every stage sat out its whole
+    // memory latency before its products)
+    double2 ra[2], rb[2];
+    double rw = 1.0;
+    const bool offdiag = DIAG ? false : (I != J);         // (a diagonal tile reads its rows once)
     auto gload = [&](int s) {
         int64_t n = nbeg + (int64_t)s * KB + p;
+        ra[0] = ra[1] = rb[0] = rb[1] = make_double2(0.0, 0.0);
         if (n < nend) {
             const double* src = Kuf + (size_t)n * Mp + I * TB + rq * 4;
-            double2 v0 = *reinterpret_cast<const double2*>(src);
-            double2 v1 = *reinterpret_cast<const double2*>(src + 2);
-            ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
-            double w = omega ? omega[n] : 1.0;
-            if (DIAG ? false : (I != J)) {                // (a diagonal tile reads its rows once)
+            ra[0] = *reinterpret_cast<const double2*>(src);
+            ra[1] = *reinterpret_cast<const double2*>(src + 2);
+            if (omega) rw = omega[n];
+            if (offdiag) {
                 const double* sb = Kuf + (size_t)n * Mp + J * TB + rq * 4;
-                double2 u0 = *reinterpret_cast<const double2*>(sb);
-                double2 u1 = *reinterpret_cast<const double2*>(sb + 2);
-                rb[0] = u0.x * w; rb[1] = u0.y * w; rb[2] = u1.x * w; rb[3] = u1.y * w;
-            } else {
-                rb[0] = ra[0] * w; rb[1] = ra[1] * w; rb[2] = ra[2] * w; rb[3] = ra[3] * w;
+                rb[0] = *reinterpret_cast<const double2*>(sb);
+                rb[1] = *reinterpret_cast<const double2*>(sb + 2);
             }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { ra[q] = 0.0; rb[q] = 0.0; }
         }
     };
     auto lstore = [&](int buf) {
         double* A = lds + buf * (2 * KB * PS) + p * PS + rq * 4;
         double* B = A + KB * PS;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { A[q] = ra[q]; B[q] = rb[q]; }
+        double2 b0 = offdiag ? rb[0] : ra[0], b1 = offdiag ? rb[1] : ra[1];
+        if (omega) { b0.x *= rw; b0.y *= rw; b1.x *= rw; b1.y *= rw; }
+        *reinterpret_cast<double2*>(A) = ra[0];
+        *reinterpret_cast<double2*>(A + 2) = ra[1];
+        *reinterpret_cast<double2*>(B) = b0;
+        *reinterpret_cast<double2*>(B + 2) = b1;
     };
     if (stages > 0) {
         gload(0);
@@ -667,7 +670,7 @@ struct SyrkGeom {
     int tile0, ntiles;              // their lower tiles
     int chunk, nchunks;             // split of the point axis
     int write_through;              // slabs stored past the L2 (launches that run beside the factorisation chains)
-    int wide;                       // 1: launched as k_syrk_stream16 (one 1024-thread workgroup per CU, `chunk` points = 4 sub-chunks)
+    int wide;                       // 1: launched as k_syrk_direct (one 512-thread workgroup per CU, no LDS staging; `chunk` a multiple of 4 points)
 };
 __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ Kuf, const double* __restrict__ omega,
                                                      double* __restrict__ slabs, int Mp, int64_t N, SyrkGeom g, int64_t* stamps,
@@ -704,140 +707,163 @@ __global__ void __launch_bounds__(256) k_syrk_stream(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same work item with the split of the point axis continued INSIDE the workgroup (round 4): 1024 threads = four groups of four
-// waves; group q streams sub-chunk q of the item's chunk exactly as a 256-thread workgroup of k_syrk_stream would (its own
-// double-buffered LDS panels: the CU holds the same 16 waves and the same LDS as with four 256-thread workgroups), and the four
-// partial tiles meet in LDS at the end -- summed in fixed order -- so that ONE slab leaves the CU instead of four.  The slabs were
-// the sweep's wasted traffic (123 MB per sweep against 43 MB algorithmic): 1 728 slabs of 32 KB written by the two
-// group launches and read back by k_assemble, whose 7 us in front of the Lambda chain are those reads.
-// LDS: four groups x 2 buffers x 2 panels x KB x PS doubles = 163 840 bytes, all a CU has; the reduction reuses it (a group's
-// 64 x 64 partial tile fits in its own 40 960 bytes).
-constexpr int PSS = PS;
-constexpr int SYRK16_THREADS = 1024;
-__global__ void __launch_bounds__(SYRK16_THREADS) k_syrk_stream16(const double* __restrict__ Kuf, const double* __restrict__ omega,
-                                                                  double* __restrict__ slabs, int Mp, int64_t N, SyrkGeom g,
-                                                                  int64_t* stamps, long long* gate, long long gate_value) {
-    __shared__ __attribute__((aligned(16))) double lds[4 * 2 * 2 * KB * PSS];
+// The same work item WITHOUT LDS staging (round 4, `wide` launches: wherever the SYRK fills the chip).  Every wave owns the WHOLE
+// 64 x 64 tile over its share of the item's points -- 16 accumulators of v_mfma_f64_16x16x4_f64 -- and loads its operands from
+// global memory straight into the registers the matrix instruction reads: lane (lk, li) of operand block u supplies
+// K_uf[n0 + lk][64 I + 16 u + li], i.e. 16 lanes = one 128-byte line of a K_uf row, SYRK_P k-steps (of 4 points) ahead.  No
+// barrier, no LDS traffic and no meeting of waves inside the loop: a wave waits for nothing but its own loads, and those are
+// SYRK_P - 1 steps old when it needs them.  The eight waves of a workgroup (two per SIMD: one fills the other's issue gaps) take the
+// chunk's k-steps round-robin, add their partial tiles up in LDS at the end in fixed order (two rounds of four tiles: 128 KB) and
+// ONE slab leaves the CU, as with round 4's first form of this launch (k_syrk_stream16: four LDS-staged wave groups per CU, each
+// meeting on an LDS counter per 16-point stage).
+// Why: tools/dpp_f64_probe.hip showed that LDS-fed v_mfma_f64 attains 63 / 72 / 73 TFLOP/s at 1 / 2 / 4 waves per SIMD on this
+// chip -- rounds 1-3 had priced the matrix pipe at 46 - 48 from a probe whose loop the compiler had filled with accumulator
+// copies -- while k_syrk_stream16 ran at 49 (N = 10^6) and 38 (T): timing variants without its group meetings / global loads / LDS
+// stores gained 7 % each and 20 % together (gpurun_out/r4r), and what was left was still the staging structure.  This kernel:
+// 71 TFLOP/s executed at N = 10^6 (4.14 instead of 5.36 ms), T's group launches 38.7 / 36.9 instead of 44.3 / 42.5 us
+// (tools/syrk_direct_probe.hip, profiles/r04_ab_log.txt [14]-[16]).
+// The k-step loop has NO branch inside: the compiler's s_waitcnt placement is exact only for a straight-line round (with a
+// conditional product in it, it drained all loads at the loop header); loads past the wave's last k-step are clamped to that step
+// (harmless re-reads), the last nt mod SYRK_P products follow behind the loop, a ragged last k-step (chunk end not a multiple of
+// 4) is formed by the wave whose turn it is, unpipelined, with zeros for the missing points.
+// ------------------------------------------------------------------------------------------------
+constexpr int SYRK_WAVES = 8;
+constexpr int SYRK_P = 5;               // k-steps in flight (per-point weights: 4 -- the weights and the weighted operands need the registers)
+constexpr int SYRK_DIRECT_THREADS = 64 * SYRK_WAVES;
+template <bool DIAG, bool WEIGHTED>
+__device__ __forceinline__ void syrk_direct_stream(d4 (&acc)[4][4], const double* __restrict__ pa, const double* __restrict__ pb,
+                                                   const double* __restrict__ pw, size_t step, int nt) {
+    constexpr int P = WEIGHTED ? 4 : SYRK_P;
+    double a[P][4], b[P][4], w[P];
+    auto load = [&](int p, int t) {
+        const double* qa = pa + (size_t)t * step;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[p][u] = qa[16 * u];
+        if constexpr (!DIAG) {
+            const double* qb = pb + (size_t)t * step;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[p][u] = qb[16 * u];
+        }
+        if constexpr (WEIGHTED) w[p] = pw[(size_t)t * 4 * SYRK_WAVES];
+    };
+    auto mma = [&](int p) {
+        double bw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bw[u] = DIAG ? a[p][u] : b[p][u];
+            if constexpr (WEIGHTED) bw[u] *= w[p];
+        }
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p][ti], bw[tj], acc[ti][tj], 0, 0, 0);
+    };
+    if (nt <= 0) return;
+#pragma unroll
+    for (int p = 0; p < P; ++p) load(p, p < nt ? p : nt - 1);
+    int t0 = 0;
+    for (; t0 + P <= nt; t0 += P) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            mma(p);
+            const int tn = t0 + p + P;
+            load(p, tn < nt ? tn : nt - 1);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P - 1; ++p)
+        if (t0 + p < nt) mma(p);
+}
+
+__global__ void __launch_bounds__(SYRK_DIRECT_THREADS) k_syrk_direct(const double* __restrict__ Kuf, const double* __restrict__ omega,
+                                                                     double* __restrict__ slabs, int Mp, int64_t N, SyrkGeom g,
+                                                                     int64_t* stamps, long long* gate, long long gate_value) {
+    __shared__ __attribute__((aligned(16))) double lds[4 * TB * TB];
     TraceScope trace(64 + g.tile0);
     stamp_enter(stamps);
     // XCD-aware block -> item map for ANY item count: the items, ordered chunk-major, are cut into 8 runs of `per` items, one per
     // XCD (workgroups are dealt round-robin over the XCDs); the grid has 8 * per blocks, the surplus ones leave
     const int nitems = g.ntiles * g.nchunks, per = (nitems + 7) >> 3;
     const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    // the last workgroup of this launch's single resident round is on a CU: whoever waited for that (the K_uu chain's first
+    // kernel) may take the CUs that are left
     if (gate && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
         __hip_atomic_store(gate, gate_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (item >= nitems) return;                       // (whole workgroup: no barrier is left behind)
     const int chunk_id = item / g.ntiles, tile_id = item % g.ntiles;
     int I, J;
     tile_from_index(g.tile0 + tile_id, I, J);
-    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    const int sub = g.chunk >> 2;                     // points per group (a multiple of KB)
-    const int64_t nbeg = (int64_t)chunk_id * g.chunk + (int64_t)grp * sub;
-    int64_t nend = nbeg + sub;
-    if (nend > N) nend = N;
-    // every group runs the SAME number of stages (the workgroup barrier below is shared): the longest group's, empty stages are zeros
-    const int64_t wg_beg = (int64_t)chunk_id * g.chunk;
-    const int64_t wg_len = (N > wg_beg) ? ((N - wg_beg < (int64_t)sub) ? (N - wg_beg) : (int64_t)sub) : 0;
-    const int stages = (int)((wg_len + KB - 1) / KB);
-    double* my = lds + grp * (2 * 2 * KB * PSS);
-    const int p = tid >> 4, rq = tid & 15;            // staging map: thread -> (point p, row quad rq): 32 B of one K_uf column
-    Acc4 acc;
-    acc_zero(acc);
-    double ra[4], rb[4];
-    auto gload = [&](int s) {
-        const int64_t n = nbeg + (int64_t)s * KB + p;
-        if (n < nend) {
-            const double* src = Kuf + (size_t)n * Mp + I * TB + rq * 4;
-            const double2 v0 = *reinterpret_cast<const double2*>(src), v1 = *reinterpret_cast<const double2*>(src + 2);
-            ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
-            const double w = omega ? omega[n] : 1.0;
-            if (I != J) {
-                const double* sb = Kuf + (size_t)n * Mp + J * TB + rq * 4;
-                const double2 u0 = *reinterpret_cast<const double2*>(sb), u1 = *reinterpret_cast<const double2*>(sb + 2);
-                rb[0] = u0.x * w; rb[1] = u0.y * w; rb[2] = u1.x * w; rb[3] = u1.y * w;
-            } else {
-                rb[0] = ra[0] * w; rb[1] = ra[1] * w; rb[2] = ra[2] * w; rb[3] = ra[3] * w;
-            }
-        } else {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int64_t cbeg = (int64_t)chunk_id * g.chunk;
+    int64_t cend = cbeg + g.chunk;
+    if (cend > N) cend = N;
+    const int nfull = cend > cbeg ? (int)((cend - cbeg) >> 2) : 0;                          // whole k-steps of the chunk
+    const int nt = nfull > wave ? (nfull - wave + SYRK_WAVES - 1) / SYRK_WAVES : 0;          // this wave's: wave, wave + 8, ...
+    d4 acc[4][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { ra[q] = 0.0; rb[q] = 0.0; }
-        }
-    };
-    auto lstore = [&](int buf) {
-        double* A = my + buf * (2 * KB * PSS) + p * PSS + rq * 4;
-        double* B = A + KB * PSS;
-        *reinterpret_cast<double2*>(A) = make_double2(ra[0], ra[1]);
-        *reinterpret_cast<double2*>(A + 2) = make_double2(ra[2], ra[3]);
-        *reinterpret_cast<double2*>(B) = make_double2(rb[0], rb[1]);
-        *reinterpret_cast<double2*>(B + 2) = make_double2(rb[2], rb[3]);
-    };
-    // The four groups are independent pipelines: a workgroup barrier per stage would make all sixteen waves wait for the slowest
-    // group's loads (measured: 44.7 instead of 41.9 us for group 0's launch, 57 instead of 45 for the masked one).  Each group meets
-    // on its own LDS counter instead -- lane 0 of a wave adds one behind the wave's LDS stores (a wave's LDS instructions execute in
-    // order, so the add follows them), everyone polls until the four adds of this round are in.  The counters sit in the unused
-    // padding columns of the very last panel row (there is no other LDS left).
-#ifndef SGP_SYRK16_WG_BARRIER
-    typedef __attribute__((address_space(3))) unsigned lds_uint;
-    lds_uint* cnt = (lds_uint*)(lds + 4 * 2 * 2 * KB * PSS - 2) + grp;
-    if (threadIdx.x < 4) ((lds_uint*)(lds + 4 * 2 * 2 * KB * PSS - 2))[threadIdx.x] = 0u;
-    __syncthreads();
-    unsigned epoch = 0;
-    auto group_sync = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        epoch += 4;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-    };
-#else
-    auto group_sync = [&]() { __syncthreads(); };
-#endif
-    if (stages > 0) {
-        gload(0);
-        lstore(0);
-    }
-    group_sync();
-    const int li = lane & 15, lk = lane >> 4;
-    for (int s = 0; s < stages; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < stages) gload(s + 1);
-        const double* ap = my + buf * (2 * KB * PSS) + lk * PSS + wr * 32 + li;
-        const double* bp = ap + KB * PSS + (wc - wr) * 32;
+    for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-        for (int k = 0; k < KB; k += 4) {
-            const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
-            acc.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.t[0][0], 0, 0, 0);
-            acc.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.t[0][1], 0, 0, 0);
-            acc.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.t[1][0], 0, 0, 0);
-            acc.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.t[1][1], 0, 0, 0);
-            ap += 4 * PSS;
-            bp += 4 * PSS;
-        }
-        if (s + 1 < stages) lstore(buf ^ 1);
-        group_sync();
-    }
-    // the four partial tiles meet in LDS ([i][j], 64 doubles per row, each group in its own region), summed in the order of the
-    // sub-chunks; thread t of the workgroup owns entries 4 t .. 4 t + 3 of the slab (two 16-byte stores)
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) my[acc_row(lane, wr, ti, r) * TB + acc_col(lane, wc, tj)] = acc.t[ti][tj][r];
-    __syncthreads();
+        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
     {
-        const int e = 4 * (int)threadIdx.x;
-        double v[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double* src = lds + q * (2 * 2 * KB * PSS) + e;
-            const double2 x0 = *reinterpret_cast<const double2*>(src), x1 = *reinterpret_cast<const double2*>(src + 2);
-            v[0] += x0.x; v[1] += x0.y; v[2] += x1.x; v[3] += x1.y;
+        const int64_t n0 = cbeg + 4 * wave + lk;        // the lane's point of the wave's first k-step
+        const double* pa = Kuf + (size_t)n0 * Mp + I * TB + li;
+        const double* pb = Kuf + (size_t)n0 * Mp + J * TB + li;
+        const double* pw = omega ? omega + n0 : nullptr;
+        const size_t step = (size_t)4 * SYRK_WAVES * Mp;
+        if (I == J) {
+            if (omega) syrk_direct_stream<true, true>(acc, pa, pb, pw, step, nt);
+            else syrk_direct_stream<true, false>(acc, pa, pb, pw, step, nt);
+        } else {
+            if (omega) syrk_direct_stream<false, true>(acc, pa, pb, pw, step, nt);
+            else syrk_direct_stream<false, false>(acc, pa, pb, pw, step, nt);
         }
-        double* out = slabs + ((size_t)chunk_id * g.ntiles + tile_id) * (TB * TB) + e;
-        *reinterpret_cast<double2*>(out) = make_double2(v[0], v[1]);
-        *reinterpret_cast<double2*>(out + 2) = make_double2(v[2], v[3]);
     }
+    if (((cend - cbeg) & 3) != 0 && cend > cbeg && wave == (nfull % SYRK_WAVES)) {          // the ragged last k-step
+        const int64_t n = cbeg + 4 * (int64_t)nfull + lk;
+        const bool in = n < cend;
+        const double* qa = Kuf + (size_t)(in ? n : cend - 1) * Mp + I * TB + li;
+        const double* qb = Kuf + (size_t)(in ? n : cend - 1) * Mp + J * TB + li;
+        const double wn = in ? (omega ? omega[n] : 1.0) : 0.0;
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { av[u] = in ? qa[16 * u] : 0.0; bv[u] = qb[16 * u] * wn; }
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
+    }
+    // the eight partial tiles meet in LDS ([i][j], 64 doubles per row), four at a time, summed in wave order; thread t owns the
+    // entries 2 (t + 512 e), 2 (t + 512 e) + 1 of the slab (16-byte stores, 1 KB runs per wave)
+    constexpr int NE = (TB * TB) / SYRK_DIRECT_THREADS / 2;
+    double2 out[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) out[e] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int round = 0; round < SYRK_WAVES / 4; ++round) {
+        if (round) __syncthreads();
+        if ((wave >> 2) == round) {
+            double* my = lds + (wave & 3) * (TB * TB);
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) my[(16 * ti + lk + 4 * r) * TB + 16 * tj + li] = acc[ti][tj][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = 2 * (tid + SYRK_DIRECT_THREADS * e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 x = *reinterpret_cast<const double2*>(lds + q * (TB * TB) + idx);
+                out[e].x += x.x; out[e].y += x.y;
+            }
+        }
+    }
+    double* dst = slabs + ((size_t)chunk_id * g.ntiles + tile_id) * (TB * TB);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) *reinterpret_cast<double2*>(dst + 2 * (tid + SYRK_DIRECT_THREADS * e)) = out[e];
     stamp_exit(stamps);
 }
 
