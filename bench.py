@@ -34,6 +34,7 @@ WORKLOADS = {
     # scaling workload: at T the replicated M^3 tail caps strong scaling at ~1.35x on 8 GPUs; the >= 6x
     # regime of the north star needs the data-sized kernels to dominate
     "N1M": (1000000, 512, 8),
+    "N100K": (100000, 512, 8),         # (diagnostic: between the latency-bound and the data-bound regime)
 }
 # trained kin40k hyper-parameters (softplus(theta_opt), experiments/regression_kin40k.ipynb:255-263)
 SIGMA2 = 0.17636613718898136

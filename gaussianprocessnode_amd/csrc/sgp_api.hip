@@ -782,18 +782,25 @@ static double model_overlap_end(const sgp_handle* h, int64_t n, const int* cuts,
         const SyrkGeom g = syrk_geometry(row_lo, nrows, cus, n, h->syrk_wide);
         return g.wide ? 13.0 + 0.029 * g.chunk : 5.0 + 0.18 * g.chunk;
     };
-    // assembly + gaps behind a group's SYRK (unmasked / masked); a chain step with its launch gap (18 before the step kernel's
-    // rework of round 3); and how long before its step a group should be there: a step that finds its group's word unset waits
-    // and then reads the statistics past the L2, element by element -- far slower than the wait alone
-    const double asm0 = 8.0, asmm = 11.0, step = 17.0, margin = 4.0, forming = 2.5;   // (forming: the poll and the extra tile loads of a step that forms a masked group)
-    if (classic_end) *classic_end = syrk_us(0, T, h->num_cus) + asm0 + step * T;
+    // The schedule's constants.  k_syrk_stream launches (small problems never overlap; kept as fitted in round 3): ~8 / ~11 us of
+    // assembly, word kernel and gaps behind an unmasked / masked group's SYRK, 4 us of margin in front of a forming step (a step
+    // that finds its group's word unset waits and then reads the statistics past the L2, element by element -- far slower than
+    // the wait alone), 2.5 us for forming.  k_syrk_direct launches: refitted to six measured plans at T (device sweep, us: {3} 216.3,
+    // {2} 216.3, {4} 224.9, {2,5} 213.2, {3,6} 221.5, {2,4} 215.5 -- profiles/r04_ab_log.txt [17]; residuals of this model
+    // +-1.3 us): in the kernel's own duration (7.5 + 0.029 us per point; syrk_us above is what HIP events see) group 0's assembly
+    // and its two boundaries are 11.5 us, the masked stream's first SYRK starts 8 us behind group 0's, a masked group is usable
+    // 5 us behind its SYRK, and a step that forms a group costs 5 us more than one that does not.
+    const bool dk = h->syrk_wide;
+    const double asm0 = dk ? 11.5 : 8.0, asmm = dk ? 5.0 : 11.0, step = 17.0, margin = dk ? 0.0 : 4.0, forming = dk ? 5.0 : 2.5;
+    const double mstart = dk ? 8.0 : 2.0, launch = dk ? 5.5 : 0.0;   // (launch: what syrk_us counts beyond the kernel's own duration)
+    if (classic_end) *classic_end = syrk_us(0, T, h->num_cus) - launch + asm0 + step * T;
     double ready[LAM_MAX_COLS];
-    double t = syrk_us(T - cuts[0], cuts[0], h->num_cus) + asm0;          // group 0 assembled
+    double t = syrk_us(T - cuts[0], cuts[0], h->num_cus) - launch + asm0;          // group 0 assembled
     for (int c = 0; c < cuts[0]; ++c) ready[c] = t;
-    t -= asm0 - 2.0;                                          // the masked stream starts when group 0's assembly does
+    t -= asm0 - mstart;                                       // the masked stream starts when group 0's assembly does
     for (int g = 0; g < ncuts; ++g) {
         const int c0 = cuts[g], c1 = (g + 1 < ncuts) ? cuts[g + 1] : T;
-        t += syrk_us(T - c1, c1 - c0, h->stat_cus_masked) + asmm;
+        t += syrk_us(T - c1, c1 - c0, h->stat_cus_masked) - launch + asmm;
         for (int c = c0; c < c1; ++c) ready[c] = t;
     }
     double end = ready[0];
@@ -817,13 +824,27 @@ static void plan_overlap(sgp_handle* h, int64_t n) {
     if (cuts.empty()) {
         double classic = 0.0, best = 1e300;
         int cand[2];
-        // ONE cut: with the step kernel of round 3 the chain no longer waits for a third group to be worth its launches -- measured
-        // at T {3} 4 290-4 320 against {2,4} 4 200-4 260 and {3,4} 4 210 sweeps/s, at N = 40 000 {5} 2 330 against {4,6} 2 270
-        // (more groups: SGP_OVERLAP_COLS)
+        // One or two cuts.  (Round 3 settled on ONE: with its 16 us steps the chain reached a third group's columns before that group
+        // was there.  With k_syrk_direct a masked group's launch is a quarter shorter and {2,5} beats {3} at T, 213.2 against 216.3 us.)
+        // Among plans the model cannot tell apart (< 0.3 us) the later second cut wins: the measured order at T.
         for (int a = 1; a < T; ++a) {
             cand[0] = a; cand[1] = a;
             const double e = model_overlap_end(h, n, cand, 1, &classic);
-            if (e < best - 1e-9) { best = e; cuts.assign(cand, cand + 1); }
+            if (e < best - 0.3) { best = e; cuts.assign(cand, cand + 1); }
+            if (!h->syrk_wide || h->allreduce) continue;     // (data-sharded: every further group is another collective)
+            for (int b = T - 1; b > a; --b) {
+                cand[1] = b;
+                // Three groups only while the masked launches are short (<= 45 us by the model: T has 38 and 22).  At N = 40 000 the
+                // model liked {3,5} (masked launches of 63 and 45 us) and the sweep lost 5 % against {4}: a chain step that finds its
+                // group late polls and then reads the statistics past the L2, the masked SYRK beside it slows down (0.038 instead of
+                // 0.029 us per point in the timeline), and the next group is later still -- a model that knows no feedback must stay
+                // out of that regime (profiles/r04_ab_log.txt [17]).
+                const double m1 = 13.0 + 0.029 * syrk_geometry(T - b, b - a, h->stat_cus_masked, n, true).chunk;
+                const double m2 = 13.0 + 0.029 * syrk_geometry(0, T - b, h->stat_cus_masked, n, true).chunk;
+                if (m1 > 45.0 || m2 > 45.0) continue;
+                const double e2 = model_overlap_end(h, n, cand, 2, &classic);
+                if (e2 < best - 0.3) { best = e2; cuts.assign(cand, cand + 2); }
+            }
         }
         if (h->env_overlap != 1 && best > classic - 5.0) return;
     }
@@ -1524,6 +1545,7 @@ extern "C" int sgp_set_allreduce(sgp_handle* h, sgp_allreduce_fn fn, void* ctx) 
     if (int prc = ensure_pack(h)) return prc;
     h->allreduce = fn;
     h->allreduce_ctx = ctx;
+    if (h->n > 0) plan_overlap(h, h->n);         // (a data-sharded sweep pays one collective per statistics group: one cut)
     return 0;
 }
 
@@ -1543,6 +1565,7 @@ extern "C" int sgp_use_rccl(sgp_handle* h, void* nccl_comm) {
     h->rccl_comm = nccl_comm;
     h->allreduce = rccl_hook;
     h->allreduce_ctx = h;
+    if (h->n > 0) plan_overlap(h, h->n);
     return 0;
 }
 
@@ -1577,12 +1600,17 @@ __global__ void __launch_bounds__(256) k_clock_probe_mfma(long long* out, int it
     d4v c0v = {0.0, 0.0, 0.0, 0.0}, c1v = c0v, c2v = c0v, c3v = c0v;
     const double a = 1.0 + threadIdx.x * 1e-9, b = 1e-9;
     const long long c0 = (long long)__builtin_amdgcn_s_memtime(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+    // (inline assembly with the accumulators pinned in VGPRs: written with the builtin, the compiler moved all four accumulators
+    // between VGPRs and AGPRs around every round of this loop -- 64 copies per 4 MFMAs -- and the "matrix rate of the chip" this
+    // probe reported through round 3 and half of round 4, 45 - 48 TFLOP/s, was the rate of THAT loop; the instruction itself
+    // sustains 72 - 73, tools/dpp_f64_probe.hip)
     for (int i = 0; i < iters; ++i) {
-        c0v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0v, 0, 0, 0);
-        c1v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1v, 0, 0, 0);
-        c2v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2v, 0, 0, 0);
-        c3v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3v, 0, 0, 0);
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c0v) : "v"(a), "v"(b));
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c1v) : "v"(a), "v"(b));
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c2v) : "v"(a), "v"(b));
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c3v) : "v"(a), "v"(b));
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // (the last results are in flight: the compiler does not know these are MFMAs)
     const long long c1 = (long long)__builtin_amdgcn_s_memtime(), r1 = (long long)__builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = (long long)(c0v[0] + c1v[1] + c2v[2] + c3v[3]); }
 }
@@ -1814,6 +1842,12 @@ extern "C" int sgp_get_phase_totals(sgp_handle* h, int64_t* totals, int64_t* cou
 // HIP-event timing of one data-sized kernel of the sweep, launched eagerly `iters` times on `stream`
 // (bench.py's roofline leg; both kernels are idempotent on the resident data)
 // ------------------------------------------------------------------------------------------------
+// the per-point quadratic forms |L_K^-1 k_n|^2, |Uv k_n|^2 and k_n . mu in one pass over the resident K_uf
+static void launch_quadform(sgp_handle* h, hipStream_t s) {
+    hipLaunchKernelGGL(k_quadform_fused, dim3(h->nblk, h->T), dim3(256), 0, s, h->dWk, h->dUvT, h->dKuf, h->dMu, h->dPa, h->dPb, h->dKmu,
+                       h->Mp, h->T, h->n);
+}
+
 extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void* stream, double* avg_us) {
     if (!h || !avg_us || iters < 1) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: bad argument");
     if (!h->swept_local || h->n == 0) return fail(h, SGP_ERR_ARG, "sgp_time_kernel: run a sweep on non-empty data first");
@@ -1836,8 +1870,7 @@ extern "C" int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void
     hipEvent_t e0 = ev.a, e1 = ev.b;
     auto launch = [&]() {
         if (qmode >= 0)
-            hipLaunchKernelGGL(k_quadform_fused, dim3(h->nblk, h->T), dim3(256), 0, s, h->dWk, h->dUvT, h->dKuf, h->dMu, h->dPa, h->dPb,
-                               h->dKmu, h->Mp, h->T, h->n);
+            launch_quadform(h, s);
         else if (G)
             launch_syrk(G->geom, s, h->dKuf, h->has_omega ? h->dOmega : nullptr, h->dSlabs + G->slab_off, h->Mp, h->n, (int64_t*)nullptr,
                         (long long*)nullptr, 0LL);
@@ -1903,8 +1936,7 @@ extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) 
     dI2 = dI1 + n;
     // |L^-1 k_n|^2 with the explicit inverse factor W_k, |Uv k_n|^2 = |L_R^T k_n|^2 and k_n . mu: ONE pass over the resident K_uf
     // (k_quadform_fused), then the fixed-order sums
-    hipLaunchKernelGGL(k_quadform_fused, dim3(h->nblk, h->T), dim3(256), 0, s, h->dWk, h->dUvT, h->dKuf, h->dMu, h->dPa, h->dPb, h->dKmu,
-                       h->Mp, h->T, n);
+    launch_quadform(h, s);
     hipLaunchKernelGGL(k_w_point_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dPa, h->dPb, h->dKmu, h->dY,
                        h->has_yv ? h->dYv : nullptr, dI1, dI2, h->dParams, h->T, n);
     // both vectors come back in one copy through the pinned staging block when they fit (two blocking copies into pageable memory

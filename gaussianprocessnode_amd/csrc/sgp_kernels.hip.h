@@ -765,7 +765,9 @@ __device__ __forceinline__ void syrk_direct_stream(d4 (&acc)[4][4], const double
     for (; t0 + P <= nt; t0 += P) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
+            __builtin_amdgcn_sched_barrier(0);        // (products and loads stay in the order written: see quadform_stream)
             mma(p);
+            __builtin_amdgcn_sched_barrier(0);
             const int tn = t0 + p + P;
             load(p, tn < nt ? tn : nt - 1);
         }

@@ -645,6 +645,44 @@ def test_theta_objective_and_gradient_at_fixed_posterior(G, N, M, D, iso, jitter
         np.testing.assert_allclose(grad, g_ref, rtol=5e-5, atol=1e-6 * np.abs(g_ref).max())
 
 
+@pytest.mark.parametrize("N,weighted", [(6007, False), (6007, True), (6006, True), (12289, False)])
+def test_direct_syrk_ragged_chunks_and_point_weights(G, N, weighted):
+    """k_syrk_direct (the SYRK of every problem that fills the chip: N x lower tiles >= 200 000) on point counts that are no multiple of
+    the 4-point k-step -- the ragged last step of a chunk is formed unpipelined by one wave -- and with per-point weights omega
+    (cubature points, GPnode/UniSGPnode.jl:153-156 with Appendix A's omega): Psi2, B and the per-point :w quantities against the
+    oracle; the overlapped and the plain order agree."""
+    M, D = 512, 8
+    rng = np.random.default_rng(N)
+    X, Xu, y, _ = synth(N, M, D, seed=N % 97)
+    om = rng.uniform(0.2, 1.5, N) if weighted else None
+    s2, ell, w = 0.9, np.linspace(1.5, 3.0, D), 50.0
+    out = {}
+    for order in ("overlapped", "plain"):
+        os.environ["SGP_OVERLAP"] = "1" if order == "overlapped" else "0"
+        try:
+            with G.SGPDevice(N, M, D, keep_kuf=True) as dev:
+                dev.set_inducing(Xu); dev.set_data(X, y, weights=om); dev.set_kernel(s2, ell, 1e-8)
+                dev.set_prior_isotropic(50.0); dev.set_noise([[w]])
+                plan = dev.overlap_plan()
+                assert bool(plan) == (order == "overlapped")
+                dev.sweep()
+                out[order] = (dev.stats(), dev.posterior(), dev.w_stats())
+        finally:
+            os.environ.pop("SGP_OVERLAP", None)
+    (Psi2, B, _), (mu, Sig, Uv), (I1, I2) = out["overlapped"]
+    st = O.suff_stats(Xu, X, y, None, s2, ell, omega=om)
+    assert relF(Psi2, st.Psi2) < 1e-13
+    assert relF(B, st.b) < 1e-13
+    (Psi2p, Bp, _), (mup, _, _), (I1p, I2p) = out["plain"]
+    assert relF(Psi2p, st.Psi2) < 1e-13 and relF(Bp, st.b) < 1e-13
+    assert relF(mu, mup) < 1e-7             # (the two orders bracket the sums differently: cond(Lambda) x eps)
+    KuuL = np.linalg.cholesky(O.kernelmatrix(s2, ell, Xu) + 1e-8 * np.eye(M))
+    rI1, rI2 = O.w_stats_perpoint(Xu, X, y, None, s2, ell, KuuL, mu, Uv)
+    cond_K = np.linalg.cond(KuuL) ** 2
+    np.testing.assert_allclose(I1, rI1, rtol=0, atol=50 * np.finfo(float).eps * cond_K * s2 + 1e-12)
+    np.testing.assert_allclose(I2, rI2, rtol=1e-6, atol=1e-8 * float(np.max(rI2)))
+
+
 def test_full_size_configs_and_size_independent_properties(G):
     """BASELINE's full sizes: C3 (N = 40 000, M = 512, D = 8) against the oracle, plus properties that hold at any size:
     statistics are additive over a split and invariant under a permutation of the points; at N = 10^6 (4 GB of K_uf) the
@@ -871,11 +909,7 @@ def test_overlapped_sweep_with_one_reduce_per_statistics_group(G):
         d.set_prior_isotropic(50.0); d.set_noise([[w]])
         return d
     other, mine = make(slice(cut, N)), make(slice(0, cut))
-    plan = mine.overlap_plan()
-    assert len(plan) >= 2, plan                      # the shard qualifies for the overlapped order, hook or not
-    T = (M + 63) // 64
-    tail = T * 64 + 8 + 1
-    sizes = [g["tiles"] * 4096 + (tail if i == 0 else 0) for i, g in enumerate(plan)]
+    assert len(mine.overlap_plan()) >= 2             # the shard qualifies for the overlapped order, hook or not
     captured, streams = [], []
 
     def capture(ptr, n, stream):
@@ -883,6 +917,11 @@ def test_overlapped_sweep_with_one_reduce_per_statistics_group(G):
             captured.append(device_tensor(ptr, n).clone())
         streams.append(stream)
     other.set_allreduce(capture)
+    plan = other.overlap_plan()                      # (re-planned when the hook is installed: every group is a collective -> one cut)
+    assert len(plan) == 2, plan
+    T = (M + 63) // 64
+    tail = T * 64 + 8 + 1
+    sizes = [g["tiles"] * 4096 + (tail if i == 0 else 0) for i, g in enumerate(plan)]
     other.sweep()
     torch.cuda.synchronize()
     assert [c.numel() for c in captured] == sizes and len(set(streams)) == len(plan)      # one call per group, each on its own stream

@@ -27,10 +27,13 @@ __global__ void __launch_bounds__(256) rate_mfma(double* out, int iters) {
     double4_t acc[NACC];
     for (int i = 0; i < NACC; ++i) acc[i] = (double4_t){0, 0, 0, 0};
     double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    // (inline assembly, accumulators pinned in VGPRs: with the builtin the compiler copied every accumulator VGPR -> AGPR -> VGPR
+    // around each round of this loop, 16 copies per MFMA, and the probe read 46 - 48 TFLOP/s where the instruction sustains 72 - 73)
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < NACC; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     double s = 0;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;

@@ -30,5 +30,5 @@ for name, N, M, D in (("T", 10000, 512, 8), ("C4", 4000, 128, 2)):
             dev.sweep(); dev.w_stats()
         t_both = (time.perf_counter() - t0) / reps
         q = dev.time_kernel(_lib.SGP_TIME_QUADFORM, 20)
-        print(f"{name}: sweep + get_scalars (one at a time) {1e6 * t_sweep:.1f} us | w_stats alone {1e6 * t_w:.1f} us (k_quadform_fused {q:.1f} us) | "
+        print(f"{name}: sweep + get_scalars (one at a time) {1e6 * t_sweep:.1f} us | w_stats alone {1e6 * t_w:.1f} us (the quadratic-form kernel {q:.1f} us) | "
               f"sweep + w_stats {1e6 * t_both:.1f} us = {1 / t_both:.0f} it/s")
