@@ -22,4 +22,6 @@ for N in (10000, 1000000):
         if N == 10000:
             g = [min(dev.time_kernel(_lib.SGP_TIME_GROUP0 + k, 10) for _ in range(3)) for k in range(2)]
             line += f"; groups {g[0]:.1f} / {g[1]:.1f} us"
+        gram = min(dev.time_kernel(_lib.SGP_T_GRAM, 10) for _ in range(3))
+        line += f"; Gram {gram:.1f} us = {8.0 * N * 512 / gram * 1e-6:.2f} TB/s of stores"
         print(line, flush=True)
