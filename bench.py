@@ -280,10 +280,10 @@ def main():
     # The SYRK of the timed sweeps.  Plain order: ONE launch over all lower tiles.  Overlapped sweep (sgp_overlap_plan): one launch
     # per statistics group, the first on all CUs, the others on the CU-masked stream -- each is timed alone with HIP events on
     # the stream (and the CUs) it uses inside the sweep; `achieved` = the sweep's SYRK flops / the sum of its launches =
-    # (flops per launch) / (average launch duration), the quantity rocprofv3 --kernel-trace --stats shows for k_syrk_stream.
+    # (flops per launch) / (average launch duration), the quantity rocprofv3 --kernel-trace --stats shows for k_syrk_direct.
     plan = dev.overlap_plan()            # (hooked sweeps too: one all-reduce per statistics group, include/sgp_hip.h)
     ntiles_all = (M + 63) // 64 * ((M + 63) // 64 + 1) // 2
-    # (SGP_BENCH_SKIP_ALONE: the rocprofv3 --pmc passes of tools/measure_round.sh -- every k_syrk_stream launch in their output is
+    # (SGP_BENCH_SKIP_ALONE: the rocprofv3 --pmc passes of tools/measure_round.sh -- every k_syrk_direct launch in their output is
     # then one of the timed sweeps' own; the stand-alone timings are skipped and the roofline block is not meaningful)
     skip_alone = os.environ.get("SGP_BENCH_SKIP_ALONE") is not None
     if skip_alone:
@@ -348,7 +348,7 @@ def main():
                                            else "none (single rank)"}},
         "sclk_mhz": sclk.value,
         "sclk_mhz_under_mfma_f64": sclk_mfma,
-        "roofline": {"kernel": "k_syrk_stream (Psi2 = K_uf K_uf^T, v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+        "roofline": {"kernel": "k_syrk_direct (Psi2 = K_uf K_uf^T, v_mfma_f64_16x16x4_f64, operands straight from global memory; k_syrk_stream where the SYRK does not fill the chip)", "bound": "mfma",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "clock": "HIP events around 10 eager launches of each of the sweep's SYRK launches alone, on the stream and the "
@@ -367,7 +367,9 @@ def main():
                      "peak_note": "78.6 = MI355X FP64 matrix spec (256 CUs x 4 SIMDs x 2048 flop / 64 cycles at 2.4 GHz); "
                                   "peak_at_measured_clock = the same arithmetic at the shader clock the chip holds under "
                                   "back-to-back v_mfma_f64 (sclk_mhz_under_mfma_f64, sgp_measure_clocks); mfma_probe_tflops = "
-                                  "what that back-to-back loop itself attains on this box"},
+                                  "what that back-to-back loop itself attains on this box (accumulators pinned in registers: 0.98 - "
+                                  "0.99 of spec; the 45 - 48 TFLOP/s quoted through round 3 measured a loop the compiler had filled "
+                                  "with accumulator copies, profiles/r04_ab_log.txt [14])"},
         # the sweep's critical path is the Lambda factorisation chain: latency-bound, priced against its pivot floor
         "roofline_chain": {"kernel": "k_potrf_step x (M/64 + 1) + k_trmv_mu_scan (Lambda = L L^T, inverse factor, Sigma rows, t, mu)",
                            "bound": "latency (dependent pivot chain)", "achieved_us": f1_us, "floor_us": chain_floor_us,
@@ -380,7 +382,8 @@ def main():
                           "peak": 8000.0, "unit": "GB/s",
                           "frac": 8.0 * n_loc * dev.stats_layout()[2] / (tick_us(_lib.SGP_T_GRAM) * 1e-6) / 1e9 / 8000.0,
                           "algorithmic_bytes_per_launch": 8.0 * n_loc * dev.stats_layout()[2],
-                          "note": "41 MB at T: the write stays in the 256 MiB Infinity Cache; PMC WRITE_SIZE 41.6 MB"},
+                          "note": "41 MB at T; PMC WRITE_SIZE 41.6 MB.  Not store-bound: the same store pattern alone sustains 6.7 TB/s "
+                                  "(tools/store_bw_probe.hip); the kernel's phases add up, profiles/r04_ab_log.txt [19]"},
         "sweep_order": ({"kind": "overlapped", "groups": plan,
                          "note": "statistics in tile-row groups (first on all CUs, the others on a CU-masked queue) while the Lambda "
                                  "chain factors the tile columns it has; `local` and `finish1_lambda_chain` overlap in time"}

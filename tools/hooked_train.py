@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A data-sharded device-paced training run on one GPU (the all-reduce hook doubles what it is handed: a second rank with the same
 slice), 40 minibatches of 500 kin40k-shaped points, M = 512 -- run under rocprofv3 --kernel-trace --stats to count launches per
-minibatch: one k_gram_uf and one k_syrk_stream each (nothing is re-formed for the theta gradient)."""
+minibatch: one k_gram_uf and one SYRK launch each (nothing is re-formed for the theta gradient)."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

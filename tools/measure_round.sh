@@ -47,7 +47,16 @@ HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python -m torch.distributed.run -
 RH_N=20000 RH_M=512 RH_D=8 RH_JIT=1e-6 RH_GTOL=1e-5 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 tools/rehearse_two_ranks.py 2>&1 | grep -E "rank [01]\]" > $O/rehearse_two_ranks_overlapped.txt; tail -3 $O/rehearse_two_ranks_overlapped.txt
 timeout -k 10 200 python tools/wstats_time.py 2>&1 | grep -v amdgpu > $O/wstats_time.txt; cat $O/wstats_time.txt
 SGP_SYRK_WIDE=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_T_syrk_256_threads.json 2> /dev/null
-[ -f gaussianprocessnode_amd/csrc/libsgp_hip_base.so ] && cp gaussianprocessnode_amd/csrc/libsgp_hip.so gaussianprocessnode_amd/csrc/libsgp_hip_fin.so && bash tools/ab_multi.sh 3 "round3_library|base|" "round4_library|fin|" "round4_256_thread_syrk|fin|SGP_SYRK_WIDE=0" > $O/ab_r3_vs_r4.txt 2>&1; cat $O/ab_r3_vs_r4.txt
+# same-box A/B of library builds (tools/ab_multi.sh): round 3's (commit 0f7549a), the first half of round 4 (8dfa5c6: LDS-staged 16-wave SYRK,
+# one cut) and this one.  The old libraries are built by hand from `git show <commit>:...`; a library that lacks an
+# export bench.py now calls prints no line.
+D=gaussianprocessnode_amd/csrc
+if [ -f $D/libsgp_hip_r4a.so ]; then cp $D/libsgp_hip.so $D/libsgp_hip_fin.so; bash tools/ab_multi.sh 3 "round3_library|base|" "round4_first_half|r4a|" "round4_final|fin|" 2>&1 | grep -v Traceback | grep -v "^  File\|IndexError\|^    " > $O/ab_r3_vs_r4.txt; cat $O/ab_r3_vs_r4.txt; fi
+for w in C3 N1M; do for v in r4a fin; do cp $D/libsgp_hip_$v.so $D/libsgp_hip.so; SGP_BENCH_SKIP_ALONE=1 timeout -k 10 300 python bench.py --no-cpu-baseline --workload $w --steps 100 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w', '$v', round(d['value'],2), 'sweeps/s')"; done; done >> $O/ab_r3_vs_r4.txt 2>&1; tail -4 $O/ab_r3_vs_r4.txt
+cp $D/libsgp_hip_fin.so $D/libsgp_hip.so
+timeout -k 10 60 ./tools/mfma_f64_probe > $O/mfma_f64_probe.txt 2>&1; timeout -k 10 60 ./tools/dpp_f64_probe > $O/dpp_f64_probe.txt 2>&1; timeout -k 10 120 ./tools/syrk_direct_probe > $O/syrk_direct_probe.txt 2>&1; timeout -k 10 60 ./tools/store_bw_probe > $O/store_bw_probe.txt 2>&1
 echo "measure_round done"
 
 fi

@@ -13,7 +13,7 @@ by_grid = {}
 def avg_kib(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and "k_syrk_stream" in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and "k_syrk_" in r["Kernel_Name"]:
             acc[0].append(float(r["Counter_Value"]))
             acc[("grid", int(r.get("Grid_Size", 0) or 0) // max(int(r.get("Workgroup_Size", 256) or 256), 1))].append(float(r["Counter_Value"]))
     v = acc[0]
@@ -28,7 +28,7 @@ try:
     commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
 except Exception:
     commit = "unknown"
-rec = {"workload": workload, "n_gpus": 1, "kernel": "k_syrk_stream16 (k_syrk_stream where the SYRK does not fill the chip)",
+rec = {"workload": workload, "n_gpus": 1, "kernel": "k_syrk_direct (k_syrk_stream where the SYRK does not fill the chip)",
        "fetch_size_bytes": f * 1024, "write_size_bytes": w * 1024, "fetch_correction": 2.0,
        "traffic_bytes_per_launch": 2.0 * f * 1024 + w * 1024, "launches_averaged": [nf, nw], "by_grid_workgroups": by_grid, "commit": commit,
        "source": "SGP_BENCH_SKIP_ALONE=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline"}

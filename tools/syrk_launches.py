@@ -5,7 +5,7 @@ launches of each alone that bench.py times with HIP events (its `roofline.launch
 Usage: syrk_launches.py <kernel_trace.csv>"""
 import collections, csv, sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_syrk_stream" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_syrk_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 by = collections.OrderedDict()
 for r in rows:
@@ -13,7 +13,7 @@ for r in rows:
     by.setdefault(grid, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 mean = lambda v: sum(v) / max(len(v), 1)
 alld = [d for v in by.values() for d in v]
-print(f"k_syrk_stream: {len(alld)} launches, average {mean(alld):.2f} us (what --stats reports)")
+print(f"k_syrk_direct / k_syrk_stream: {len(alld)} launches, average {mean(alld):.2f} us (what --stats reports)")
 for grid, d in by.items():
     print(f"  grid {grid:5d} workgroups: {len(d):4d} launches, average {mean(d):.2f} us, min {min(d):.2f}, max {max(d):.2f}; last 10 (alone, "
           f"HIP-event timed): {mean(d[-10:]):.2f} us")
