@@ -283,7 +283,7 @@ int sgp_get_phase_totals(sgp_handle* h, int64_t* totals /* SGP_T_COUNT */, int64
 int sgp_get_step_trace(int64_t* out /* 512 */);
 /* diagnostics of the variant library built with -DSGP_SWEEP_TRACE (all zeros otherwise): out[65 s] = begin, out[65 s + 1 .. 65 s + 64]
  * = exit ticks (100 MHz; take the maximum) of trace slot s of the last sweep, 256 slots: 0 k_prep_xu, 2 k_gram_uf, 16 + j step j of the
- * Lambda chain, 40 + j of the K_uu chain, 64 + first tile of a k_syrk_stream launch, 128 + first tile row of a k_assemble launch,
+ * Lambda chain, 40 + j of the K_uu chain, 64 + first tile of a SYRK launch (k_syrk_direct / k_syrk_stream), 128 + first tile row of a k_assemble launch,
  * 200 + j the moment step j had its statistics, ... (csrc/sgp_kernels.hip.h, g_sweep_trace; tools/sweep_trace.py prints them). */
 int sgp_get_sweep_trace(int64_t* out /* 256 * 65 */);
 int sgp_get_chain_trace(sgp_handle* h, int32_t which, int64_t* out /* 384 */);
