@@ -35,6 +35,7 @@ WORKLOADS = {
     # regime of the north star needs the data-sized kernels to dominate
     "N1M": (1000000, 512, 8),
     "N100K": (100000, 512, 8),         # (diagnostic: between the latency-bound and the data-bound regime)
+    "N5K": (5000, 512, 8),             # (diagnostic: one rank's shard of T on two GPUs)
 }
 # trained kin40k hyper-parameters (softplus(theta_opt), experiments/regression_kin40k.ipynb:255-263)
 SIGMA2 = 0.17636613718898136

@@ -200,7 +200,7 @@ struct sgp_handle {
     int env_g1_mode = 2;           // SGP_G1_AFTER (see enqueue_stats_overlapped)
     int env_syrk_wt = 0;           // SGP_SYRK_WT (see plan_overlap)
     bool env_syrk_wide = true;     // SGP_SYRK_WIDE=0: the 256-thread SYRK everywhere (A/B switch)
-    int64_t gate_min = 200000;     // points x lower tiles from which the SYRK is taken to fill the chip (SGP_GATE_MIN: A/B switch)
+    int64_t gate_min = 10000;      // points x lower tiles from which the SYRK is taken to fill the chip (SGP_GATE_MIN: A/B switch; see set_point_count)
     bool syrk_wide = false;        // the resident problem's SYRK launches are k_syrk_direct (set_point_count)
     std::vector<int> env_overlap_cols;   // SGP_OVERLAP_COLS: group boundaries (tile columns of P Lambda P), e.g. "3" or "2,4"
     int nblk = 0, ntiles = 0, num_cus = 256;
@@ -889,6 +889,12 @@ static int set_point_count(sgp_handle* h, int64_t n) {
     // (enqueue_kuu), so nothing is reserved for it and the grid is sized for all CUs (T: 25 -> 28 chunks, 62.7 -> 57.4 us; the
     // chain then runs after the SYRK and still ends ~9 us before its join).  Small problems keep the early chain: there the
     // two chains are the sweep, and a late K_uu chain is waited for (C1: -15 %, C5: -2 % with the gate).
+    // The threshold (points x lower tiles) was 200 000 through the first half of round 4 -- what the LDS-staged SYRK needed to fill
+    // the chip; k_syrk_direct has one workgroup per CU and splits the point axis down to 32 points, so far smaller problems gain
+    // from it, from the gate and, from ~50 000 on, from the overlapped order (sweeps/s at the old / new threshold, one box,
+    // tools/gate_sweep.py, profiles/r04_ab_log.txt [22]): N = 5 000, M = 512: 4 534 -> 4 970; C2 (N = 10 000, M = 256): 7 333 -> 7 640;
+    // 3 000 x 512: 4 819 -> 5 057; 10 000 x 128: 10 523 -> 11 836; C4 (4 000 x 128): 11 205 -> 13 032; C5 (1 500 x 48, one tile:
+    // 1 500) loses 2 % if gated and C1 15 %: the threshold is 10 000.
     h->gate_side = n * (int64_t)h->ntiles >= h->gate_min && h->dJoin && !(h->cfg.flags & SGP_FLAG_GRAPH) && !h->use_chain &&
                    !h->env_no_gate;
     // (the in-CU split needs the whole LDS of a CU: only where the K_uu chain is gated behind this launch, i.e. the SYRK fills the chip)

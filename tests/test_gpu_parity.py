@@ -647,7 +647,7 @@ def test_theta_objective_and_gradient_at_fixed_posterior(G, N, M, D, iso, jitter
 
 @pytest.mark.parametrize("N,weighted", [(6007, False), (6007, True), (6006, True), (12289, False)])
 def test_direct_syrk_ragged_chunks_and_point_weights(G, N, weighted):
-    """k_syrk_direct (the SYRK of every problem that fills the chip: N x lower tiles >= 200 000) on point counts that are no multiple of
+    """k_syrk_direct (the SYRK of every problem that fills the chip: N x lower tiles >= 10 000) on point counts that are no multiple of
     the 4-point k-step -- the ragged last step of a chunk is formed unpipelined by one wave -- and with per-point weights omega
     (cubature points, GPnode/UniSGPnode.jl:153-156 with Appendix A's omega): Psi2, B and the per-point :w quantities against the
     oracle; the overlapped and the plain order agree."""
