@@ -832,6 +832,9 @@ static void plan_overlap(sgp_handle* h, int64_t n) {
             const double e = model_overlap_end(h, n, cand, 1, &classic);
             if (e < best - 0.3) { best = e; cuts.assign(cand, cand + 1); }
             if (!h->syrk_wide || h->allreduce) continue;     // (data-sharded: every further group is another collective)
+            // (three groups were fitted and validated at eight tile columns; with four -- M = 256 -- the planner's {1,2} lost 8 % against the
+            // plain order at N = 20 000 where {1} gains: fewer than six columns keep one cut)
+            if (T < 6) continue;
             for (int b = T - 1; b > a; --b) {
                 cand[1] = b;
                 // Three groups only while the masked launches are short (<= 45 us by the model: T has 38 and 22).  At N = 40 000 the
@@ -846,7 +849,9 @@ static void plan_overlap(sgp_handle* h, int64_t n) {
                 if (e2 < best - 0.3) { best = e2; cuts.assign(cand, cand + 2); }
             }
         }
-        if (h->env_overlap != 1 && best > classic - 5.0) return;
+        // (the plain order stays unless the model sees a gain: 5 us with the LDS-staged SYRK's constants; 1 us with k_syrk_direct's --
+        // at C2 (M = 256, four tile columns) the model sees 1.1 us for the cut {1} and the sweep gains 4.5, 129.2 -> 124.8 us)
+        if (h->env_overlap != 1 && best > classic - (h->syrk_wide ? 1.0 : 5.0)) return;
     }
     if ((int)cuts.size() + 1 > LAM_MAX_GROUPS) return;
     size_t off = 0;
