@@ -305,7 +305,11 @@ int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void* stream, d
  * bitwise reproducible.  sgp_overlap_plan reports what the next sgp_sweep will do: *ngroups = 0 (plain order) or the number
  * of groups with, per group, info[8 g ..] = {first, past-the-last tile column of P Lambda P, lower tiles, point chunks, points
  * per chunk, masked (0/1), CUs available, the Lambda-chain step that forms the group}.  Environment: SGP_OVERLAP=0 turns it
- * off, SGP_OVERLAP=1 forces it wherever it is possible, SGP_OVERLAP_COLS="3" / "2,4" sets the group boundaries. */
+ * off, SGP_OVERLAP=1 forces it wherever it is possible, SGP_OVERLAP_COLS="3" / "2,4" sets the group boundaries.
+ * "Fills the chip" = points x lower tiles >= 10 000 (SGP_GATE_MIN overrides): from there on the SYRK is k_syrk_direct (one
+ * workgroup per CU, no LDS staging; SGP_SYRK_WIDE=0: the LDS-staged k_syrk_stream everywhere) and the K_uu chain is held back
+ * until its single round is resident.  The planner places one cut, or two from six tile columns on while the masked launches
+ * are short; a data-sharded sweep (hook installed) keeps one cut -- every group is a collective. */
 int sgp_overlap_plan(const sgp_handle* h, int32_t* ngroups, int32_t* info /* 8 per group, up to 8 groups; may be NULL */);
 
 #ifdef __cplusplus
