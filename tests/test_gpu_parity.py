@@ -519,9 +519,12 @@ def test_kin40k_full_training_sweep_real_data(G, golden):
 # MultiSGP (GPnode/MultiSGPnode.jl): cubature points as weighted data, Kronecker precision, Wishart statistics
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("T,M,Do,gauss_out", [(30, 48, 2, False), (17, 20, 3, True), (300, 48, 2, True), (7, 65, 3, False),
-                                                (33, 21, 4, True), (60, 130, 2, True), (5, 1, 2, False)])
+                                                (33, 21, 4, True), (60, 130, 2, True), (5, 1, 2, False),
+                                                (1000, 70, 2, True), (601, 130, 2, False)])
 def test_multisgp_sweep_matches_oracle(G, T, M, Do, gauss_out):
-    """BASELINE config 5 shape (pendulum: 300 steps, M=48, D=2, srcubature = 5 points per step)."""
+    """BASELINE config 5 shape (pendulum: 300 steps, M=48, D=2, srcubature = 5 points per step).  The last two cases are large
+    enough (points x lower tiles >= 10 000) for the gated K_uu chain and k_syrk_direct with per-point weights -- 3 005 points: a
+    ragged last k-step."""
     rng = np.random.default_rng(T + M)
     Din = 2
     Xu = rng.uniform(-2, 2, (M, Din))
