@@ -2902,14 +2902,15 @@ __device__ __forceinline__ void tile_mma_swz(Acc4& acc, const double* As, const 
 // that two workgroups share a CU, and no atomics).  The workgroup with I == nb mod T also forms k_n . mu from the K_uf tiles it
 // stages anyway (four partial rows, one per wave).
 // Software-pipelined as before: the next tile pair is fetched into registers while the matrix cores work on the current one;
-// the triangular mask of the diagonal tile is applied in registers on the way into LDS; panels whose global reads run along k
-// are stored transposed-with-XOR (tile_mma_bswz).
+// the triangular mask of the diagonal tile is applied in registers on the way into LDS; panels are stored as they arrive (see
+// lstore_a / lstore_b).
 //   pa, pb : [2 T][N] partial column sums (row 2 I + wr),  kmu : [4][N]
 __global__ void __launch_bounds__(256, 2) k_quadform_fused(const double* __restrict__ Wk, const double* __restrict__ LR,
                                                         const double* __restrict__ Kuf, const double* __restrict__ mu,
                                                         double* __restrict__ pa, double* __restrict__ pb, double* __restrict__ kmu,
                                                         int ld, int T, int64_t N) {
-    __shared__ double lds[2 * TB * PS];
+    __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
+    constexpr int KS = 66;                            // row stride of a [row][kk] panel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int I = blockIdx.y;
     const int64_t n0 = (int64_t)blockIdx.x * TB;
@@ -2944,26 +2945,33 @@ __global__ void __launch_bounds__(256, 2) k_quadform_fused(const double* __restr
             if (n >= N) { rb[u][0] = make_double2(0.0, 0.0); rb[u][1] = make_double2(0.0, 0.0); }
         }
     };
-    // first factor: As[kk = hi][i = lo4 + q] (lower: kk <= i); second: As[kk = lo4 + q][i = hi, XOR-swizzled] (i <= kk) -- in both
-    // the entries to drop from the DIAGONAL tile are those with lo4 + q < hi
+    // Panels go into LDS the way they arrive (round 4b): an operand whose global reads run along the contraction index kk -- K_uf's
+    // columns, LR^T -- is stored [row][kk] with a row stride of KS = 66 doubles (a thread's four kk = two 16-byte stores; the MFMA
+    // operand read, 16 lanes = 16 rows at one kk, then hits 16 different bank pairs: 66 x 2 dwords = 4 mod 64), the first factor
+    // (W_K as stored: contiguous along i) stays [kk][i] with stride PS.  Before, the kk-contiguous panels were TRANSPOSED on the
+    // way in, four 8-byte stores per 32 bytes with an XOR swizzle: PMC counted 58 % of the LDS's active cycles as bank conflicts
+    // (profiles/r04_ab_log.txt [21]).
+    // first factor: As[kk = hi][i = lo4 + q] (lower: kk <= i); second: As[i = hi][kk = lo4 + q] (i <= kk) -- in both the entries to
+    // drop from the DIAGONAL tile are those with lo4 + q < hi
     auto lstore_a = [&](int second, bool dg) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int t = tid + 256 * u, hi = t >> 4, lo4 = (t & 15) * 4;
-            const double va[4] = {ra[u][0].x, ra[u][0].y, ra[u][1].x, ra[u][1].y};
-            double* dst = second ? As + lo4 * PS + (hi ^ (lo4 & 60)) : As + hi * PS + lo4;
-            const int step = second ? PS : 1;
+            double va[4] = {ra[u][0].x, ra[u][0].y, ra[u][1].x, ra[u][1].y};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q * step] = (dg && lo4 + q < hi) ? 0.0 : va[q];
+            for (int q = 0; q < 4; ++q) va[q] = (dg && lo4 + q < hi) ? 0.0 : va[q];
+            double* dst = As + hi * (second ? KS : PS) + lo4;
+            *reinterpret_cast<double2*>(dst) = make_double2(va[0], va[1]);
+            *reinterpret_cast<double2*>(dst + 2) = make_double2(va[2], va[3]);
         }
     };
     auto lstore_b = [&]() {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int t = tid + 256 * u, j = t >> 4, lo4 = (t & 15) * 4;
-            const double vb[4] = {rb[u][0].x, rb[u][0].y, rb[u][1].x, rb[u][1].y};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Bs[(lo4 + q) * PS + (j ^ (lo4 & 60))] = vb[q];                    // Bs[kk][j] = Kuf[k*64 + kk, n0 + j]
+            double* dst = Bs + j * KS + lo4;                                                         // Bs[j][kk] = Kuf[k*64 + kk, n0 + j]
+            *reinterpret_cast<double2*>(dst) = rb[u][0];
+            *reinterpret_cast<double2*>(dst + 2) = rb[u][1];
         }
     };
     // k_n . mu from the staged K_uf tile: thread -> (point j = tid & 63, sixteen rows of the tile per wave)
@@ -3009,22 +3017,23 @@ __global__ void __launch_bounds__(256, 2) k_quadform_fused(const double* __restr
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int kk = 16 * wave + q;
-                kacc = fma(Bs[kk * PS + (j ^ (kk & 60))], mu[k * TB + kk], kacc);
+                kacc = fma(Bs[j * KS + kk], mu[k * TB + kk], kacc);
             }
         }
-        const double* ap = As + lk * PS;
-        const double* bp = Bs + lk * PS;
+        // operand A of MFMA k-step kk: As[kk][row] (first factor) or As[row][kk] (second); operand B: Bs[column][kk]
+        const int ak = second ? 1 : PS, ar = second ? KS : 1;
+        const double* ap = As + lk * ak;
+        const double* bp = Bs + lk;
 #pragma unroll 4
         for (int kk = 0; kk < TB; kk += 4) {
-            const int x = kk & 60, xa = second ? x : 0;
-            const double a0 = ap[r0 ^ xa], a1 = ap[r1 ^ xa];
-            const double b0 = bp[c0 ^ x], b1 = bp[c1 ^ x];
+            const double a0 = ap[r0 * ar], a1 = ap[r1 * ar];
+            const double b0 = bp[c0 * KS], b1 = bp[c1 * KS];
             acc.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.t[0][0], 0, 0, 0);
             acc.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.t[0][1], 0, 0, 0);
             acc.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.t[1][0], 0, 0, 0);
             acc.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.t[1][1], 0, 0, 0);
-            ap += 4 * PS;
-            bp += 4 * PS;
+            ap += 4 * ak;
+            bp += 4;
         }
     }
     colsums_out(pb);
