@@ -418,28 +418,27 @@ __device__ __forceinline__ void tile_mma(Acc4& acc, const double* As, const doub
     }
 }
 
-// tile_mma with a SWIZZLED B panel: Bs[k][j] is stored at column j ^ (k & 60).  The kernels that build their B panel from K_uf
-// (k_quadform_cols, k_theta_grad_uf) read 32-byte pieces of K_uf columns -- 16 threads per column, thread g the k-rows 4 g .. 4 g + 3 --
-// and store them transposed: unswizzled, the 16 threads of a column write rows 4 g + q, 320 doubles apart = the same LDS bank,
-// a 16-way conflict on every store (the per-point kernels ran at 22 TFLOP/s).  With the XOR the 16 rows land on 16 different
-// bank pairs; a 16-lane MFMA operand read (one row, 16 consecutive columns) stays a permutation of an aligned 16-group, i.e.
-// conflict-free as before.
-__device__ __forceinline__ int bswz(int k, int j) { return j ^ (k & 60); }
-__device__ __forceinline__ void tile_mma_bswz(Acc4& acc, const double* As, const double* Bs, int kcount, int lane, int wr, int wc) {
+// tile_mma with a B panel that is stored as it arrives from a matrix whose rows run along the contraction index (K_uf: a point's
+// kernel values): Bs[j][k], row stride KMS = 66 doubles.  The kernels that build their B panel from K_uf (k_quadform_fused,
+// k_theta_grad_uf) read 32-byte pieces of K_uf rows -- 16 threads per row, thread g the k-entries 4 g .. 4 g + 3 -- and store them
+// with two 16-byte LDS stores; a 16-lane MFMA operand read (16 rows at one k) then hits 16 different bank pairs (66 x 2 dwords =
+// 4 mod 64).  Rounds 3 / 4a transposed the pieces on the way in (four 8-byte stores with an XOR swizzle): PMC counted 58 % of the
+// LDS's active cycles as bank conflicts (profiles/r04_ab_log.txt [21], [25]).
+constexpr int KMS = 66;
+__device__ __forceinline__ void tile_mma_bk(Acc4& acc, const double* As, const double* Bs, int kcount, int lane, int wr, int wc) {
     const int li = lane & 15, lk = lane >> 4;
     const double* ap = As + lk * PS + wr * 32 + li;
-    const double* bp = Bs + lk * PS;
-    const int c0 = wc * 32 + li, c1 = c0 + 16;
+    const double* bp = Bs + (wc * 32 + li) * KMS + lk;
 #pragma unroll 4
     for (int k = 0; k < kcount; k += 4) {
         double a0 = ap[0], a1 = ap[16];
-        double b0 = bp[c0 ^ (k & 60)], b1 = bp[c1 ^ (k & 60)];
+        double b0 = bp[0], b1 = bp[16 * KMS];
         acc.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.t[0][0], 0, 0, 0);
         acc.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.t[0][1], 0, 0, 0);
         acc.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.t[1][0], 0, 0, 0);
         acc.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.t[1][1], 0, 0, 0);
         ap += 4 * PS;
-        bp += 4 * PS;
+        bp += 4;
     }
 }
 
@@ -2872,26 +2871,6 @@ __global__ void __launch_bounds__(256) k_kernelmatrix(const double* __restrict__
 // reduced over the row-blocks by atomics-free two-pass (partial[rowblk][n]).
 //   first factor used as stored (lower, rows i, sum over k <= i);  second factor transposed (upper), sum over k >= i.
 // ------------------------------------------------------------------------------------------------
-template <bool ASWZ>
-__device__ __forceinline__ void tile_mma_swz(Acc4& acc, const double* As, const double* Bs, int kcount, int lane, int wr, int wc) {
-    const int li = lane & 15, lk = lane >> 4;
-    const double* ap = As + lk * PS;
-    const double* bp = Bs + lk * PS;
-    const int r0 = wr * 32 + li, r1 = r0 + 16, c0 = wc * 32 + li, c1 = c0 + 16;
-#pragma unroll 4
-    for (int k = 0; k < kcount; k += 4) {
-        const int x = k & 60;
-        double a0 = ap[ASWZ ? (r0 ^ x) : r0], a1 = ap[ASWZ ? (r1 ^ x) : r1];
-        double b0 = bp[c0 ^ x], b1 = bp[c1 ^ x];
-        acc.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.t[0][0], 0, 0, 0);
-        acc.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.t[0][1], 0, 0, 0);
-        acc.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.t[1][0], 0, 0, 0);
-        acc.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.t[1][1], 0, 0, 0);
-        ap += 4 * PS;
-        bp += 4 * PS;
-    }
-}
-
 // ONE launch for both quadratic forms (round 4; round 3 launched the body once per factor and a third kernel re-read K_uf for
 // k_n . mu): workgroup (point block nb, row tile I) walks T + 1 tile products --
 //     steps 0 .. I   :  rows I of  W_K K_uf   (W_K = L_K^-1, lower: tile columns k <= I)        -> a = sum of squares down the column
@@ -2910,7 +2889,7 @@ __global__ void __launch_bounds__(256, 2) k_quadform_fused(const double* __restr
                                                         double* __restrict__ pa, double* __restrict__ pb, double* __restrict__ kmu,
                                                         int ld, int T, int64_t N) {
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
-    constexpr int KS = 66;                            // row stride of a [row][kk] panel
+    constexpr int KS = KMS;                           // row stride of a [row][kk] panel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int I = blockIdx.y;
     const int64_t n0 = (int64_t)blockIdx.x * TB;
@@ -3102,7 +3081,7 @@ __global__ void __launch_bounds__(256) k_theta_grad_uf(const double* __restrict_
     // grid (nblk, T, KS): with few points (minibatches) the K loop is split over blockIdx.z so that the launch fills the
     // chip; the contraction is linear in G K_uf, so every split contributes its own partial sums (the y mu term rides
     // with split 0)
-    __shared__ double lds[2 * TB * PS];
+    __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
     __shared__ double ys[TB], om[TB], mus[TB];
     __shared__ double wsum[4][GRAD_SLOTS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
@@ -3117,21 +3096,21 @@ __global__ void __launch_bounds__(256) k_theta_grad_uf(const double* __restrict_
     for (int k = kbeg; k < kend; ++k) {
         __syncthreads();
         load_panel_n(As, G, Mp, I * TB, k * TB, TB, tid);          // As[kk][i] = G[I*64 + i, k*64 + kk]  (G symmetric)
-        for (int t = tid; t < TB * 16; t += 256) {                 // Bs[kk][j] = Kuf[k*64 + kk, n0 + j]
+        for (int t = tid; t < TB * 16; t += 256) {                 // Bs[j][kk] = Kuf[k*64 + kk, n0 + j]  (stored as it arrives: tile_mma_bk)
             int j = t >> 4, g = t & 15;
             int64_t n = n0 + j;
-            double v[4] = {0.0, 0.0, 0.0, 0.0};
+            double2 v0 = make_double2(0.0, 0.0), v1 = v0;
             if (n < N) {
                 const double* src = Kuf + (size_t)n * Mp + k * TB + g * 4;
-                double2 v0 = *reinterpret_cast<const double2*>(src);
-                double2 v1 = *reinterpret_cast<const double2*>(src + 2);
-                v[0] = v0.x; v[1] = v0.y; v[2] = v1.x; v[3] = v1.y;
+                v0 = *reinterpret_cast<const double2*>(src);
+                v1 = *reinterpret_cast<const double2*>(src + 2);
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Bs[(g * 4 + q) * PS + bswz(g * 4, j)] = v[q];
+            double* dst = Bs + j * KMS + g * 4;
+            *reinterpret_cast<double2*>(dst) = v0;
+            *reinterpret_cast<double2*>(dst + 2) = v1;
         }
         __syncthreads();
-        tile_mma_bswz(acc, As, Bs, TB, lane, wr, wc);
+        tile_mma_bk(acc, As, Bs, TB, lane, wr, wc);
     }
     __syncthreads();
     // the panels are done: their LDS now holds the scaled coordinates of this block's 64 inducing rows / 64 points
