@@ -200,6 +200,7 @@ struct sgp_handle {
     int env_g1_mode = 2;           // SGP_G1_AFTER (see enqueue_stats_overlapped)
     int env_syrk_wt = 0;           // SGP_SYRK_WT (see plan_overlap)
     bool env_syrk_wide = true;     // SGP_SYRK_WIDE=0: the 256-thread SYRK everywhere (A/B switch)
+    bool env_no_zero_copy = false; // SGP_NO_ZERO_COPY=1: sgp_w_stats copies its results back instead of writing them to pinned memory (A/B switch)
     int64_t gate_min = 10000;      // points x lower tiles from which the SYRK is taken to fill the chip (SGP_GATE_MIN: A/B switch; see set_point_count)
     bool syrk_wide = false;        // the resident problem's SYRK launches are k_syrk_direct (set_point_count)
     std::vector<int> env_overlap_cols;   // SGP_OVERLAP_COLS: group boundaries (tile columns of P Lambda P), e.g. "3" or "2,4"
@@ -568,6 +569,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         if (const char* wt = getenv("SGP_SYRK_WT")) h->env_syrk_wt = atoi(wt);
         if (const char* sw = getenv("SGP_SYRK_WIDE")) h->env_syrk_wide = atoi(sw) != 0;
         if (const char* gm = getenv("SGP_GATE_MIN")) h->gate_min = atoll(gm);
+        if (const char* zc = getenv("SGP_NO_ZERO_COPY")) h->env_no_zero_copy = atoi(zc) != 0;
         if (const char* oc = getenv("SGP_OVERLAP_COLS"))
             for (const char* q = oc; *q;) {
                 h->env_overlap_cols.push_back(atoi(q));
@@ -1948,12 +1950,12 @@ extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) 
     // |L^-1 k_n|^2 with the explicit inverse factor W_k, |Uv k_n|^2 = |L_R^T k_n|^2 and k_n . mu: ONE pass over the resident K_uf
     // (k_quadform_fused), then the fixed-order sums
     launch_quadform(h, s);
+    // Both vectors come back through the pinned staging block when they fit (two blocking copies into pageable memory were ~60 us of
+    // a 280 us call at n = 10 000) -- and the finishing kernel writes them THERE (pinned host memory is mapped into the device's
+    // address space: 160 KB of coalesced stores over the bus under the kernel, instead of a copy-engine launch behind it)
+    const bool staged = h->hStage && 2 * (size_t)n <= h->stage_doubles && !h->env_no_zero_copy;
     hipLaunchKernelGGL(k_w_point_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dPa, h->dPb, h->dKmu, h->dY,
-                       h->has_yv ? h->dYv : nullptr, dI1, dI2, h->dParams, h->T, n);
-    // both vectors come back in one copy through the pinned staging block when they fit (two blocking copies into pageable memory
-    // were ~60 us of a 280 us call at n = 10 000)
-    const bool staged = h->hStage && 2 * (size_t)n <= h->stage_doubles;
-    if (staged) HIPCHK(h, hipMemcpyAsync(h->hStage, dI1, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s));
+                       h->has_yv ? h->dYv : nullptr, staged ? h->hStage : dI1, staged ? h->hStage + n : dI2, h->dParams, h->T, n);
     HIPCHK(h, wait_stream(s));
     HIPCHK(h, hipGetLastError());
     if (int src = check_sync_status(h)) return src;          // (the sweep whose q(v) these are: a hand-off that gave up voids them too)
