@@ -200,6 +200,8 @@ struct sgp_handle {
     int env_g1_mode = 2;           // SGP_G1_AFTER (see enqueue_stats_overlapped)
     int env_syrk_wt = 0;           // SGP_SYRK_WT (see plan_overlap)
     bool env_syrk_wide = true;     // SGP_SYRK_WIDE=0: the 256-thread SYRK everywhere (A/B switch)
+    bool defer_request = false, kuu_deferred = false;   // the K_uu chain's steps enqueued alternately with the Lambda chain's (sgp_sweep, see enqueue_finish1)
+    bool env_no_interleave = false; // SGP_NO_INTERLEAVE=1: each chain's launches in one piece, as through round 4a (A/B switch)
     bool env_no_zero_copy = false; // SGP_NO_ZERO_COPY=1: sgp_w_stats copies its results back instead of writing them to pinned memory (A/B switch)
     int64_t gate_min = 10000;      // points x lower tiles from which the SYRK is taken to fill the chip (SGP_GATE_MIN: A/B switch; see set_point_count)
     bool syrk_wide = false;        // the resident problem's SYRK launches are k_syrk_direct (set_point_count)
@@ -373,36 +375,57 @@ static void launch_syrk(const SyrkGeom& g, hipStream_t s, const double* Kuf, con
 // (sigma_row_tile); pass the same buffer to launch_ata, which then only adds the last block row.
 // step_wait (may be nullptr): step_wait[j] != nullptr makes the stream wait for that event in front of step j (data-sharded
 // overlapped sweeps: the group of tile columns that step j forms has come back from its all-reduce, see enqueue_stats_overlapped).
-static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, double* scratch, hipStream_t s,
-                         double* Winv = nullptr, const LamForm* form = nullptr, double* Sacc = nullptr,
-                         const double* tv_xi = nullptr, double* tv_t = nullptr, const hipEvent_t* step_wait = nullptr) {
-    LamForm none;
-    memset(&none, 0, sizeof none);
-    none.trace_chain = form ? 1 : 0;
+// (a sequence object: launch_potrf runs it to the end; the interleaved enqueue of a sweep's two chains -- enqueue_chains_interleaved --
+// alternates between two of them)
+struct PotrfSeq {
+    double* A; int ld, Tn; int* info; int n_valid; double* scratch; hipStream_t s;
+    double* Winv; LamForm form; bool has_form; double* Sacc; const double* tv_xi; double* tv_t; const hipEvent_t* step_wait;
+    int j = 0;
+    PotrfSeq(double* A_, int ld_, int Tn_, int* info_, int n_valid_, double* scratch_, hipStream_t s_, double* Winv_ = nullptr,
+             const LamForm* form_ = nullptr, double* Sacc_ = nullptr, const double* tv_xi_ = nullptr, double* tv_t_ = nullptr,
+             const hipEvent_t* step_wait_ = nullptr)
+        : A(A_), ld(ld_), Tn(Tn_), info(info_), n_valid(n_valid_), scratch(scratch_), s(s_), Winv(Winv_), has_form(form_ != nullptr),
+          Sacc(Sacc_), tv_xi(tv_xi_), tv_t(tv_t_), step_wait(step_wait_) {
+        if (form_) form = *form_;
+        else { memset(&form, 0, sizeof form); }
+    }
     // extra workgroups of launch j: (j >= 2) finish block row j - 1 of W, pre-accumulate block row j (not in the last,
     // potrf-free launch j = Tn), with Sacc add block row j - 2's contribution to Sigma = W^T W; (j >= 1, with tv_t) one
     // workgroup computes block j - 1 of the forward solve t = W (P xi)
-    auto extras = [&](int j) {
+    int extras(int jj) const {
         if (!Winv) return 0;
         int e = 0;
-        if (j >= 2) {
-            e += 2 * (j - 1) * (j < Tn ? 2 : 1);
-            if (Sacc && j < Tn) e += (j - 1) * j / 2;           // (row Tn - 2 of Sigma: left to the product launch, see k_potrf_step)
+        if (jj >= 2) {
+            e += 2 * (jj - 1) * (jj < Tn ? 2 : 1);
+            if (Sacc && jj < Tn) e += (jj - 1) * jj / 2;           // (row Tn - 2 of Sigma: left to the product launch, see k_potrf_step)
         }
-        if (tv_t && j >= 1) e += 1;
+        if (tv_t && jj >= 1) e += 1;
         return e;
-    };
-    for (int j = 0; j < Tn; ++j) {
-        const int nt = Tn - j;
-        if (step_wait && step_wait[j]) (void)hipStreamWaitEvent(s, step_wait[j], 0);
-        hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + potrf_twins(Tn, j) + extras(j)), dim3(PSTEP_THREADS), 0, s, A, ld, j, Tn, info, n_valid,
-                           scratch, Winv, Sacc, tv_xi, tv_t, form ? *form : none);      // (every step: a tile column may be formed later than step 0)
     }
-    if (Winv && extras(Tn) > 0)
-        hipLaunchKernelGGL(k_potrf_step, dim3(extras(Tn)), dim3(PSTEP_THREADS), 0, s, A, ld, Tn, Tn, info, n_valid, scratch, Winv, Sacc,
-                           tv_xi, tv_t, none);
+    bool done() const { return j > Tn; }
+    void next() {                                     // launch j: a Cholesky step (j < Tn) or the launch behind the last step (j == Tn)
+        LamForm none;
+        memset(&none, 0, sizeof none);
+        none.trace_chain = has_form ? 1 : 0;
+        if (j < Tn) {
+            const int nt = Tn - j;
+            if (step_wait && step_wait[j]) (void)hipStreamWaitEvent(s, step_wait[j], 0);
+            hipLaunchKernelGGL(k_potrf_step, dim3(nt * (nt + 1) / 2 + potrf_twins(Tn, j) + extras(j)), dim3(PSTEP_THREADS), 0, s, A, ld, j, Tn, info,
+                               n_valid, scratch, Winv, Sacc, tv_xi, tv_t, has_form ? form : none);   // (every step: a tile column may be formed later than step 0)
+        } else if (j == Tn && Winv && extras(Tn) > 0) {
+            hipLaunchKernelGGL(k_potrf_step, dim3(extras(Tn)), dim3(PSTEP_THREADS), 0, s, A, ld, Tn, Tn, info, n_valid, scratch, Winv, Sacc,
+                               tv_xi, tv_t, none);
+        }
+        ++j;
+    }
+};
+static void launch_potrf(double* A, int ld, int Tn, int* info, int n_valid, double* scratch, hipStream_t s,
+                         double* Winv = nullptr, const LamForm* form = nullptr, double* Sacc = nullptr,
+                         const double* tv_xi = nullptr, double* tv_t = nullptr, const hipEvent_t* step_wait = nullptr) {
+    PotrfSeq q(A, ld, Tn, info, n_valid, scratch, s, Winv, form, Sacc, tv_xi, tv_t, step_wait);
+    while (!q.done()) q.next();
 }
-// C = W^T W (rev: written index-reversed).  With mu: also R = C + mu mu^T, and with Psi2 the per-block shares of tr(R Psi2).
+
 static void launch_ata(const double* W, double* C, int ld, int Tn, hipStream_t s, int rev = 0, const double* mu = nullptr,
                        double* R = nullptr, const double* Psi2 = nullptr, const double* Kinv = nullptr,
                        double* trace_part = nullptr, const UvArgs* uv = nullptr, const double* Sacc = nullptr) {
@@ -570,6 +593,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         if (const char* sw = getenv("SGP_SYRK_WIDE")) h->env_syrk_wide = atoi(sw) != 0;
         if (const char* gm = getenv("SGP_GATE_MIN")) h->gate_min = atoll(gm);
         if (const char* zc = getenv("SGP_NO_ZERO_COPY")) h->env_no_zero_copy = atoi(zc) != 0;
+        if (const char* ni = getenv("SGP_NO_INTERLEAVE")) h->env_no_interleave = atoi(ni) != 0;
         if (const char* oc = getenv("SGP_OVERLAP_COLS"))
             for (const char* q = oc; *q;) {
                 h->env_overlap_cols.push_back(atoi(q));
@@ -1129,7 +1153,17 @@ extern "C" int sgp_bind_stats(sgp_handle* h, void* stats_dev) {
 //   F2 (main stream) : Sigma, R, both traces, Uv pass 2, scalars                               [sgp_sweep_finish]
 // The two chains are latency-bound pivot sequences that use a handful of CUs each; they overlap only when they sit on
 // different streams (parallel branches inside ONE captured graph were observed to execute back to back).
-static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
+// the K_uu chain in three pieces -- [k_prep_xu, Gram] [Cholesky steps + inverse factor] [K_uu^-1, join word] -- so that a sweep can
+// enqueue its two chains' steps alternately (enqueue_chains_interleaved)
+static void kuu_gram(sgp_handle* h, hipStream_t s, bool gate) {
+    if (gate) hipLaunchKernelGGL(k_gram_uu_lds, dim3(h->T, h->T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, h->M, h->Mp, h->D);
+    else hipLaunchKernelGGL(k_gram_uu, dim3(h->T, h->T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, h->M, h->Mp, h->D);
+}
+static void kuu_tail(sgp_handle* h, hipStream_t s) {
+    launch_ata(h->dWk, h->dKinv, h->Mp, h->T, s, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->dSaccK);
+    if (h->join_by_flag) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_JOIN, h->join_epoch);
+}
+static void enqueue_kuu_head(sgp_handle* h, hipStream_t s, bool steps_too) {
     const int M = h->M, Mp = h->Mp, D = h->D, T = h->T;
     const bool words = h->dev_words && s == h->side;
     // The gate (the chain's whole-CU workgroups stay off the chip until the SYRK's resident round is on it) sits inside k_prep_xu, in
@@ -1152,16 +1186,17 @@ static void enqueue_kuu(sgp_handle* h, hipStream_t s) {
         std::swap(h->dKuu, h->dKuuAlt);         // this launch's factor goes to the buffer the last one refilled with sentinels
         launch_chain(h, 0, h->dKuu, h->dKuuAlt, Mp, T, h->dInfo + 0, M, s, h->dWk, nullptr, h->dSaccK, nullptr, nullptr, h->dXusK,
                      h->dParamsK, M, D);
-    } else
-#endif
-    {
-        if (gate) hipLaunchKernelGGL(k_gram_uu_lds, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
-        else hipLaunchKernelGGL(k_gram_uu, dim3(T, T), dim3(256), 0, s, h->dXusK, h->dKuu, h->dParamsK, M, Mp, D);
-        launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk, nullptr, h->dSaccK);
+        kuu_tail(h, s);
+        return;
     }
-    launch_ata(h->dWk, h->dKinv, Mp, T, s, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->dSaccK);
-    if (h->join_by_flag) hipLaunchKernelGGL(k_join_set, dim3(1), dim3(64), 0, s, h->dJoin + WORD_JOIN, h->join_epoch);
+#endif
+    kuu_gram(h, s, gate);
+    if (steps_too) {
+        launch_potrf(h->dKuu, Mp, T, h->dInfo + 0, M, h->dScratch, s, h->dWk, nullptr, h->dSaccK);
+        kuu_tail(h, s);
+    }
 }
+static void enqueue_kuu(sgp_handle* h, hipStream_t s) { enqueue_kuu_head(h, s, true); }
 
 static void launch_gram(sgp_handle* h, hipStream_t s, bool opens_sweep) {
     int64_t* sweep_begin = opens_sweep ? h->dStamps : nullptr;
@@ -1299,8 +1334,24 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
         launch_chain(h, 1, h->dLam, h->dLamAlt, Qp, TQ, h->dInfo + 1, Qp, s, h->dWl, &form, h->dTmp, h->dXi, uvt0, nullptr, nullptr, 0, 0);
     } else
 #endif
-        launch_potrf(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + POTRF_SCRATCH, s, h->dWl, &form, h->dTmp, h->dXi, uvt0,
+    {
+        PotrfSeq lam(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + POTRF_SCRATCH, s, h->dWl, &form, h->dTmp, h->dXi, uvt0,
                      any_wait ? step_wait : nullptr);
+        if (h->kuu_deferred) {
+            // The K_uu chain's Cholesky steps were held back (sweep_local_impl): its launches and the Lambda chain's go out ALTERNATELY, so
+            // that on a GPU that is idle when the sweep arrives -- the first sweep of a timed block; every sweep of a drop-in that
+            // fetches something in between -- neither chain waits for the host to get through the other's ten launches (the Lambda
+            // chain's first step used to arrive ~25 us after the GPU was ready for it).  Same launches, same order on each stream.
+            PotrfSeq kuu(h->dKuu, h->Mp, h->T, h->dInfo + 0, h->M, h->dScratch, h->side, h->dWk, nullptr, h->dSaccK);
+            while (!lam.done() || !kuu.done()) {
+                if (!lam.done()) lam.next();
+                if (!kuu.done()) kuu.next();
+            }
+            kuu_tail(h, h->side);
+        } else {
+            while (!lam.done()) lam.next();
+        }
+    }
     // mu = Sigma xi = P W'^T W' P xi as two triangular mat-vecs; their intermediate t IS p = V^-T mu up to the reversal,
     // so the closed-form Uv needs no further solve and nothing here waits for Sigma itself
     double* uvp = h->dXi;                    // xi is consumed by the forward solve; p lands in the same vector afterwards
@@ -1472,12 +1523,20 @@ static int sweep_local_impl(sgp_handle* h, void* stream, bool overlapped) {
     };
     if (stats_first)
         if (int src = enqueue_stats()) return src;
-    rc = run_sequence(h, h->gKuu, enqueue_kuu, h->side);
+    // (one-shot sgp_sweep on the library's streams: only the K_uu chain's first two kernels go out here, its steps are enqueued
+    // alternately with the Lambda chain's by sgp_sweep_finish -- see enqueue_finish1)
+    h->kuu_deferred = h->defer_request && stats_first && !h->use_events && !h->use_chain && s == h->own;
+    if (h->kuu_deferred) {
+        enqueue_kuu_head(h, h->side, false);
+        HIPCHK(h, hipGetLastError());
+        rc = 0;
+    } else
+        rc = run_sequence(h, h->gKuu, enqueue_kuu, h->side);
 #ifdef SGP_WITH_PERSISTENT_CHAIN
     h->gate_kuu = false;
 #endif
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->evSide, h->side));
+    if (!h->kuu_deferred) HIPCHK(h, hipEventRecord(h->evSide, h->side));
     if (!stats_first)
         if (int src = enqueue_stats()) return src;
     h->stats_dirty = false;
@@ -1497,6 +1556,10 @@ extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
     h->in_flight = true;
     int rc = run_sequence(h, h->gFinish, enqueue_finish1, s);
     if (rc) return rc;
+    if (h->kuu_deferred) {                                   // (the K_uu chain's steps and tail went out inside enqueue_finish1)
+        HIPCHK(h, hipEventRecord(h->evSide, h->side));
+        h->kuu_deferred = false;
+    }
     if (!h->join_by_flag) HIPCHK(h, hipStreamWaitEvent(s, h->evSide, 0));          // join with the K_uu chain
     ++h->done_epoch;                                         // what this sweep's k_scalars writes when it is through
     rc = run_sequence(h, h->gFinish2, enqueue_finish2, s);
@@ -1534,7 +1597,9 @@ extern "C" int sgp_sweep(sgp_handle* h, void* stream) {
     // (with an all-reduce hook as well: one reduce per statistics group, see enqueue_stats_overlapped)
     const bool overlapped = h->overlap && !stream && h->n > 0 && !h->training;
     h->pack_now = h->allreduce != nullptr;
+    h->defer_request = !h->env_no_interleave;
     int rc = sweep_local_impl(h, stream, overlapped);
+    h->defer_request = false;
     h->pack_now = false;
     if (rc) return rc;
     if (h->allreduce && !overlapped) {
