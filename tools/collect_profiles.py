@@ -16,7 +16,7 @@ names = {"bench_T.json": "r04_bench_T.json", "bench_N1M.json": "r04_bench_N1M.js
          "train_kin40k.txt": "r04_train_kin40k.json", "train_banana.txt": "r04_train_banana.json", "pytest_gpu.txt": "r04_pytest_gpu.txt",
          "rehearse_two_ranks_overlapped.txt": "r04_rehearse_two_ranks_overlapped.txt", "wstats_time.txt": "r04_wstats_time.txt",
          "hooked_train_rc.txt": "r04_hooked_train_rc.txt", "ab_r3_vs_r4.txt": "r04_ab_r3_vs_r4_measurement_box.txt",
-         "bench_T_syrk_256_threads.json": "r04_bench_T_syrk_256_threads.json",
+         "bench_T_syrk_256_threads.json": "r04_bench_T_syrk_256_threads.json", "bench_driver_style.json": "r04_bench_T_driver_style_steps20.json",
          "mfma_f64_probe.txt": "r04_mfma_f64_probe.txt", "dpp_f64_probe.txt": "r04_dpp_f64_probe.txt",
          "syrk_direct_probe.txt": "r04_syrk_direct_probe.txt", "store_bw_probe.txt": "r04_store_bw_probe.txt",
          }
