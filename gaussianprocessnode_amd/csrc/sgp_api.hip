@@ -201,7 +201,7 @@ struct sgp_handle {
     int env_syrk_wt = 0;           // SGP_SYRK_WT (see plan_overlap)
     bool env_syrk_wide = true;     // SGP_SYRK_WIDE=0: the 256-thread SYRK everywhere (A/B switch)
     bool defer_request = false, kuu_deferred = false;   // the K_uu chain's steps enqueued alternately with the Lambda chain's (sgp_sweep, see enqueue_finish1)
-    bool env_no_interleave = false; // SGP_NO_INTERLEAVE=1: each chain's launches in one piece, as through round 4a (A/B switch)
+    bool env_interleave = false;    // SGP_INTERLEAVE=1: the two chains' launches enqueued alternately (A/B switch; measured neutral, off)
     bool env_no_zero_copy = false; // SGP_NO_ZERO_COPY=1: sgp_w_stats copies its results back instead of writing them to pinned memory (A/B switch)
     int64_t gate_min = 10000;      // points x lower tiles from which the SYRK is taken to fill the chip (SGP_GATE_MIN: A/B switch; see set_point_count)
     bool syrk_wide = false;        // the resident problem's SYRK launches are k_syrk_direct (set_point_count)
@@ -593,7 +593,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         if (const char* sw = getenv("SGP_SYRK_WIDE")) h->env_syrk_wide = atoi(sw) != 0;
         if (const char* gm = getenv("SGP_GATE_MIN")) h->gate_min = atoll(gm);
         if (const char* zc = getenv("SGP_NO_ZERO_COPY")) h->env_no_zero_copy = atoi(zc) != 0;
-        if (const char* ni = getenv("SGP_NO_INTERLEAVE")) h->env_no_interleave = atoi(ni) != 0;
+        if (const char* ni = getenv("SGP_INTERLEAVE")) h->env_interleave = atoi(ni) != 0;
         if (const char* oc = getenv("SGP_OVERLAP_COLS"))
             for (const char* q = oc; *q;) {
                 h->env_overlap_cols.push_back(atoi(q));
@@ -1338,10 +1338,12 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
         PotrfSeq lam(h->dLam, Qp, TQ, h->dInfo + 1, Qp, h->dScratch + POTRF_SCRATCH, s, h->dWl, &form, h->dTmp, h->dXi, uvt0,
                      any_wait ? step_wait : nullptr);
         if (h->kuu_deferred) {
-            // The K_uu chain's Cholesky steps were held back (sweep_local_impl): its launches and the Lambda chain's go out ALTERNATELY, so
-            // that on a GPU that is idle when the sweep arrives -- the first sweep of a timed block; every sweep of a drop-in that
-            // fetches something in between -- neither chain waits for the host to get through the other's ten launches (the Lambda
-            // chain's first step used to arrive ~25 us after the GPU was ready for it).  Same launches, same order on each stream.
+            // (SGP_INTERLEAVE=1, off by default.)  The K_uu chain's Cholesky steps were held back (sweep_local_impl): its launches and the
+            // Lambda chain's go out ALTERNATELY, so that on a GPU that is idle when the sweep arrives neither chain waits for the host to
+            // get through the other's ten launches (the Lambda chain's first step arrives ~25 us after the GPU is ready for it).  Same
+            // launches, same order on each stream.  Measured: the first A/B gained 1.3 % on 20-sweep blocks and 5 % on the sweep; w_stats
+            // loop, two repeats on other boxes were neutral to -1 % -- switching streams between launches costs the host ~20 us per
+            // sweep (120 instead of 100 us), which on a busy host is exactly what a short block lacks (profiles/r04_ab_log.txt [30]).
             PotrfSeq kuu(h->dKuu, h->Mp, h->T, h->dInfo + 0, h->M, h->dScratch, h->side, h->dWk, nullptr, h->dSaccK);
             while (!lam.done() || !kuu.done()) {
                 if (!lam.done()) lam.next();
@@ -1597,7 +1599,7 @@ extern "C" int sgp_sweep(sgp_handle* h, void* stream) {
     // (with an all-reduce hook as well: one reduce per statistics group, see enqueue_stats_overlapped)
     const bool overlapped = h->overlap && !stream && h->n > 0 && !h->training;
     h->pack_now = h->allreduce != nullptr;
-    h->defer_request = !h->env_no_interleave;
+    h->defer_request = h->env_interleave;
     int rc = sweep_local_impl(h, stream, overlapped);
     h->defer_request = false;
     h->pack_now = false;
