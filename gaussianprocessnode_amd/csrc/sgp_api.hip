@@ -1924,7 +1924,8 @@ extern "C" int sgp_get_phase_totals(sgp_handle* h, int64_t* totals, int64_t* cou
 // ------------------------------------------------------------------------------------------------
 // the per-point quadratic forms |L_K^-1 k_n|^2, |Uv k_n|^2 and k_n . mu in one pass over the resident K_uf
 static void launch_quadform(sgp_handle* h, hipStream_t s) {
-    hipLaunchKernelGGL(k_quadform_fused, dim3(h->nblk, h->T), dim3(256), 0, s, h->dWk, h->dUvT, h->dKuf, h->dMu, h->dPa, h->dPb, h->dKmu,
+    // (grid.y: 2 T work items per point block -- a factor's part of a row tile --, largest first: see k_quadform_fused)
+    hipLaunchKernelGGL(k_quadform_fused, dim3(h->nblk, 2 * h->T), dim3(256), 0, s, h->dWk, h->dUvT, h->dKuf, h->dMu, h->dPa, h->dPb, h->dKmu,
                        h->Mp, h->T, h->n);
 }
 

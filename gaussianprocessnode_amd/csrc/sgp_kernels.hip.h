@@ -2875,9 +2875,9 @@ __global__ void __launch_bounds__(256) k_kernelmatrix(const double* __restrict__
 // k_n . mu): workgroup (point block nb, row tile I) walks T + 1 tile products --
 //     steps 0 .. I   :  rows I of  W_K K_uf   (W_K = L_K^-1, lower: tile columns k <= I)        -> a = sum of squares down the column
 //     steps I .. T-1 :  rows I of  Uv  K_uf   (Uv upper = LR^T: tile columns k >= I)            -> b
-// so every workgroup carries the same work (the per-factor launches had 1 .. T products per workgroup), the K_uf tile of
-// k = I is staged once for both factors, and the accumulator is reused: at the switch the column sums of squares of the first
-// factor leave as two partial rows (one per wave row, summed in fixed order by k_w_point_finish -- no LDS beyond the panels, so
+// (round 4a: both step ranges in ONE workgroup -- equal work, the K_uf tile of k = I staged once --; round 4b: one workgroup per
+// factor's part, largest first, see the grid map below: equal items quantise badly on 512 slots.)  The column sums of squares of a
+// part leave as two partial rows (one per wave row, summed in fixed order by k_w_point_finish -- no LDS beyond the panels, so
 // that two workgroups share a CU, and no atomics).  The workgroup with I == nb mod T also forms k_n . mu from the K_uf tiles it
 // stages anyway (four partial rows, one per wave).
 // Software-pipelined as before: the next tile pair is fetched into registers while the matrix cores work on the current one;
@@ -2891,7 +2891,16 @@ __global__ void __launch_bounds__(256, 2) k_quadform_fused(const double* __restr
     __shared__ __attribute__((aligned(16))) double lds[2 * TB * PS];
     constexpr int KS = KMS;                           // row stride of a [row][kk] panel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    const int I = blockIdx.y;
+    // grid.y = 2 T work items per point block, LARGEST FIRST (workgroups are dispatched x fastest, then y: the long items of all point
+    // blocks start first and the short ones fill the CUs as they drain -- list scheduling by the hardware's own dispatcher):
+    //     y = 2 c     : the first factor's part of row tile I = T - 1 - c   (steps k = 0 .. I:      T - c products)
+    //     y = 2 c + 1 : the second factor's part of row tile I = c           (steps k = I .. T - 1:  T - c products)
+    // As ONE item per (point block, row tile) -- T + 1 products each, the K_uf tile of k = I staged once for both factors -- the
+    // 1 256 equal workgroups of T needed three rounds on the 512 slots for 2.45 rounds' worth of work (PMC: 1.59 of 2 waves per SIMD
+    // resident on average).
+    const int cls = blockIdx.y >> 1, part_b = blockIdx.y & 1;
+    const int I = part_b ? cls : T - 1 - cls;
+    const int s_begin = part_b ? I + 1 : 0, s_end = part_b ? T : I;      // steps as before: s <= I first factor (k = s), s > I second (k = s - 1)
     const int64_t n0 = (int64_t)blockIdx.x * TB;
     double* As = lds;
     double* Bs = lds + TB * PS;
@@ -2954,7 +2963,7 @@ __global__ void __launch_bounds__(256, 2) k_quadform_fused(const double* __restr
         }
     };
     // k_n . mu from the staged K_uf tile: thread -> (point j = tid & 63, sixteen rows of the tile per wave)
-    const bool kmu_duty = (I == (int)(blockIdx.x % (unsigned)T));
+    const bool kmu_duty = part_b && I == 0;          // (the second factor's part of row tile 0 walks over ALL tile columns of K_uf)
     double kacc = 0.0;
     // column sums of squares over the wave's 32 rows -> partial row 2 I + wr
     auto colsums_out = [&](double* __restrict__ part) {
@@ -2971,27 +2980,23 @@ __global__ void __launch_bounds__(256, 2) k_quadform_fused(const double* __restr
             if (lane < 16 && n < N) part[(size_t)(2 * I + wr) * N + n] = cs;
         }
     };
-    gload_a(0, 0);
-    gload_b(0);
+    gload_a(part_b, s_begin - part_b);
+    gload_b(s_begin - part_b);
     const int li = lane & 15, lk = lane >> 4;
     const int r0 = wr * 32 + li, r1 = r0 + 16, c0 = wc * 32 + li, c1 = c0 + 16;
 #pragma unroll 1
-    for (int s = 0; s <= T; ++s) {                    // steps 0 .. I: first factor, tile column k = s; I + 1 .. T: second, k = s - 1
+    for (int s = s_begin; s <= s_end; ++s) {          // steps 0 .. I: first factor, tile column k = s; I + 1 .. T: second, k = s - 1
         const int second = s > I ? 1 : 0, k = s - second;
         __syncthreads();                              // the previous tile pair has been consumed
-        if (s == I + 1) {                             // the switch: the first factor's column sums leave, the accumulator starts over
-            colsums_out(pa);
-            acc_zero(acc);
-        }
         lstore_a(second, k == I);
-        if (s != I + 1) lstore_b();                   // (the second factor starts on the K_uf tile that is already staged)
+        lstore_b();
         __syncthreads();
-        if (s < T) {                                  // the next step's tiles: in flight while the matrix cores run
+        if (s < s_end) {                              // the next step's tiles: in flight while the matrix cores run
             const int sn = s + 1, secn = sn > I ? 1 : 0, kn = sn - secn;
             gload_a(secn, kn);
-            if (sn != I + 1) gload_b(kn);
+            gload_b(kn);
         }
-        if (kmu_duty && s != I + 1) {
+        if (kmu_duty) {
             const int j = tid & 63;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -3015,7 +3020,7 @@ __global__ void __launch_bounds__(256, 2) k_quadform_fused(const double* __restr
             bp += 4;
         }
     }
-    colsums_out(pb);
+    colsums_out(part_b ? pb : pa);
     if (kmu_duty) {
         const int64_t n = n0 + (tid & 63);
         if (n < N) kmu[(size_t)wave * N + n] = kacc;
