@@ -51,11 +51,13 @@ SGP_SYRK_WIDE=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_T
 # one cut) and this one.  The old libraries are built by hand from `git show <commit>:...`; a library that lacks an
 # export bench.py now calls prints no line.
 D=gaussianprocessnode_amd/csrc
-if [ -f $D/libsgp_hip_r4a.so ]; then cp $D/libsgp_hip.so $D/libsgp_hip_fin.so; bash tools/ab_multi.sh 3 "round3_library|base|" "round4_first_half|r4a|" "round4_final|fin|" 2>&1 | grep -v Traceback | grep -v "^  File\|IndexError\|^    " > $O/ab_r3_vs_r4.txt; cat $O/ab_r3_vs_r4.txt; fi
+if [ -f $D/libsgp_hip_r4a.so ]; then
+cp $D/libsgp_hip.so $D/libsgp_hip_fin.so; bash tools/ab_multi.sh 3 "round3_library|base|" "round4_first_half|r4a|" "round4_final|fin|" 2>&1 | grep -v Traceback | grep -v "^  File\|IndexError\|^    " > $O/ab_r3_vs_r4.txt; cat $O/ab_r3_vs_r4.txt
 for w in C3 N1M; do for v in r4a fin; do cp $D/libsgp_hip_$v.so $D/libsgp_hip.so; SGP_BENCH_SKIP_ALONE=1 timeout -k 10 300 python bench.py --no-cpu-baseline --workload $w --steps 100 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w', '$v', round(d['value'],2), 'sweeps/s')"; done; done >> $O/ab_r3_vs_r4.txt 2>&1; tail -4 $O/ab_r3_vs_r4.txt
 cp $D/libsgp_hip_fin.so $D/libsgp_hip.so
+fi
 timeout -k 10 60 ./tools/mfma_f64_probe > $O/mfma_f64_probe.txt 2>&1; timeout -k 10 60 ./tools/dpp_f64_probe > $O/dpp_f64_probe.txt 2>&1; timeout -k 10 120 ./tools/syrk_direct_probe > $O/syrk_direct_probe.txt 2>&1; timeout -k 10 60 ./tools/store_bw_probe > $O/store_bw_probe.txt 2>&1
 echo "measure_round done"
 
