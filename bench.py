@@ -75,20 +75,26 @@ def synthetic(N, M, D, seed=1, n_test=2000):
     return X, Xu, y, Xt, yt
 
 
-def _rate(dev, reps, per_point=False):
-    """Back-to-back sweeps per second on a prepared device (with the per-point :w quantities fetched every sweep if asked)."""
+def _rate(dev, reps, per_point=False, blocks=5):
+    """Back-to-back sweeps per second on a prepared device (with the per-point :w quantities fetched every sweep if asked):
+    the MEDIAN of `blocks` timed blocks of reps / blocks sweeps, like the headline -- on the shared boxes the host thread loses a
+    10 ms scheduler tick a few times per thousand iterations (tools/per_point_outliers.py), a fifth of a 200-sweep measurement."""
     for _ in range(10):
         dev.sweep()
         if per_point:
             dev.w_stats()
     dev.scalars()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        dev.sweep()
-        if per_point:
-            dev.w_stats()
-    dev.scalars()
-    return reps / (time.perf_counter() - t0)
+    per = max(1, reps // blocks)
+    rates = []
+    for _ in range(blocks):
+        t0 = time.perf_counter()
+        for _ in range(per):
+            dev.sweep()
+            if per_point:
+                dev.w_stats()
+        dev.scalars()
+        rates.append(per / (time.perf_counter() - t0))
+    return float(np.median(rates))
 
 
 def extras(headline):
@@ -125,7 +131,7 @@ def extras(headline):
                 tf = flops / (q_us * 1e-6) / 1e12
                 out["per_point"].append({
                     "config": name, "sweeps_per_s_with_w_stats": rate_pp, "sweeps_per_s_without": rate,
-                    "what": "sgp_sweep + sgp_w_stats (k_quadform_fused + k_w_point_finish, then 2 n doubles to the host in one copy) per iteration",
+                    "what": "sgp_sweep + sgp_w_stats (k_quadform_fused + k_w_point_finish, then 2 n doubles to the host in one copy) per iteration; median of 5 blocks of 40",
                     "roofline_quadform": {"kernel": "k_quadform_fused (|L^-1 k_n|^2, |Uv k_n|^2 and k_n . mu in one pass over the resident K_uf)", "bound": "mfma",
                                           "launch_us": q_us, "algorithmic_flops_per_launch": flops, "achieved": tf,
                                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS}})
