@@ -160,6 +160,8 @@ struct sgp_handle {
     int64_t* dStamps = nullptr;
     int64_t* dStampTotals = nullptr;
     Params* hParams = nullptr;     // pinned
+    double* hMirror = nullptr;     // pinned: the last sweep's scalars + hand-off status word + epoch, written by k_scalars itself
+    long long mirror_epoch = -1;   // done_epoch of the sweep whose k_scalars was given hMirror; -1: something enqueued since may have changed the status word
     double* hStage = nullptr;      // pinned staging of sgp_set_data (minibatches: one synchronisation instead of six blocking copies)
     size_t stage_doubles = 0;
     uint64_t params_gen = 1;       // bumped by every setter that changes hParams or Xu
@@ -673,6 +675,12 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
             (void)hipGetLastError();
         }
     }
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->hMirror), sizeof(double) * (SGP_R_COUNT + 2), hipHostMallocDefault) != hipSuccess) {
+        h->hMirror = nullptr;                               // (not fatal: the getters copy from the device)
+        (void)hipGetLastError();
+    } else {
+        for (int i = 0; i < SGP_R_COUNT + 2; ++i) h->hMirror[i] = -1.0;
+    }
     memset(h->hParams, 0, sizeof(Params));
     h->hParams->sigma2 = 1.0;
     for (int d = 0; d < MAXD; ++d) h->hParams->inv_ell[d] = 1.0;
@@ -763,6 +771,7 @@ extern "C" int sgp_destroy(sgp_handle* h) {
 #endif
     if (h->hParams) hipHostFree(h->hParams);
     if (h->hStage) hipHostFree(h->hStage);
+    if (h->hMirror) hipHostFree(h->hMirror);
     if (h->evSide) hipEventDestroy(h->evSide);
     if (h->evDone) hipEventDestroy(h->evDone);
     for (hipEvent_t e : h->evGroup) if (e) hipEventDestroy(e);
@@ -1121,6 +1130,7 @@ extern "C" int sgp_carry_posterior(sgp_handle* h, void* stream) {
     HIPCHK(h, hipGetLastError());
     h->prior_form = 1;
     h->in_flight = true;                       // (asynchronous: a following setter must wait for it before it touches the prior)
+    h->mirror_epoch = -1;
     return 0;
 }
 
@@ -1367,6 +1377,11 @@ static void enqueue_finish1(sgp_handle* h, hipStream_t s) {
 }
 
 // after the join with the side stream (K_uu chain): Sigma, R, the traces, Uv pass 2 and the scalars
+// k_scalars' pinned mirror (see there): on for eager sweeps outside a device-paced training run (whose loop reads nothing back)
+static double* mirror_for(const sgp_handle* h) {
+    return (h->hMirror && !(h->cfg.flags & SGP_FLAG_GRAPH) && !h->env_no_zero_copy && !h->training) ? h->hMirror : nullptr;
+}
+
 static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
     const int M = h->M, Mp = h->Mp, Q = h->Q, Qp = h->Qp, TQ = h->TQ;
     double* uvp = h->dXi;
@@ -1401,7 +1416,8 @@ static void enqueue_finish2(sgp_handle* h, hipStream_t s) {
                        h->dStamps + STAMP_STRIDE * SGP_T_FINISH2, h->dStamps, h->dStampTotals,
                        (h->cfg.flags & SGP_FLAG_GRAPH) ? (long long*)nullptr : h->dJoin + WORD_DONE, h->done_epoch,
                        h->use_chain ? (const double*)nullptr : (const double*)(h->dScratch + POTRF_LOGDET), h->T,
-                       h->use_chain ? (const double*)nullptr : (const double*)(h->dScratch + POTRF_SCRATCH + POTRF_LOGDET), TQ);
+                       h->use_chain ? (const double*)nullptr : (const double*)(h->dScratch + POTRF_SCRATCH + POTRF_LOGDET), TQ,
+                       mirror_for(h));
 }
 
 static int set_device_checked(int device) {
@@ -1566,6 +1582,7 @@ extern "C" int sgp_sweep_finish(sgp_handle* h, void* stream) {
     ++h->done_epoch;                                         // what this sweep's k_scalars writes when it is through
     rc = run_sequence(h, h->gFinish2, enqueue_finish2, s);
     if (rc) return rc;
+    h->mirror_epoch = mirror_for(h) ? h->done_epoch : -1;
     // the next sweep's K_uu chain may overwrite K_uu^-1 after this
     if (h->use_events) HIPCHK(h, hipEventRecord(h->evDone, s));
     h->overlap_now = false;
@@ -1740,7 +1757,16 @@ extern "C" int sgp_wait(sgp_handle* h) {
     return sync_all(h);
 }
 
+// The mirror speaks for the device when the last thing enqueued that can touch the status word is the sweep whose k_scalars wrote
+// it (mirror_epoch), that kernel has run (its epoch is in the mirror; the caller has waited for the stream) and no getter has
+// reported a give-up since.
+static bool mirror_fresh(const sgp_handle* h) {
+    return h->hMirror && h->mirror_epoch >= 0 && h->mirror_epoch == h->done_epoch && !h->sync_reported &&
+           h->hMirror[SGP_R_COUNT + 1] == (double)h->mirror_epoch;
+}
+
 static int check_sync_status(sgp_handle* h) {
+    if (mirror_fresh(h) && h->hMirror[SGP_R_COUNT] == 0.0) return 0;        // (a set word takes the slow path: message, sticky flag)
     int bits = 0;
     HIPCHK(h, hipMemcpy(&bits, h->dInfo + 3, sizeof(int), hipMemcpyDeviceToHost));
     if (bits == 0) return 0;
@@ -1787,7 +1813,8 @@ extern "C" int sgp_get_scalars(sgp_handle* h, double* out) {
     int rc = sync_all(h);
     if (rc) return rc;
     if (int src = check_sync_status(h)) return src;
-    HIPCHK(h, hipMemcpy(out, h->dOut, SGP_R_COUNT * sizeof(double), hipMemcpyDeviceToHost));
+    if (mirror_fresh(h)) memcpy(out, h->hMirror, SGP_R_COUNT * sizeof(double));
+    else HIPCHK(h, hipMemcpy(out, h->dOut, SGP_R_COUNT * sizeof(double), hipMemcpyDeviceToHost));
     if (out[SGP_R_INFO_KUU] < 0 || out[SGP_R_INFO_LAMBDA] < 0)
         return fail(h, SGP_ERR_HIP, "the persistent factorisation launch gave up waiting (deadlock guard): its workgroups were not all resident");
     if (out[SGP_R_INFO_KUU] > 0) { h->err = "K_uu is not positive definite"; return (int)out[SGP_R_INFO_KUU]; }
@@ -2125,6 +2152,7 @@ static int enqueue_theta_grad(sgp_handle* h, hipStream_t s) {
     // by side -- the K_uu half on the side stream, which idles between two sweeps -- and meet in the finishing kernel through
     // a device word (an event would cost the main stream ~6 us, see sgp_sweep_finish).
     const bool split = s == h->own && h->dJoin && !(h->cfg.flags & SGP_FLAG_GRAPH) && !h->env_grad_one_stream;
+    h->mirror_epoch = -1;                      // (the gradient's hand-offs report into the same status word)
     hipStream_t su = split ? h->side : s;
     if (split)
         hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, su, (const long long*)(h->dJoin + WORD_DONE), h->done_epoch,
@@ -2174,7 +2202,7 @@ static int theta_objective_eval(sgp_handle* h, hipStream_t s, double* value) {
     hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, s, h->dStats, (const double*)h->dTrace, (int)TRACE_BLOCKS,
                        (const double*)(h->dTrace + TRACE_BLOCKS), (int)TRACE_BLOCKS, h->dMu, h->dKuu, h->dLam, h->dInfo, h->dParams,
                        h->dOut2, h->dWishart, M, Mp, h->dout, Q, Qp, Qp - Q, (int64_t*)nullptr, (int64_t*)nullptr,
-                       (int64_t*)nullptr, (long long*)nullptr, 0LL, (const double*)nullptr, 0, (const double*)nullptr, 0);
+                       (int64_t*)nullptr, (long long*)nullptr, 0LL, (const double*)nullptr, 0, (const double*)nullptr, 0, (double*)nullptr);
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     double out[SGP_R_COUNT], sc[SGP_S_COUNT];

@@ -2671,7 +2671,10 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
                                                  double* __restrict__ wishart, int M, int Mp, int d_out, int Q, int Qp,
                                                  int lam_off, int64_t* stamps, int64_t* all_stamps,
                                                  int64_t* totals, long long* done_word, long long done_value,
-                                                 const double* __restrict__ ldK, int nldK, const double* __restrict__ ldL, int nldL) {
+                                                 const double* __restrict__ ldK, int nldK, const double* __restrict__ ldL, int nldL,
+                                                 double* __restrict__ mirror) {
+    // mirror (may be nullptr): SGP_R_COUNT + 2 doubles of PINNED HOST memory that receive out[], the hand-off status word info[3]
+    // and done_value -- what sgp_get_scalars / sgp_w_stats read after their wait instead of two blocking copies (~25 us apiece)
     // ldK / ldL (may be nullptr: then the diagonals of Lkuu / Llam are read): per-step sums of log L_cc left by the factorisation
     // launches (POTRF_LOGDET)
     // done_word (may be nullptr): set to done_value once this kernel -- the sweep's last reader of the K_uu chain's outputs --
@@ -2693,7 +2696,7 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
         if (all_stamps && tid >= 192) fold = stamp_fold_load(all_stamps, totals, tid - 192);
         // what the closing thread needs besides the five sums, fetched with everything else (not after the reduction)
         const double c_syy = sc[0], c_skk = sc[1], c_n = sc[2], c_w = P->W[0], c_sigma2 = P->sigma2, c_elogw = P->E_logw;
-        const int c_i0 = info[0], c_i1 = info[1], c_i2 = info[2];
+        const int c_i0 = info[0], c_i1 = info[1], c_i2 = info[2], c_i3 = mirror ? info[3] : 0;
         double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};         // tr(Kuu^-1 Psi2), tr(R Psi2), log|L_K|, log|L_Lambda|, b' mu
         for (int b = tid; b < nK; b += 256) v[0] += partK[b];
         for (int b = tid; b < nR; b += 256) v[1] += partR[b];
@@ -2727,6 +2730,11 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
             out[5] = (double)c_i2;
             out[6] = 2.0 * t[2];
             out[7] = 2.0 * t[3];
+            if (mirror) {
+                mirror[0] = sum_I1; mirror[1] = sum_I2; mirror[2] = out[2]; mirror[3] = (double)c_i0; mirror[4] = (double)c_i1;
+                mirror[5] = (double)c_i2; mirror[6] = 2.0 * t[2]; mirror[7] = 2.0 * t[3];
+                mirror[SGP_R_COUNT] = (double)c_i3; mirror[SGP_R_COUNT + 1] = (double)done_value;
+            }
             if (done_word)
                 __hip_atomic_store((__attribute__((address_space(1))) long long*)done_word, done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -2796,6 +2804,11 @@ __global__ void __launch_bounds__(256) k_scalars(const double* __restrict__ stat
         out[5] = (double)info[2];
         out[6] = ld_k;
         out[7] = ld_l;
+        if (mirror) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mirror[i] = out[i];
+            mirror[SGP_R_COUNT] = (double)info[3]; mirror[SGP_R_COUNT + 1] = (double)done_value;
+        }
     }
     stamp_exit(stamps);
     // last kernel of a sweep: close the sweep stamp and add this sweep's phase durations to the running totals

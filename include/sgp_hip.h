@@ -165,6 +165,8 @@ int sgp_bind_stats(sgp_handle* h, void* stats_dev);
  * sgp_get_posterior: mean_cov(qv) + meta.Uv (GPnode/UniSGPnode.jl:66-69).  Any pointer may be NULL.
  * mu_v: d_out*M; Sigma_v, Uv: (d_out*M)^2 column-major; Uv upper-triangular with Uv' Uv = Sigma_v + mu mu'. */
 int sgp_get_posterior(sgp_handle* h, double* mu_v, double* Sigma_v, double* Uv);
+/* (sgp_get_scalars waits for the handle's work, polled, and then reads a pinned block the sweep's last kernel wrote the scalars and the
+ * hand-off status to -- no device-to-host copy behind the wait; SGP_NO_ZERO_COPY=1 restores the copies) */
 int sgp_get_scalars(sgp_handle* h, double* out /* SGP_R_COUNT */);
 /* sgp_get_stats: the reduced statistics (tests, theta-gradient): Psi2 M x M, B M x d_out, scalars SGP_S_COUNT */
 int sgp_get_stats(sgp_handle* h, double* Psi2, double* B, double* scalars);

@@ -15,20 +15,19 @@ for name, N, M, D in (("T", 10000, 512, 8), ("C4", 4000, 128, 2)):
         dev.set_prior_isotropic(50.0); dev.set_noise([[10.0]])
         for _ in range(20):
             dev.sweep(); dev.w_stats()
-        reps = 200
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            dev.sweep(); dev.scalars()
-        t_sweep = (time.perf_counter() - t0) / reps
+        # every figure: the median of 5 blocks of 40 (the host thread of a shared box loses a 10 ms tick now and then, A/B log [35])
+        def timed(body, blocks=5, reps=40):
+            ts = []
+            for _ in range(blocks):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    body()
+                ts.append((time.perf_counter() - t0) / reps)
+            return float(np.median(ts))
+        t_sweep = timed(lambda: (dev.sweep(), dev.scalars()))
         dev.sweep(); dev.scalars()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            dev.w_stats()
-        t_w = (time.perf_counter() - t0) / reps
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            dev.sweep(); dev.w_stats()
-        t_both = (time.perf_counter() - t0) / reps
+        t_w = timed(dev.w_stats)
+        t_both = timed(lambda: (dev.sweep(), dev.w_stats()))
         q = dev.time_kernel(_lib.SGP_TIME_QUADFORM, 20)
         print(f"{name}: sweep + get_scalars (one at a time) {1e6 * t_sweep:.1f} us | w_stats alone {1e6 * t_w:.1f} us (the quadratic-form kernel {q:.1f} us) | "
               f"sweep + w_stats {1e6 * t_both:.1f} us = {1 / t_both:.0f} it/s")
