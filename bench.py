@@ -199,6 +199,16 @@ def main():
                     help="back-to-back timed blocks of --steps sweeps each (default 15, 5 at N > 1e5); the MEDIAN block is reported")
     args = ap.parse_args()
 
+    # Host side of this rank on the CPUs of the GPU's NUMA node, before torch or HIP create a thread (what numactl --cpunodebind
+    # does; gaussianprocessnode_amd/hostbind.py says why: an unconfined process on a two-socket host runs its short blocks 6 % slower
+    # one start in four).  Loaded by path: importing the package would load the HIP runtime first.
+    import importlib.util
+    _spec = importlib.util.spec_from_file_location("_sgp_hostbind", os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                                 "gaussianprocessnode_amd", "hostbind.py"))
+    hostbind = importlib.util.module_from_spec(_spec)
+    _spec.loader.exec_module(hostbind)
+    host_binding = hostbind.bind_to_gpu_node(0 if os.environ.get("SGP_BENCH_REHEARSAL") is not None else int(os.environ.get("LOCAL_RANK", "0")))
+
     import torch
     import torch.distributed as dist
     from gaussianprocessnode_amd import _lib
@@ -217,6 +227,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    if host_binding["how"] != "none":
+        # check the guess against the runtime's own answer (enumeration orders can differ); correct every thread if it was wrong
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+            host_binding["runtime_bdf"] = bdf
+            if node >= 0 and node != host_binding["node"] and hostbind.rebind_all_threads(node):
+                host_binding.update(node=node, how="gpu (corrected after the runtime started)")
+        except (OSError, AttributeError, ValueError):
+            pass
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
@@ -353,6 +374,7 @@ def main():
                    "collective": {"backend": sweep.backend, "world_size_seen": sweep.world,
                                   "where": "inside sgp_sweep (C ABI all-reduce hook) on the sweep's stream" if sweep.hooked
                                            else "none (single rank)"}},
+        "host_binding": host_binding,
         "sclk_mhz": sclk.value,
         "sclk_mhz_under_mfma_f64": sclk_mfma,
         "roofline": {"kernel": "k_syrk_direct (Psi2 = K_uf K_uf^T, v_mfma_f64_16x16x4_f64, operands straight from global memory; k_syrk_stream where the SYRK does not fill the chip)", "bound": "mfma",

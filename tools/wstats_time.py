@@ -4,6 +4,10 @@ finished sweep, and of the two in a loop, at T and at the banana shape.    pytho
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib.util
+_spec = importlib.util.spec_from_file_location("_sgp_hostbind", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussianprocessnode_amd", "hostbind.py"))
+_hb = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_hb)
+print("host binding:", _hb.bind_to_gpu_node(0))       # (before the HIP runtime starts: see hostbind.py)
 import gaussianprocessnode_amd as G
 from gaussianprocessnode_amd import _lib
 
