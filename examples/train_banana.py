@@ -19,6 +19,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from gaussianprocessnode_amd import hostbind  # noqa: E402
+
+hostbind.bind_to_gpu_node(0)      # the host side on the GPU's NUMA node, before the HIP runtime starts
 
 
 def run(epochs=500, batch=200, device_paced=True):

@@ -686,6 +686,51 @@ def test_direct_syrk_ragged_chunks_and_point_weights(G, N, weighted):
     np.testing.assert_allclose(I2, rI2, rtol=1e-6, atol=1e-8 * float(np.max(rI2)))
 
 
+def _sc(dev):
+    import dataclasses
+    return np.array(dataclasses.astuple(dev.scalars()), dtype=float)
+
+
+@pytest.mark.parametrize("N,M,D", [(10000, 512, 8), (4000, 128, 2)])
+def test_one_sweep_at_a_time_is_bitwise_the_back_to_back_sweep(G, N, M, D):
+    """A caller that fetches something after every sweep (sgp_get_scalars / sgp_w_stats between two sgp_sweep calls) gets the two
+    chains' launches enqueued alternately from the third such sweep on, and its scalars through the pinned mirror k_scalars writes:
+    posterior, scalars and per-point quantities are bitwise those of the plain host order (SGP_INTERLEAVE=0) and of the copies
+    (SGP_NO_ZERO_COPY=1), and the scalars equal what sgp_get_posterior's own status check and a later getter see."""
+    X, Xu, y, _ = synth(N, M, D, seed=5)
+    s2, ell, w = 0.9, np.linspace(1.5, 3.0, D), 50.0
+    out = {}
+    for mode, env in (("auto", {}), ("never", {"SGP_INTERLEAVE": "0"}), ("always", {"SGP_INTERLEAVE": "1"}), ("copies", {"SGP_NO_ZERO_COPY": "1"})):
+        os.environ.update(env)
+        try:
+            with G.SGPDevice(N, M, D, keep_kuf=True) as dev:
+                dev.set_inducing(Xu); dev.set_data(X, y); dev.set_kernel(s2, ell, 1e-8)
+                dev.set_prior_isotropic(50.0); dev.set_noise([[w]])
+                sc = []
+                for it in range(6):                     # one at a time: the streak reaches three
+                    dev.sweep()
+                    sc.append(_sc(dev) if it % 2 == 0 else np.concatenate(dev.w_stats())[:8])
+                final = _sc(dev)
+                again = _sc(dev)          # (a second getter without a sweep in between)
+                assert np.array_equal(final, again)
+                dev.sweep(); dev.sweep()                # back to back, then one fetch
+                out[mode] = (sc, final, _sc(dev), dev.posterior(), dev.w_stats())
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    ref = out["never"]
+    for mode in ("auto", "always", "copies"):
+        got = out[mode]
+        for a, b in zip(got[0], ref[0]):
+            assert np.array_equal(a, b), mode
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), mode
+        for a, b in zip(got[3], ref[3]):
+            assert np.array_equal(a, b), mode
+        for a, b in zip(got[4], ref[4]):
+            assert np.array_equal(a, b), mode
+    assert np.array_equal(ref[1], ref[2])              # (same inputs: every sweep gives the same scalars)
+
+
 def test_full_size_configs_and_size_independent_properties(G):
     """BASELINE's full sizes: C3 (N = 40 000, M = 512, D = 8) against the oracle, plus properties that hold at any size:
     statistics are additive over a split and invariant under a permutation of the points; at N = 10^6 (4 GB of K_uf) the

@@ -2,6 +2,7 @@
 """Sweep rate against the "the SYRK fills the chip" threshold (SGP_GATE_MIN: points x lower tiles from which the K_uu chain is gated
 behind the SYRK, the SYRK is k_syrk_direct and the overlapped order is considered) for problem shapes around the threshold."""
 import os, sys, time
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _bind  # noqa: E401,E702  (NUMA node of the GPU first)
 import numpy as np
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import gaussianprocessnode_amd as G

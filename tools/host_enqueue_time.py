@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Host time of sgp_sweep at T: how long does the host need to enqueue one sweep, and how does a block of 20 sweeps unfold?"""
 import os, sys, time
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _bind  # noqa: E401,E702  (NUMA node of the GPU first)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

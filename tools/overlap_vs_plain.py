@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Sweep rate with the planner's choice against the plain order (SGP_OVERLAP=0) for a list of shapes."""
 import os, sys, time
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _bind  # noqa: E401,E702  (NUMA node of the GPU first)
 import numpy as np
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import gaussianprocessnode_amd as G

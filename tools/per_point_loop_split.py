@@ -2,6 +2,7 @@
 """Per-point loop (sgp_sweep; sgp_w_stats) at T and C4: where an iteration's wall time goes on the host (the enqueue of the sweep,
 the blocking call), eager (overlapped order) against a captured graph (plain order), and the sweep alone after a wait."""
 import os, sys, time
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _bind  # noqa: E401,E702  (NUMA node of the GPU first)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaussianprocessnode_amd import SGPDevice

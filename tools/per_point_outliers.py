@@ -2,6 +2,7 @@
 """Per-iteration wall times of the per-point loop (sgp_sweep; sgp_w_stats) and of (sgp_sweep; sgp_wait) at T: how often an iteration
 takes much longer than the median, how long, and in which call."""
 import gc, os, sys, time
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _bind  # noqa: E401,E702  (NUMA node of the GPU first)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaussianprocessnode_amd import SGPDevice
