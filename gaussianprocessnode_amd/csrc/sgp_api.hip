@@ -203,13 +203,10 @@ struct sgp_handle {
     int env_syrk_wt = 0;           // SGP_SYRK_WT (see plan_overlap)
     bool env_syrk_wide = true;     // SGP_SYRK_WIDE=0: the 256-thread SYRK everywhere (A/B switch)
     bool defer_request = false, kuu_deferred = false;   // the K_uu chain's steps enqueued alternately with the Lambda chain's (sgp_sweep, see enqueue_finish1)
-    int env_interleave = -1;        // SGP_INTERLEAVE: the two chains' launches enqueued alternately -- 1 always, 0 never, unset: for a caller that runs
-                                    // ONE SWEEP AT A TIME (solo_streak), where every sweep starts on an idle device and the Lambda chain otherwise waits
-                                    // for the host to get through the K_uu chain's 14 launches.  Back to back the host is a sweep ahead, alternating
-                                    // streams only costs it ~20 us -- and a process that mixes the two orders runs its back-to-back blocks 6 % slower
-                                    // one time in four (profiles/r04_ab_log.txt [37]), hence the streak and not the idle device alone
-    bool idle_hint = false;         // a blocking call has just returned: nothing of this handle is queued on the device
-    int solo_streak = 0;            // sweeps in a row that were each followed by a blocking call before the next one
+    bool env_interleave = true;     // the K_uu chain's and the Lambda chain's launches enqueued alternately (SGP_INTERLEAVE=0: chain after chain).  A sweep
+                                    // that starts on an idle device -- the first of a block, every sweep of a caller that fetches something in between --
+                                    // otherwise has its Lambda chain wait for the host to get through the other chain's 14 launches; once the host is a
+                                    // sweep ahead the order makes no difference (profiles/r04_ab_log.txt [30], [37], [38])
     bool env_no_zero_copy = false; // SGP_NO_ZERO_COPY=1: sgp_w_stats copies its results back instead of writing them to pinned memory (A/B switch)
     int64_t gate_min = 10000;      // points x lower tiles from which the SYRK is taken to fill the chip (SGP_GATE_MIN: A/B switch; see set_point_count)
     bool syrk_wide = false;        // the resident problem's SYRK launches are k_syrk_direct (set_point_count)
@@ -601,7 +598,7 @@ extern "C" int sgp_create(const sgp_config* cfg, sgp_handle** out) {
         if (const char* sw = getenv("SGP_SYRK_WIDE")) h->env_syrk_wide = atoi(sw) != 0;
         if (const char* gm = getenv("SGP_GATE_MIN")) h->gate_min = atoll(gm);
         if (const char* zc = getenv("SGP_NO_ZERO_COPY")) h->env_no_zero_copy = atoi(zc) != 0;
-        if (const char* ni = getenv("SGP_INTERLEAVE")) h->env_interleave = atoi(ni) != 0 ? 1 : 0;
+        if (const char* ni = getenv("SGP_INTERLEAVE")) h->env_interleave = atoi(ni) != 0;
         if (const char* oc = getenv("SGP_OVERLAP_COLS"))
             for (const char* q = oc; *q;) {
                 h->env_overlap_cols.push_back(atoi(q));
@@ -1136,7 +1133,6 @@ extern "C" int sgp_carry_posterior(sgp_handle* h, void* stream) {
     HIPCHK(h, hipGetLastError());
     h->prior_form = 1;
     h->in_flight = true;                       // (asynchronous: a following setter must wait for it before it touches the prior)
-    h->idle_hint = false;
     h->mirror_epoch = -1;
     return 0;
 }
@@ -1501,7 +1497,6 @@ static int sweep_local_impl(sgp_handle* h, void* stream, bool overlapped) {
         h->sync_reported = false;
     }
     h->in_flight = true;
-    h->idle_hint = false;
     h->overlap_now = overlapped;
     // The K_uu chain depends on theta and Xu only: it starts on the (low-priority) side stream as soon as the previous
     // sweep has finished with its outputs, runs beside the data-sized kernels, the all-reduce and the Lambda chain, and is
@@ -1624,9 +1619,7 @@ extern "C" int sgp_sweep(sgp_handle* h, void* stream) {
     // (with an all-reduce hook as well: one reduce per statistics group, see enqueue_stats_overlapped)
     const bool overlapped = h->overlap && !stream && h->n > 0 && !h->training;
     h->pack_now = h->allreduce != nullptr;
-    h->solo_streak = h->idle_hint ? h->solo_streak + 1 : 0;
-    h->idle_hint = false;
-    h->defer_request = h->env_interleave == 1 || (h->env_interleave < 0 && h->solo_streak >= 3);
+    h->defer_request = h->env_interleave;
     int rc = sweep_local_impl(h, stream, overlapped);
     h->defer_request = false;
     h->pack_now = false;
@@ -1756,7 +1749,6 @@ static int sync_all(sgp_handle* h) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, drain_device(h));
     h->in_flight = false;
-    h->idle_hint = true;
     return 0;
 }
 
@@ -2064,7 +2056,6 @@ extern "C" int sgp_w_stats(sgp_handle* h, double* I1, double* I2, void* stream) 
                        h->has_yv ? h->dYv : nullptr, staged ? h->hStage : dI1, staged ? h->hStage + n : dI2, h->dParams, h->T, n);
     HIPCHK(h, wait_stream(s));
     HIPCHK(h, hipGetLastError());
-    h->idle_hint = s == h->own && h->last_stream == h->own;     // (the sweep's other streams were joined in front of its tail)
     if (int src = check_sync_status(h)) return src;          // (the sweep whose q(v) these are: a hand-off that gave up voids them too)
     if (staged) {
         if (I1) memcpy(I1, h->hStage, sizeof(double) * n);

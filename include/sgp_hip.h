@@ -312,10 +312,10 @@ int sgp_time_kernel(sgp_handle* h, int32_t which, int32_t iters, void* stream, d
  * workgroup per CU, no LDS staging; SGP_SYRK_WIDE=0: the LDS-staged k_syrk_stream everywhere) and the K_uu chain is held back
  * until its single round is resident.  The planner places one cut, or two from six tile columns on while the masked launches
  * are short; a data-sharded sweep (hook installed) keeps one cut -- every group is a collective.
- * Host order of the launches: a caller that runs one sweep at a time (three sgp_sweep calls in a row each followed by a blocking
- * call of this handle) gets the launches of the K_uu chain and of the Lambda chain enqueued alternately -- a sweep that starts on an
- * idle device then does not have its Lambda chain wait for the host to get through the other chain's 14 launches; back-to-back
- * sweeps keep chain after chain (SGP_INTERLEAVE=0 never / 1 always).  Same kernels, same results either way. */
+ * Host order of the launches: sgp_sweep on the library's streams enqueues the launches of the K_uu chain and of the Lambda chain
+ * alternately -- a sweep that starts on an idle device (the first of a block, every sweep of a caller that fetches something in
+ * between) then does not have its Lambda chain wait for the host to get through the other chain's 14 launches; once the host is a
+ * sweep ahead the order makes no difference (SGP_INTERLEAVE=0: chain after chain).  Same kernels, same results either way. */
 int sgp_overlap_plan(const sgp_handle* h, int32_t* ngroups, int32_t* info /* 8 per group, up to 8 groups; may be NULL */);
 
 #ifdef __cplusplus

@@ -693,21 +693,21 @@ def _sc(dev):
 
 @pytest.mark.parametrize("N,M,D", [(10000, 512, 8), (4000, 128, 2)])
 def test_one_sweep_at_a_time_is_bitwise_the_back_to_back_sweep(G, N, M, D):
-    """A caller that fetches something after every sweep (sgp_get_scalars / sgp_w_stats between two sgp_sweep calls) gets the two
-    chains' launches enqueued alternately from the third such sweep on, and its scalars through the pinned mirror k_scalars writes:
+    """A caller that fetches something after every sweep (sgp_get_scalars / sgp_w_stats between two sgp_sweep calls) gets its scalars
+    through the pinned mirror k_scalars writes, and sgp_sweep enqueues the two chains' launches alternately:
     posterior, scalars and per-point quantities are bitwise those of the plain host order (SGP_INTERLEAVE=0) and of the copies
     (SGP_NO_ZERO_COPY=1), and the scalars equal what sgp_get_posterior's own status check and a later getter see."""
     X, Xu, y, _ = synth(N, M, D, seed=5)
     s2, ell, w = 0.9, np.linspace(1.5, 3.0, D), 50.0
     out = {}
-    for mode, env in (("auto", {}), ("never", {"SGP_INTERLEAVE": "0"}), ("always", {"SGP_INTERLEAVE": "1"}), ("copies", {"SGP_NO_ZERO_COPY": "1"})):
+    for mode, env in (("default", {}), ("never", {"SGP_INTERLEAVE": "0"}), ("copies", {"SGP_NO_ZERO_COPY": "1"})):
         os.environ.update(env)
         try:
             with G.SGPDevice(N, M, D, keep_kuf=True) as dev:
                 dev.set_inducing(Xu); dev.set_data(X, y); dev.set_kernel(s2, ell, 1e-8)
                 dev.set_prior_isotropic(50.0); dev.set_noise([[w]])
                 sc = []
-                for it in range(6):                     # one at a time: the streak reaches three
+                for it in range(6):                     # one at a time
                     dev.sweep()
                     sc.append(_sc(dev) if it % 2 == 0 else np.concatenate(dev.w_stats())[:8])
                 final = _sc(dev)
@@ -719,7 +719,7 @@ def test_one_sweep_at_a_time_is_bitwise_the_back_to_back_sweep(G, N, M, D):
             for k in env:
                 os.environ.pop(k, None)
     ref = out["never"]
-    for mode in ("auto", "always", "copies"):
+    for mode in ("default", "copies"):
         got = out[mode]
         for a, b in zip(got[0], ref[0]):
             assert np.array_equal(a, b), mode
