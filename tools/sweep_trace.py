@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of ONE sweep from in-kernel stamps (variant library built with -DSGP_SWEEP_TRACE): how the statistics streams, the
 Lambda chain and the K_uu chain of an (overlapped) sweep really interleave -- without a profiler slowing the host's launches.
-    python tools/sweep_trace.py [N M D] [sweeps]        (SGP_OVERLAP / SGP_OVERLAP_COLS as for the library)"""
+    python tools/sweep_trace.py [N M D] [sweeps]        (SGP_OVERLAP / SGP_OVERLAP_COLS as for the library; SGP_TRACE_SOLO=1: a fetch after every sweep)"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,8 +25,11 @@ dev.set_kernel(bench.SIGMA2, bench.ELL[:D] if D <= len(bench.ELL) else np.full(D
 dev.set_prior_isotropic(bench.PRIOR_VAR)
 dev.set_noise([[bench.W_BAR]])
 print("plan:", dev.overlap_plan())
+solo = os.environ.get("SGP_TRACE_SOLO") is not None      # one sweep at a time: the traced (last) sweep starts on an idle device
 for _ in range(sweeps):
     dev.sweep()
+    if solo:
+        dev.scalars()
 sc = dev.scalars()
 buf = (C.c_int64 * (256 * 65))()
 _lib.check(lib.sgp_get_sweep_trace(buf), None, "sgp_get_sweep_trace", lib=lib)
